@@ -1,0 +1,173 @@
+/*
+ * pn2.h -- C ABI of libpn2_hip.so: the PointNet++ set-abstraction / feature-propagation
+ * hot path as hand-written gfx950 (MI355X) HIP kernels.
+ *
+ * The reference (Jiang-Muyun/PointNet12) has no FFI: its hot path is 314 lines of ATen
+ * calls in model/pointnet_util.py.  This library sits BELOW a Python mirror of that file
+ * (pointnet12_amd/pointnet_util.py); every entry point names the reference lines whose
+ * ATen op sequence it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add to call these from the original file.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; tensors are dense row-major
+ *     with the shapes given; float = IEEE fp32; indices = int64 (torch.long at the API);
+ *   - the caller owns all memory (no allocation, no retained pointers, no global state);
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - return value: PN2_OK (0) or a negative PN2_E* code (pn2_error_string() names it);
+ *     launch errors are reported through hipGetLastError() as PN2_ELAUNCH;
+ *   - results: index outputs are bit-identical to the reference's CPU results (the fp32
+ *     expression forms are pinned in oracle/pn2_oracle.c); float outputs agree to 1e-5.
+ */
+#ifndef PN2_H
+#define PN2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN2_ABI_VERSION 1
+
+#define PN2_OK 0
+#define PN2_EINVAL (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define PN2_ELAUNCH (-2)    /* hipLaunch / hipMemsetAsync failed */
+#define PN2_EUNSUPPORTED (-3)
+
+typedef void *pn2_stream_t;
+
+int pn2_version(void);
+const char *pn2_error_string(int code);
+
+/* ------------------------------------------------------------------ geometry (index-exact) */
+
+/* farthest_point_sample, model/pointnet_util.py:63-84 (the npoint-iteration Python loop).
+ * xyz [B,N,3]; start [B] = the randint draw of :75 (host code owns the RNG);
+ * out_idx [B,npoint].  work: caller scratch of pn2_fps_workspace_bytes(B,N) bytes (may be
+ * NULL when that is 0).  Distance form ((dx*dx+dy*dy)+dz*dz) un-fused, argmax ties to the
+ * lowest index. */
+int64_t pn2_fps_workspace_bytes(int B, int N);
+int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out_idx,
+            void *work, pn2_stream_t stream);
+
+/* query_ball_point, model/pointnet_util.py:87-107 (dense [B,S,N] distance matrix + sort).
+ * xyz [B,N,3], new_xyz [B,S,3], r2 = float32(radius**2); out_idx [B,S,nsample]: the first
+ * nsample indices with !(d > r2) in ascending order, padded with the first; N everywhere
+ * for an empty ball (the reference's tensor at :107). */
+int pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int nsample,
+                   int64_t *out_idx, pn2_stream_t stream);
+
+/* square_distance, model/pointnet_util.py:19-40. src [B,S,3], dst [B,N,3] -> out [B,S,N]. */
+int pn2_square_distance(const float *src, const float *dst, int B, int S, int N, float *out, pn2_stream_t stream);
+
+/* 3-NN search + inverse-distance weights, model/pointnet_util.py:295-300 (dense matrix +
+ * full sort + clamp 1e-10 + reciprocal + normalise).  xyz1 [B,N,3], xyz2 [B,S,3], S >= 3.
+ * idx [B,N,3], dist [B,N,3] (raw, unclamped, ascending), weight [B,N,3]. Ties -> lower index. */
+int pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int64_t *idx, float *dist,
+                 float *weight, pn2_stream_t stream);
+
+/* ------------------------------------------------------------------ gathers / scatters */
+
+/* index_points, model/pointnet_util.py:43-60.  points [B,N,C], idx [B,M] -> out [B,M,C].
+ * err (device int, may be NULL): set to 1 if any index is outside [0,N) (the reference raises
+ * IndexError); offending rows are written as zeros. */
+int pn2_gather_rows(const float *points, const int64_t *idx, int B, int N, int C, int M, float *out, int *err,
+                    pn2_stream_t stream);
+/* backward of the above: grad_points [B,N,C] += scatter of grad_out [B,M,C] (caller zeroes). */
+int pn2_gather_rows_bwd(const float *grad_out, const int64_t *idx, int B, int N, int C, int M, float *grad_points,
+                        pn2_stream_t stream);
+
+/* Grouping of sample_and_group (:127-133) and of the MSG loop (:243-251): gather K
+ * neighbours, subtract the centroid from xyz, concatenate with the D features.
+ * xyz [B,N,3], points [B,N,D] or NULL (D = 0), new_xyz [B,S,3], idx [B,S,K].
+ * out [B*S*K, ld] position-major rows, ld >= 3+D; row = [xyz-c, feat] if xyz_first (SSG, :131)
+ * else [feat, xyz-c] (MSG, :247); columns 3+D..ld-1 are zero.  new_xyz == NULL means
+ * "do not centre" (sample_and_group_all, :140-157, with idx = arange). */
+int pn2_group(const float *xyz, const float *points, const float *new_xyz, const int64_t *idx, int B, int N, int S,
+              int K, int D, int xyz_first, int ld, float *out, int *err, pn2_stream_t stream);
+/* backward: grad_points [B,N,D] += feature columns of grad_rows [B*S*K, ld] (caller zeroes). */
+int pn2_group_bwd(const float *grad_rows, const int64_t *idx, int B, int N, int S, int K, int D, int xyz_first,
+                  int ld, float *grad_points, pn2_stream_t stream);
+
+/* Inverse-distance interpolation, model/pointnet_util.py:301: out[b,n,col0+c] =
+ * ((p2[i0,c]*w0 + p2[i1,c]*w1) + p2[i2,c]*w2).  points2 [B,S,D]; out rows of pitch ld
+ * (so the result lands directly inside the concatenated FP input, :305). */
+int pn2_three_interp(const float *points2, const int64_t *idx, const float *weight, int B, int N, int S, int D,
+                     float *out, int ld, int col0, pn2_stream_t stream);
+/* backward: grad_points2 [B,S,D] += w_k * grad_out[b,n,col0+c] (caller zeroes). */
+int pn2_three_interp_bwd(const float *grad_out, int ld, int col0, const int64_t *idx, const float *weight, int B,
+                         int N, int S, int D, float *grad_points2, pn2_stream_t stream);
+
+/* Strided 2-D copy: dst[r, dcol0 + c] = src[r, scol0 + c], r < rows, c < cols (the cat of :305,
+ * and its backward split). */
+int pn2_copy_cols(const float *src, int lds, int scol0, float *dst, int ldd, int dcol0, int64_t rows, int cols,
+                  pn2_stream_t stream);
+
+/* ------------------------------------------------------------------ shared MLP (1x1 conv + BN + ReLU [+ max])
+ *
+ * Position-major activations: one grouped position per row, P = B*S*K rows (B*N for FP).
+ * Replaces nn.Conv2d/Conv1d(k=1) + nn.BatchNorm2d/1d + F.relu (+ torch.max over K),
+ * model/pointnet_util.py:194-199, :251-256, :309-312, and their autograd.
+ *
+ * Per-channel "affine" blocks are float[4*C] arrays written by pn2_bn_finalize:
+ *   [0..C) mean   [C..2C) scale = gamma*invstd   [2C..3C) beta   [3C..4C) invstd
+ * and relu((y-mean)*scale+beta) is applied on the fly wherever a pre-BN tensor is consumed.
+ */
+
+/* Y[P,N] = act(X)[P,K] * W[N,K]^T + bias.  X has row pitch ldx (>= K, multiple of 4, pad
+ * columns zero), W row pitch ldw (>= K, multiple of 4, pad columns zero), Y pitch ldy
+ * (multiple of 4).  in_affine: NULL (X is used as is) or the affine block (4*ldx floats) of
+ * the layer that produced X.  stats: NULL or double[2*N] (caller zeroes) receiving
+ * sum(y) and sum(y*y) per output channel over the P rows (training-mode BN statistics). */
+int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias,
+                    float *Y, int ldy, int64_t P, int K, int N, double *stats, pn2_stream_t stream);
+
+/* BatchNorm statistics -> affine block.  training != 0: mean/var (biased) from stats/P,
+ * running_mean/var (may be NULL) updated with `momentum` and the unbiased variance,
+ * *num_batches_tracked (may be NULL) incremented.  training == 0: running statistics are used. */
+int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, const float *beta, float eps,
+                    float momentum, int training, float *running_mean, float *running_var,
+                    int64_t *num_batches_tracked, float *affine, pn2_stream_t stream);
+
+/* out[g,c] = max_k relu(bn(Y[g*K+k, c])), arg[g,c] = first k attaining it (K = 1: plain
+ * BN+ReLU, arg may be NULL).  Y pitch ldy, out pitch ldo. */
+int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int K, int C, float *out, int ldo,
+                    int32_t *arg, pn2_stream_t stream);
+
+/* Backward, last layer after max-pool: red[0..C) = sum dZ, red[C..2C) = sum dZ*yhat with
+ * dZ[g*K+k,c] = (k==arg[g,c] && out[g,c]>0) ? dOut[g,c] : 0.   red is double[2*C], caller zeroes. */
+int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
+                        const float *affine, int64_t G, int K, int C, double *red, pn2_stream_t stream);
+/* Backward, dense (FP) last layer: dZ = dOut * (out > 0) written to dZ [P, ldz]; same reductions. */
+int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,
+                        int64_t P, int C, float *dZ, int ldz, double *red, pn2_stream_t stream);
+
+/* Per-channel BN-backward coefficients from the reductions: coef float[4*C] =
+ * [c0 = gamma*invstd, q1 = -c0*invstd*red1/P, q0 = -c0*red0/P, mean]; dgamma = red1, dbeta = red0.
+ * dY = c0*dZ + q1*(y-mean) + q0.  use_batch_stats == 0 (eval-mode BN): q1 = q0 = 0. */
+int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, const float *affine,
+                    int use_batch_stats, float *coef, float *dgamma, float *dbeta, pn2_stream_t stream);
+
+/* dgrad: dXact[P,N] = dY[P,K] * Wt[N,K]^T with dY formed on the fly from (dZ or the pooled
+ * pair dOut/arg, Y, coef); K = C_l, N = C_{l-1}; Wt = W^T padded to pitch ldw.
+ *   dZ != NULL: dense dZ [P, ldz];  dZ == NULL: pooled form (dOut [G,ldo], out, arg, Kpool).
+ * Epilogue, prev_Y != NULL: dZprev = dXact * (bn_relu(prev_Y) > 0) -> dXout, and
+ *   prev_red (double[2*N], caller zeroes) += sum dZprev, sum dZprev*yhat_prev;
+ * prev_Y == NULL (first layer): dXout = dXact. */
+int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dOut, int ldo, const float *out, const int32_t *arg,
+                      int Kpool, const float *Y, int ldy, const float *coef, const float *Wt, int ldw,
+                      const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
+                      double *prev_red, int64_t P, int K, int N, pn2_stream_t stream);
+
+/* wgrad: dW[M,N] (pitch lddw, caller zeroes) += sum_p dY[p,m] * Xact[p,n]; M = C_l, N = C_{l-1}.
+ * dY formed as in dgrad; Xact = bn_relu(prev_Y) when prev_affine != NULL, else X as is.
+ * dbias (may be NULL, caller zeroes) += sum_p dY[p,m]. */
+int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dOut, int ldo, const float *out, const int32_t *arg,
+                      int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
+                      const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
+                      pn2_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PN2_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libpn2_hip.so (the C ABI declared in include/pn2.h).
+
+The HIP library is the only compute path of this package: if it is missing or a symbol
+cannot be resolved this module raises -- there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpn2_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/pn2.h one to one (tests check the header against this table)
+SIGNATURES = {
+    "pn2_version": (_i, []),
+    "pn2_error_string": (ctypes.c_char_p, [_i]),
+    "pn2_fps_workspace_bytes": (_i64, [_i, _i]),
+    "pn2_fps": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "pn2_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "pn2_square_distance": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pn2_three_nn": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pn2_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pn2_gather_rows_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "pn2_group": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pn2_group_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "pn2_three_interp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "pn2_three_interp_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "pn2_copy_cols": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
+    "pn2_conv1x1_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
+    "pn2_bn_finalize": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pn2_bn_relu_max": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
+    "pn2_pool_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp]),
+    "pn2_relu_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp]),
+    "pn2_bn_bwd_coef": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pn2_conv1x1_dgrad": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp,
+                               _i64, _i, _i, _vp]),
+    "pn2_conv1x1_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
+                               _i64, _i, _i, _vp]),
+}
+
+
+class Pn2Error(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libpn2_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library and bind every symbol of SIGNATURES; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Pn2Error("libpn2_hip.so not found at %s -- build it with `python -c \"import __graft_entry__ as g; "
+                       "g.build()\"` (hipcc, gfx950). There is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pn2_version() != 1:
+        raise Pn2Error("libpn2_hip.so ABI version %d, expected 1" % lib.pn2_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise Pn2Error("%s failed: %s (%d)" % (what, load().pn2_error_string(rc).decode(), rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

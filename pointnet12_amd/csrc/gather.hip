@@ -1,0 +1,205 @@
+// Row gathers / scatters around the shared MLP: index_points, grouping, 3-point interpolation.
+// All of these are HBM/L2-bandwidth work: one lane per output element, consecutive lanes on
+// consecutive channels of one source row so every wave moves contiguous row segments.
+#include "pn2_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// index_points (pointnet_util.py:58-59): out[b,m,:] = points[b, idx[b,m], :]
+__global__ __launch_bounds__(TPB) void gather_rows_kernel(const float *__restrict__ points,
+                                                          const int64_t *__restrict__ idx, int N, int C, int M,
+                                                          int64_t total, float *__restrict__ out,
+                                                          int *__restrict__ err) {
+    int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= total) return;
+    int c = (int)(e % C);
+    int64_t r = e / C;            // b*M + m
+    int64_t b = r / M;
+    int64_t j = idx[r];
+    float v = 0.f;
+    if (j >= 0 && j < N) v = points[(b * N + j) * C + c];
+    else if (err) *err = 1;
+    out[e] = v;
+}
+
+__global__ __launch_bounds__(TPB) void gather_rows_bwd_kernel(const float *__restrict__ grad_out,
+                                                              const int64_t *__restrict__ idx, int N, int C, int M,
+                                                              int64_t total, float *__restrict__ grad_points) {
+    int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= total) return;
+    int c = (int)(e % C);
+    int64_t r = e / C;
+    int64_t b = r / M;
+    int64_t j = idx[r];
+    if (j >= 0 && j < N) atomicAdd(grad_points + (b * N + j) * C + c, grad_out[e]);
+}
+
+// Grouping (pointnet_util.py:127-133 / :243-251): row p = (b,s,k) of the position-major
+// matrix = [xyz[j]-centre, feat[j]] or [feat[j], xyz[j]-centre], zero padded to ld.
+__global__ __launch_bounds__(TPB) void group_kernel(const float *__restrict__ xyz, const float *__restrict__ points,
+                                                    const float *__restrict__ new_xyz,
+                                                    const int64_t *__restrict__ idx, int N, int S, int K, int D,
+                                                    int xyz_first, int ld, int64_t total, float *__restrict__ out,
+                                                    int *__restrict__ err) {
+    int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= total) return;
+    int c = (int)(e % ld);
+    int64_t p = e / ld;           // (b*S + s)*K + k
+    int64_t g = p / K;            // b*S + s
+    int64_t b = g / S;
+    int64_t j = idx ? idx[p] : (p % K);
+    float v = 0.f;
+    if (j < 0 || j >= N) {
+        if (err) *err = 1;
+    } else if (c < 3 + D) {
+        int cx = xyz_first ? c : c - D;          // position inside the xyz triple, if any
+        if (cx >= 0 && cx < 3) {
+            v = xyz[(b * N + j) * 3 + cx];
+            if (new_xyz) v = v - new_xyz[g * 3 + cx];
+        } else {
+            int cf = xyz_first ? c - 3 : c;
+            v = points[(b * N + j) * D + cf];
+        }
+    }
+    out[e] = v;
+}
+
+__global__ __launch_bounds__(TPB) void group_bwd_kernel(const float *__restrict__ grad_rows,
+                                                        const int64_t *__restrict__ idx, int N, int S, int K, int D,
+                                                        int xyz_first, int ld, int64_t total,
+                                                        float *__restrict__ grad_points) {
+    int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;   // over P * D feature elements
+    if (e >= total) return;
+    int cf = (int)(e % D);
+    int64_t p = e / D;
+    int64_t b = p / ((int64_t)S * K);
+    int64_t j = idx ? idx[p] : (p % K);
+    if (j < 0 || j >= N) return;
+    float gval = grad_rows[p * ld + (xyz_first ? 3 + cf : cf)];
+    atomicAdd(grad_points + (b * N + j) * D + cf, gval);
+}
+
+// pointnet_util.py:301: interpolated[b,n,c] = ((p2[i0,c]*w0 + p2[i1,c]*w1) + p2[i2,c]*w2)
+__global__ __launch_bounds__(TPB) void three_interp_kernel(const float *__restrict__ points2,
+                                                           const int64_t *__restrict__ idx,
+                                                           const float *__restrict__ w, int N, int S, int D,
+                                                           int64_t total, float *__restrict__ out, int ld, int col0) {
+    int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= total) return;
+    int c = (int)(e % D);
+    int64_t r = e / D;            // b*N + n
+    int64_t b = r / N;
+    const int64_t *i3 = idx + r * 3;
+    const float *w3 = w + r * 3;
+    const float *base = points2 + b * S * D + c;
+    float t0 = __fmul_rn(base[i3[0] * D], w3[0]);
+    float t1 = __fmul_rn(base[i3[1] * D], w3[1]);
+    float t2 = __fmul_rn(base[i3[2] * D], w3[2]);
+    out[r * ld + col0 + c] = __fadd_rn(__fadd_rn(t0, t1), t2);
+}
+
+__global__ __launch_bounds__(TPB) void three_interp_bwd_kernel(const float *__restrict__ grad_out, int ld, int col0,
+                                                               const int64_t *__restrict__ idx,
+                                                               const float *__restrict__ w, int N, int S, int D,
+                                                               int64_t total, float *__restrict__ grad_points2) {
+    int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= total) return;
+    int c = (int)(e % D);
+    int64_t r = e / D;
+    int64_t b = r / N;
+    const int64_t *i3 = idx + r * 3;
+    const float *w3 = w + r * 3;
+    float g = grad_out[r * ld + col0 + c];
+    float *base = grad_points2 + b * S * D + c;
+    atomicAdd(base + i3[0] * D, g * w3[0]);
+    atomicAdd(base + i3[1] * D, g * w3[1]);
+    atomicAdd(base + i3[2] * D, g * w3[2]);
+}
+
+__global__ __launch_bounds__(TPB) void copy_cols_kernel(const float *__restrict__ src, int lds, int scol0,
+                                                        float *__restrict__ dst, int ldd, int dcol0, int cols,
+                                                        int64_t total) {
+    int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= total) return;
+    int c = (int)(e % cols);
+    int64_t r = e / cols;
+    dst[r * ldd + dcol0 + c] = src[r * lds + scol0 + c];
+}
+
+inline unsigned blocks_for(int64_t total) { return (unsigned)pn2_cdiv(total, TPB); }
+
+}  // namespace
+
+extern "C" {
+
+int pn2_gather_rows(const float *points, const int64_t *idx, int B, int N, int C, int M, float *out, int *err,
+                    pn2_stream_t stream) {
+    PN2_CHECK_ARG(points && idx && out && B > 0 && N > 0 && C > 0 && M > 0);
+    int64_t total = (int64_t)B * M * C;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), points, idx, N, C, M,
+                       total, out, err);
+    return pn2_launch_status();
+}
+
+int pn2_gather_rows_bwd(const float *grad_out, const int64_t *idx, int B, int N, int C, int M, float *grad_points,
+                        pn2_stream_t stream) {
+    PN2_CHECK_ARG(grad_out && idx && grad_points && B > 0 && N > 0 && C > 0 && M > 0);
+    int64_t total = (int64_t)B * M * C;
+    hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), grad_out, idx, N, C,
+                       M, total, grad_points);
+    return pn2_launch_status();
+}
+
+int pn2_group(const float *xyz, const float *points, const float *new_xyz, const int64_t *idx, int B, int N, int S,
+              int K, int D, int xyz_first, int ld, float *out, int *err, pn2_stream_t stream) {
+    PN2_CHECK_ARG(xyz && out && B > 0 && N > 0 && S > 0 && K > 0 && D >= 0 && ld >= 3 + D);
+    PN2_CHECK_ARG(D == 0 || points != nullptr);
+    PN2_CHECK_ARG(idx != nullptr || K == N);
+    int64_t total = (int64_t)B * S * K * ld;
+    hipLaunchKernelGGL(group_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), xyz, points, new_xyz, idx, N, S,
+                       K, D, xyz_first, ld, total, out, err);
+    return pn2_launch_status();
+}
+
+int pn2_group_bwd(const float *grad_rows, const int64_t *idx, int B, int N, int S, int K, int D, int xyz_first, int ld,
+                  float *grad_points, pn2_stream_t stream) {
+    PN2_CHECK_ARG(grad_rows && grad_points && B > 0 && N > 0 && S > 0 && K > 0 && D > 0 && ld >= 3 + D);
+    PN2_CHECK_ARG(idx != nullptr || K == N);
+    int64_t total = (int64_t)B * S * K * D;
+    hipLaunchKernelGGL(group_bwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), grad_rows, idx, N, S, K, D,
+                       xyz_first, ld, total, grad_points);
+    return pn2_launch_status();
+}
+
+int pn2_three_interp(const float *points2, const int64_t *idx, const float *weight, int B, int N, int S, int D,
+                     float *out, int ld, int col0, pn2_stream_t stream) {
+    PN2_CHECK_ARG(points2 && idx && weight && out && B > 0 && N > 0 && S > 0 && D > 0 && col0 >= 0 && ld >= col0 + D);
+    int64_t total = (int64_t)B * N * D;
+    hipLaunchKernelGGL(three_interp_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), points2, idx, weight, N,
+                       S, D, total, out, ld, col0);
+    return pn2_launch_status();
+}
+
+int pn2_three_interp_bwd(const float *grad_out, int ld, int col0, const int64_t *idx, const float *weight, int B, int N,
+                         int S, int D, float *grad_points2, pn2_stream_t stream) {
+    PN2_CHECK_ARG(grad_out && idx && weight && grad_points2 && B > 0 && N > 0 && S > 0 && D > 0 && col0 >= 0 &&
+                  ld >= col0 + D);
+    int64_t total = (int64_t)B * N * D;
+    hipLaunchKernelGGL(three_interp_bwd_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), grad_out, ld, col0,
+                       idx, weight, N, S, D, total, grad_points2);
+    return pn2_launch_status();
+}
+
+int pn2_copy_cols(const float *src, int lds, int scol0, float *dst, int ldd, int dcol0, int64_t rows, int cols,
+                  pn2_stream_t stream) {
+    PN2_CHECK_ARG(src && dst && rows > 0 && cols > 0 && scol0 >= 0 && dcol0 >= 0 && lds >= scol0 + cols &&
+                  ldd >= dcol0 + cols);
+    int64_t total = rows * cols;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), src, lds, scol0, dst, ldd,
+                       dcol0, cols, total);
+    return pn2_launch_status();
+}
+
+}  // extern "C"

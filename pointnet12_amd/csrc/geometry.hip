@@ -1,0 +1,322 @@
+// Index-exact geometry kernels: farthest-point sampling, ball query, 3-NN, pair distances.
+//
+// COMPILED WITH -ffp-contract=off.  The reference's results depend on the exact fp32
+// expression forms (pinned in oracle/pn2_oracle.c against the reference itself):
+//   FPS distance   d = ((dx*dx + dy*dy) + dz*dz)            no fused multiply-add
+//   pair distance  dot = fma(az,bz, fma(ay,by, ax*bx)); n(p) = ((x*x + y*y) + z*z)
+//                  d = ((-2*dot) + n(query)) + n(candidate)
+// so every fused step below is an explicit __builtin_fmaf and nothing else may contract.
+#include "pn2_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sq_norm3(float x, float y, float z) {
+    float xx = x * x, yy = y * y, zz = z * z;
+    return (xx + yy) + zz;
+}
+
+__device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float nq, float px, float py, float pz,
+                                           float np) {
+    float dot = qx * px;
+    dot = __builtin_fmaf(qy, py, dot);
+    dot = __builtin_fmaf(qz, pz, dot);
+    float d = -2.0f * dot;
+    d = d + nq;
+    d = d + np;
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Farthest-point sampling: one workgroup per cloud, the cloud and its running min-distance
+// live in registers (PPT points per thread, point j = t + i*THREADS), the cloud is mirrored in
+// LDS as float4 so the winner's coordinates are one broadcast ds_read_b128 away.
+// Each of the npoint dependent iterations costs: PPT distance updates, a per-thread argmax,
+// a 64-lane shuffle max on a packed (distance bits, ~index) key -- distances are >= 0 so their
+// fp32 bit patterns order like unsigned ints and "largest key" = largest distance, lowest
+// index -- one LDS slot per wave and ONE barrier (slots are double-buffered by iteration
+// parity).  pointnet_util.py:77-83.
+// ---------------------------------------------------------------------------------------------
+template <int THREADS, int PPT, bool XYZ_LDS>
+__global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ xyz, int N,
+                                                      const int64_t *__restrict__ start, int npoint,
+                                                      int64_t *__restrict__ out) {
+    constexpr int NW = THREADS / 64;
+    extern __shared__ float4 fps_lds[];
+    float4 *cloud = fps_lds;                                                     // [N] when XYZ_LDS
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(fps_lds + (XYZ_LDS ? N : 0));  // [2][NW]
+
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *p = xyz + (size_t)b * N * 3;
+
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        int j = t + i * THREADS;
+        if (j < N) {
+            px[i] = p[3 * j]; py[i] = p[3 * j + 1]; pz[i] = p[3 * j + 2];
+            md[i] = 1e10f;
+            if (XYZ_LDS) cloud[j] = make_float4(px[i], py[i], pz[i], 0.f);
+        } else {
+            px[i] = py[i] = pz[i] = 0.f;
+            md[i] = 0.f;
+        }
+    }
+    if (XYZ_LDS) __syncthreads();
+
+    int far = (int)start[b];
+    int64_t *o = out + (size_t)b * npoint;
+    for (int it = 0; it < npoint; ++it) {
+        if (t == 0) o[it] = far;
+        float cx, cy, cz;
+        if (XYZ_LDS) {
+            float4 c = cloud[far];
+            cx = c.x; cy = c.y; cz = c.z;
+        } else {
+            int f = __builtin_amdgcn_readfirstlane(far);
+            cx = p[3 * f]; cy = p[3 * f + 1]; cz = p[3 * f + 2];
+        }
+        float bm = -1.0f;
+        int bj = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            int j = t + i * THREADS;
+            float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+            float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            float d = (xx + yy) + zz;
+            md[i] = d < md[i] ? d : md[i];
+            if (j < N && md[i] > bm) { bm = md[i]; bj = j; }
+        }
+        unsigned long long key = bm < 0.f ? 0ull
+                                          : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
+        key = pn2_wave_max_u64(key);
+        if (NW > 1) {
+            unsigned long long *s = slots + (it & 1) * NW;
+            if (lane == 0) s[wave] = key;
+            __syncthreads();
+            key = s[lane & (NW - 1)];
+#pragma unroll
+            for (int m = NW >> 1; m >= 1; m >>= 1) {
+                unsigned long long other = __shfl_xor(key, m, 64);
+                key = other > key ? other : key;
+            }
+        }
+        far = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    }
+}
+
+// Any N: the running distance lives in caller scratch (global), the cloud is re-read from
+// L2 every iteration.  Used beyond the register-resident range (N > 16384).
+__global__ __launch_bounds__(1024) void fps_large_kernel(const float *__restrict__ xyz, int N,
+                                                         const int64_t *__restrict__ start, int npoint,
+                                                         int64_t *__restrict__ out, float *__restrict__ work) {
+    __shared__ unsigned long long slots[2][16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *p = xyz + (size_t)b * N * 3;
+    float *md = work + (size_t)b * N;
+    for (int j = t; j < N; j += 1024) md[j] = 1e10f;
+    int far = (int)start[b];
+    int64_t *o = out + (size_t)b * npoint;
+    for (int it = 0; it < npoint; ++it) {
+        if (t == 0) o[it] = far;
+        int f = __builtin_amdgcn_readfirstlane(far);
+        float cx = p[3 * f], cy = p[3 * f + 1], cz = p[3 * f + 2];
+        float bm = -1.0f;
+        int bj = 0;
+        for (int j = t; j < N; j += 1024) {
+            float dx = p[3 * j] - cx, dy = p[3 * j + 1] - cy, dz = p[3 * j + 2] - cz;
+            float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            float d = (xx + yy) + zz;
+            float m = md[j];
+            m = d < m ? d : m;
+            md[j] = m;
+            if (m > bm) { bm = m; bj = j; }
+        }
+        unsigned long long key = bm < 0.f ? 0ull
+                                          : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
+        key = pn2_wave_max_u64(key);
+        if (lane == 0) slots[it & 1][wave] = key;
+        __syncthreads();
+        key = slots[it & 1][lane & 15];
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            unsigned long long other = __shfl_xor(key, m, 64);
+            key = other > key ? other : key;
+        }
+        far = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    }
+}
+
+template <int THREADS, int PPT>
+int launch_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, hipStream_t s) {
+    constexpr int NW = THREADS / 64;
+    const bool in_lds = (size_t)N * 16 + 2 * NW * 8 <= 160 * 1024;  // gfx950: 160 KiB of LDS per workgroup
+    size_t lds = (in_lds ? (size_t)N * 16 : 0) + 2 * NW * 8;
+    if (in_lds) {
+        if (lds > 64 * 1024) {   // above the default dynamic-LDS window: opt in once per instantiation
+            static bool raised = false;
+            if (!raised) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<THREADS, PPT, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return PN2_ELAUNCH;
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL((fps_kernel<THREADS, PPT, true>), dim3(B), dim3(THREADS), lds, s, xyz, N, start, npoint, out);
+    } else
+        hipLaunchKernelGGL((fps_kernel<THREADS, PPT, false>), dim3(B), dim3(THREADS), lds, s, xyz, N, start, npoint, out);
+    return pn2_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ball query: one wave per query centre scans the cloud in index order, 64 candidates per
+// step; a ballot + prefix popcount gives each in-radius lane its output slot, and the wave
+// stops as soon as nsample slots are filled (the reference sorts a full N-row instead,
+// pointnet_util.py:100-106).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ xyz,
+                                                         const float *__restrict__ new_xyz, int N, int S, float r2,
+                                                         int nsample, int64_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (s >= S) return;
+    const float *p = xyz + (size_t)b * N * 3;
+    const float *q = new_xyz + ((size_t)b * S + s) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float nq = sq_norm3(qx, qy, qz);
+    int64_t *row = out + ((size_t)b * S + s) * nsample;
+    int cnt = 0, first = N;
+    for (int base = 0; base < N && cnt < nsample; base += 64) {
+        const int j = base + lane;
+        bool in = false;
+        if (j < N) {
+            float x = p[3 * j], y = p[3 * j + 1], z = p[3 * j + 2];
+            float d = pair_dist(qx, qy, qz, nq, x, y, z, sq_norm3(x, y, z));
+            in = !(d > r2);
+        }
+        const unsigned long long mask = __ballot(in);
+        if (mask) {
+            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (in && pos < nsample) row[pos] = j;
+            if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+            cnt += __popcll(mask);
+        }
+    }
+    if (cnt > nsample) cnt = nsample;
+    for (int k = cnt + lane; k < nsample; k += 64) row[k] = first;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3-NN + inverse-distance weights: one thread per query point, the S candidates are staged
+// through LDS as (x, y, z, |p|^2) and broadcast-read; the reference materialises [B,N,S] and
+// sorts every row (pointnet_util.py:295-300).
+// ---------------------------------------------------------------------------------------------
+constexpr int NN_TILE = 1024;
+
+__global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ xyz1,
+                                                       const float *__restrict__ xyz2, int N, int S,
+                                                       int64_t *__restrict__ idx, float *__restrict__ dist,
+                                                       float *__restrict__ weight) {
+    __shared__ float4 tile[NN_TILE];
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const bool live = n < N;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (live) {
+        const float *q = xyz1 + ((size_t)b * N + n) * 3;
+        qx = q[0]; qy = q[1]; qz = q[2];
+    }
+    const float nq = sq_norm3(qx, qy, qz);
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = 0, i1 = 0, i2 = 0;
+    const float *c = xyz2 + (size_t)b * S * 3;
+    for (int base = 0; base < S; base += NN_TILE) {
+        const int cnt = min(NN_TILE, S - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += 256) {
+            float x = c[3 * (base + k)], y = c[3 * (base + k) + 1], z = c[3 * (base + k) + 2];
+            tile[k] = make_float4(x, y, z, sq_norm3(x, y, z));
+        }
+        __syncthreads();
+        for (int k = 0; k < cnt; ++k) {
+            const float4 v = tile[k];
+            const float d = pair_dist(qx, qy, qz, nq, v.x, v.y, v.z, v.w);
+            const int j = base + k;
+            if (d < d2) {
+                if (d < d1) {
+                    d2 = d1; i2 = i1;
+                    if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                    else { d1 = d; i1 = j; }
+                } else { d2 = d; i2 = j; }
+            }
+        }
+    }
+    if (!live) return;
+    const size_t o = ((size_t)b * N + n) * 3;
+    idx[o] = i0; idx[o + 1] = i1; idx[o + 2] = i2;
+    dist[o] = d0; dist[o + 1] = d1; dist[o + 2] = d2;
+    float w0 = d0 < 1e-10f ? 1e-10f : d0, w1 = d1 < 1e-10f ? 1e-10f : d1, w2 = d2 < 1e-10f ? 1e-10f : d2;
+    w0 = __fdiv_rn(1.0f, w0); w1 = __fdiv_rn(1.0f, w1); w2 = __fdiv_rn(1.0f, w2);
+    const float sum = (w0 + w1) + w2;
+    weight[o] = __fdiv_rn(w0, sum); weight[o + 1] = __fdiv_rn(w1, sum); weight[o + 2] = __fdiv_rn(w2, sum);
+}
+
+__global__ __launch_bounds__(256) void square_distance_kernel(const float *__restrict__ src,
+                                                              const float *__restrict__ dst, int S, int N,
+                                                              float *__restrict__ out) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const float *q = src + ((size_t)b * S + i) * 3;
+    const float *p = dst + ((size_t)b * N + j) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2], x = p[0], y = p[1], z = p[2];
+    out[((size_t)b * S + i) * N + j] = pair_dist(qx, qy, qz, sq_norm3(qx, qy, qz), x, y, z, sq_norm3(x, y, z));
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t pn2_fps_workspace_bytes(int B, int N) { return N > 16384 ? (int64_t)B * N * 4 : 0; }
+
+int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out_idx, void *work,
+            pn2_stream_t stream) {
+    PN2_CHECK_ARG(xyz && start && out_idx && B > 0 && N > 0 && npoint > 0);
+    hipStream_t s = pn2_s(stream);
+    if (N <= 64) return launch_fps<64, 1>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 128) return launch_fps<64, 2>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 256) return launch_fps<64, 4>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 512) return launch_fps<64, 8>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 1024) return launch_fps<128, 8>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 2048) return launch_fps<256, 8>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, start, npoint, out_idx, s);
+    PN2_CHECK_ARG(work != nullptr);
+    hipLaunchKernelGGL(fps_large_kernel, dim3(B), dim3(1024), 0, s, xyz, N, start, npoint, out_idx, (float *)work);
+    return pn2_launch_status();
+}
+
+int pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int nsample,
+                   int64_t *out_idx, pn2_stream_t stream) {
+    PN2_CHECK_ARG(xyz && new_xyz && out_idx && B > 0 && N > 0 && S > 0 && nsample > 0 && B <= 65535);
+    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)pn2_cdiv(S, 4), B), dim3(256), 0, pn2_s(stream), xyz, new_xyz, N,
+                       S, r2, nsample, out_idx);
+    return pn2_launch_status();
+}
+
+int pn2_square_distance(const float *src, const float *dst, int B, int S, int N, float *out, pn2_stream_t stream) {
+    PN2_CHECK_ARG(src && dst && out && B > 0 && S > 0 && N > 0 && S <= 65535 && B <= 65535);
+    hipLaunchKernelGGL(square_distance_kernel, dim3((unsigned)pn2_cdiv(N, 256), S, B), dim3(256), 0, pn2_s(stream), src,
+                       dst, S, N, out);
+    return pn2_launch_status();
+}
+
+int pn2_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int64_t *idx, float *dist, float *weight,
+                 pn2_stream_t stream) {
+    PN2_CHECK_ARG(xyz1 && xyz2 && idx && dist && weight && B > 0 && N > 0 && S >= 3 && B <= 65535);
+    hipLaunchKernelGGL(three_nn_kernel, dim3((unsigned)pn2_cdiv(N, 256), B), dim3(256), 0, pn2_s(stream), xyz1, xyz2, N, S,
+                       idx, dist, weight);
+    return pn2_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,514 @@
+"""MI355X-native counterpart of the reference's ``model/pointnet_util.py``.
+
+Same public names, argument orders, tensor layouts and ``state_dict`` keys as the reference
+(``PointNetSetAbstraction``, ``PointNetSetAbstractionMsg``, ``PointNetFeaturePropagation`` and
+the six module-level functions), so ``model/pointnet2.py:5`` style imports work unchanged.
+Underneath, every op is a hand-written gfx950 kernel reached through the C ABI of
+``include/pn2.h`` (ctypes, raw device pointers, torch's current HIP stream).  PyTorch only
+owns memory, streams and the autograd graph; there is no eager/CPU fallback -- a missing
+``libpn2_hip.so`` or a non-GPU tensor raises.
+
+Layout notes
+  * function level: channel-last ``[B, N, C]`` (as the reference); module level: channel-first
+    ``[B, C, N]``.  Modules return channel-first *views* of channel-last storage (the reference
+    does the same for ``new_xyz``, pointnet_util.py:200), so the ``permute + contiguous`` at the
+    top of the next module is free.
+  * inside a module the grouped tensor is position-major ``[P, C]`` (P = B*S*K rows); the
+    reference's ``[B, C, K, S]`` permute (pointnet_util.py:194) never happens.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check as _check, ptr as _p
+
+
+def timeit(tag, t):                      # pointnet_util.py:7-9 (unused helper, kept for API parity)
+    from time import time
+    print("{}: {}s".format(tag, time() - t))
+    return time()
+
+
+def pc_normalize(pc):                    # pointnet_util.py:11-17 (unused helper, kept for API parity)
+    pc = pc - np.mean(pc, axis=0)
+    return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+
+
+def _r4(c):
+    return (c + 3) & ~3
+
+
+def _gpu_f32(t, name):
+    if not t.is_cuda:
+        raise _lib.Pn2Error("%s must live on the GPU: this package has no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))   # the reference raises too (:74,82)
+    return t.contiguous()
+
+
+def _empty_rows(rows, cols, device):
+    """[rows, round4(cols)] float32; pad columns (if any) are zero."""
+    ld = _r4(cols)
+    if ld == cols:
+        return torch.empty(rows, ld, device=device, dtype=torch.float32)
+    return torch.zeros(rows, ld, device=device, dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------------------- primitives
+
+def square_distance(src, dst):
+    """[B,N,3] x [B,M,3] -> [B,N,M]; bit form of pointnet_util.py:19-40."""
+    src, dst = _gpu_f32(src, "src"), _gpu_f32(dst, "dst")
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    out = torch.empty(B, N, M, device=src.device, dtype=torch.float32)
+    _check(_lib.load().pn2_square_distance(_p(src), _p(dst), B, N, M, _p(out), _lib.stream()), "pn2_square_distance")
+    return out
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx, checked):
+        B, N, C = points.shape
+        M = idx.numel() // B
+        out = torch.empty(B, M, C, device=points.device, dtype=torch.float32)
+        err = torch.zeros(1, device=points.device, dtype=torch.int32) if checked else None
+        _check(_lib.load().pn2_gather_rows(_p(points), _p(idx), B, N, C, M, _p(out), _p(err), _lib.stream()),
+               "pn2_gather_rows")
+        if checked and int(err.item()) != 0:
+            raise IndexError("index out of range in index_points")     # as the reference's advanced indexing
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, C, M)
+        return out.view(tuple(idx.shape) + (C,))
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx,) = ctx.saved_tensors
+        B, N, C, M = ctx.shape
+        grad = grad.contiguous()
+        gp = torch.zeros(B, N, C, device=grad.device, dtype=torch.float32)
+        _check(_lib.load().pn2_gather_rows_bwd(_p(grad), _p(idx), B, N, C, M, _p(gp), _lib.stream()),
+               "pn2_gather_rows_bwd")
+        return gp, None, None
+
+
+def index_points(points, idx, _checked=True):
+    """points [B,N,C], idx [B,S] or [B,S,K] (int64) -> [B,S,C] / [B,S,K,C]; pointnet_util.py:43-60."""
+    points = _gpu_f32(points, "points")
+    idx = idx.contiguous()
+    if idx.dtype != torch.int64:
+        idx = idx.long()
+    return _GatherRows.apply(points, idx, _checked)
+
+
+def draw_fps_start(B, N, device):
+    """The start draw of pointnet_util.py:75: one CPU-generator randint per FPS call, then H2D."""
+    return torch.randint(0, N, (B,), dtype=torch.long).to(device, non_blocking=True)
+
+
+def farthest_point_sample(xyz, npoint, start=None):
+    """xyz [B,N,3] -> int64 [B,npoint]; pointnet_util.py:63-84.  ``start`` overrides the random draw."""
+    xyz = _gpu_f32(xyz, "xyz")
+    B, N, C = xyz.shape
+    if C != 3:
+        raise RuntimeError("farthest_point_sample needs 3 coordinates (pointnet_util.py:79)")
+    if start is None:
+        start = draw_fps_start(B, N, xyz.device)
+    start = start.to(device=xyz.device, dtype=torch.int64).contiguous()
+    out = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
+    lib = _lib.load()
+    nbytes = lib.pn2_fps_workspace_bytes(B, N)
+    work = torch.empty(nbytes, device=xyz.device, dtype=torch.uint8) if nbytes else None
+    _check(lib.pn2_fps(_p(xyz), B, N, _p(start), npoint, _p(out), _p(work), _lib.stream()), "pn2_fps")
+    return out
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """-> int64 [B,S,nsample]; pointnet_util.py:87-107 (first nsample in-radius indices, padded with the first)."""
+    xyz, new_xyz = _gpu_f32(xyz, "xyz"), _gpu_f32(new_xyz, "new_xyz")
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    if nsample > N:
+        raise RuntimeError("nsample (%d) > N (%d): the reference's mask assignment fails here too" % (nsample, N))
+    out = torch.empty(B, S, nsample, device=xyz.device, dtype=torch.int64)
+    r2 = float(np.float32(radius ** 2))
+    _check(_lib.load().pn2_ball_query(_p(xyz), _p(new_xyz), B, N, S, r2, nsample, _p(out), _lib.stream()),
+           "pn2_ball_query")
+    return out
+
+
+def three_nn(xyz1, xyz2):
+    """3 nearest of xyz2 [B,S,3] for every point of xyz1 [B,N,3] -> (idx int64, raw dist, weights), each [B,N,3].
+
+    pointnet_util.py:295-300; ties go to the lower index (the reference's sort leaves tie order undefined)."""
+    xyz1, xyz2 = _gpu_f32(xyz1, "xyz1"), _gpu_f32(xyz2, "xyz2")
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    if S < 3:
+        raise RuntimeError("three_nn needs S >= 3 (S == 2 raises in the reference as well)")
+    idx = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.int64)
+    dist = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+    w = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+    _check(_lib.load().pn2_three_nn(_p(xyz1), _p(xyz2), B, N, S, _p(idx), _p(dist), _p(w), _lib.stream()),
+           "pn2_three_nn")
+    return idx, dist, w
+
+
+class _Group(torch.autograd.Function):
+    """Gather K neighbours per centroid, centre xyz, concat features -> position-major [B*S*K, ld]."""
+
+    @staticmethod
+    def forward(ctx, xyz, points, new_xyz, idx, S, K, xyz_first):
+        B, N, _ = xyz.shape
+        D = 0 if points is None else points.shape[2]
+        rows = _empty_rows(B * S * K, 3 + D, xyz.device)
+        ld = rows.shape[1]
+        _check(_lib.load().pn2_group(_p(xyz), _p(points), _p(new_xyz), _p(idx), B, N, S, K, D, int(xyz_first), ld,
+                                     _p(rows), None, _lib.stream()), "pn2_group")
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, S, K, D, int(xyz_first), ld)
+        return rows
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        (idx,) = ctx.saved_tensors
+        B, N, S, K, D, xyz_first, ld = ctx.dims
+        gp = None
+        if D > 0 and ctx.needs_input_grad[1]:
+            grad_rows = grad_rows.contiguous()
+            gp = torch.zeros(B, N, D, device=grad_rows.device, dtype=torch.float32)
+            _check(_lib.load().pn2_group_bwd(_p(grad_rows), _p(idx), B, N, S, K, D, xyz_first, ld, _p(gp),
+                                             _lib.stream()), "pn2_group_bwd")
+        return None, gp, None, None, None, None, None
+
+
+class _InterpCat(torch.autograd.Function):
+    """cat([points1, three_interpolate(points2)], -1) written straight into one [B*N, ld] matrix."""
+
+    @staticmethod
+    def forward(ctx, points1, points2, idx, w):
+        B, S, D2 = points2.shape
+        N = idx.shape[1]
+        D1 = 0 if points1 is None else points1.shape[2]
+        rows = _empty_rows(B * N, D1 + D2, points2.device)
+        ld = rows.shape[1]
+        lib, st = _lib.load(), _lib.stream()
+        if D1:
+            _check(lib.pn2_copy_cols(_p(points1), D1, 0, _p(rows), ld, 0, B * N, D1, st), "pn2_copy_cols")
+        _check(lib.pn2_three_interp(_p(points2), _p(idx), _p(w), B, N, S, D2, _p(rows), ld, D1, st), "pn2_three_interp")
+        ctx.save_for_backward(idx, w)
+        ctx.dims = (B, N, S, D1, D2, ld)
+        return rows
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        idx, w = ctx.saved_tensors
+        B, N, S, D1, D2, ld = ctx.dims
+        grad_rows = grad_rows.contiguous()
+        lib, st = _lib.load(), _lib.stream()
+        g1 = g2 = None
+        if D1 and ctx.needs_input_grad[0]:
+            g1 = torch.empty(B, N, D1, device=grad_rows.device, dtype=torch.float32)
+            _check(lib.pn2_copy_cols(_p(grad_rows), ld, 0, _p(g1), D1, 0, B * N, D1, st), "pn2_copy_cols")
+        if ctx.needs_input_grad[1]:
+            g2 = torch.zeros(B, S, D2, device=grad_rows.device, dtype=torch.float32)
+            _check(lib.pn2_three_interp_bwd(_p(grad_rows), ld, D1, _p(idx), _p(w), B, N, S, D2, _p(g2), st),
+                   "pn2_three_interp_bwd")
+        return g1, g2, None, None
+
+
+# --------------------------------------------------------------------------------------- shared MLP
+
+class _SharedMLP(torch.autograd.Function):
+    """L x (1x1 conv + BatchNorm + ReLU) on position-major rows, then max over ``pool`` consecutive rows.
+
+    forward(rows [P, ld0], c_in, pool, training, bn_cfg, *flat) with ``flat`` = per layer
+    (weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked) and
+    ``bn_cfg`` = per layer (eps, momentum).  pool == 0: no pooling, output [P, C_L] (FP);
+    pool == K: output [P/K, C_L] (SA).  Pre-BN activations of every layer are kept for backward.
+    """
+
+    @staticmethod
+    def forward(ctx, rows, c_in, pool, training, bn_cfg, *flat):
+        lib, st = _lib.load(), _lib.stream()
+        dev = rows.device
+        L = len(flat) // 7
+        P = rows.shape[0]
+        chans = [c_in] + [flat[7 * l].shape[0] for l in range(L)]
+        stats = torch.zeros(2 * sum(chans[1:]), device=dev, dtype=torch.float64) if training else None
+        Ys, affs, Wps = [], [], []
+        x, ldx, x_aff, off = rows, rows.shape[1], None, 0
+        for l in range(L):
+            w, b, gamma, beta, rmean, rvar, nbt = flat[7 * l:7 * l + 7]
+            co, ci = chans[l + 1], chans[l]
+            wp = w.detach().reshape(co, ci)
+            if ldx != ci:
+                wp = torch.nn.functional.pad(wp, (0, ldx - ci))
+            wp = wp.contiguous()
+            y = _empty_rows(P, co, dev)
+            st_l = stats[off:off + 2 * co] if training else None
+            _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(wp), ldx, _p(b), _p(y), y.shape[1], P, ci, co,
+                                       _p(st_l), st), "pn2_conv1x1_fwd")
+            aff = torch.zeros(4 * _r4(co), device=dev, dtype=torch.float32)
+            eps, mom = bn_cfg[l]
+            _check(lib.pn2_bn_finalize(_p(st_l), P, co, _p(gamma), _p(beta), eps, mom, int(training),
+                                       _p(rmean), _p(rvar), _p(nbt), _p(aff), st), "pn2_bn_finalize")
+            Ys.append(y)
+            affs.append(aff)
+            Wps.append(wp)
+            x, ldx, x_aff = y, y.shape[1], aff
+            off += 2 * co
+        cl = chans[-1]
+        K = pool if pool else 1
+        G = P // K
+        out = _empty_rows(G, cl, dev)
+        arg = torch.empty(G, out.shape[1], device=dev, dtype=torch.int32) if pool else None
+        _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), out.shape[1], _p(arg), st),
+               "pn2_bn_relu_max")
+        ctx.meta = (chans, pool, bool(training), P)
+        ctx.tensors = (rows, Ys, affs, out, arg, [flat[7 * l] for l in range(L)], [flat[7 * l + 2] for l in range(L)])
+        return out[:, :cl] if out.shape[1] != cl else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib, st = _lib.load(), _lib.stream()
+        chans, pool, training, P = ctx.meta
+        rows, Ys, affs, out, arg, Ws, gammas = ctx.tensors
+        dev = rows.device
+        L = len(Ys)
+        cl = chans[-1]
+        ldo = out.shape[1]
+        if ldo != cl:
+            g = torch.zeros_like(out)
+            g[:, :cl] = grad_out
+            grad_out = g
+        grad_out = grad_out.contiguous()
+        red = torch.zeros(2 * sum(chans[1:]), device=dev, dtype=torch.float64)
+        offs = np.cumsum([0] + [2 * c for c in chans[1:]])
+        K = pool if pool else 1
+        G = P // K
+        dZ = None
+        red_L = red[offs[L - 1]:offs[L]]
+        if pool:
+            _check(lib.pn2_pool_bwd_reduce(_p(grad_out), ldo, _p(out), _p(arg), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]),
+                                           G, K, cl, _p(red_L), st), "pn2_pool_bwd_reduce")
+        else:
+            dZ = _empty_rows(P, cl, dev)
+            _check(lib.pn2_relu_bwd_reduce(_p(grad_out), ldo, _p(out), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), P, cl,
+                                           _p(dZ), dZ.shape[1], _p(red_L), st), "pn2_relu_bwd_reduce")
+        grads = [None] * (7 * L)
+        d_rows = None
+        for l in range(L - 1, -1, -1):
+            co, ci = chans[l + 1], chans[l]
+            y, aff = Ys[l], affs[l]
+            ldy = y.shape[1]
+            coef = torch.zeros(4 * _r4(co), device=dev, dtype=torch.float32)
+            dgamma = torch.empty(co, device=dev, dtype=torch.float32)
+            dbeta = torch.empty(co, device=dev, dtype=torch.float32)
+            _check(lib.pn2_bn_bwd_coef(_p(red[offs[l]:offs[l + 1]]), P, co, _p(gammas[l]), _p(aff), int(training),
+                                       _p(coef), _p(dgamma), _p(dbeta), st), "pn2_bn_bwd_coef")
+            x = rows if l == 0 else Ys[l - 1]
+            x_aff = None if l == 0 else affs[l - 1]
+            ldx = x.shape[1]
+            dW = torch.zeros(co, ci, device=dev, dtype=torch.float32)
+            dbias = torch.zeros(co, device=dev, dtype=torch.float32)
+            pooled = dZ is None
+            a_dz, a_ldz = (None, 0) if pooled else (_p(dZ), dZ.shape[1])
+            a_pool = (_p(grad_out), ldo, _p(out), _p(arg), K) if pooled else (None, 0, None, None, 0)
+            _check(lib.pn2_conv1x1_wgrad(a_dz, a_ldz, *a_pool, _p(y), ldy, _p(coef), _p(x), ldx, _p(x_aff), _p(dW), ci,
+                                         None if training else _p(dbias), P, co, ci, st), "pn2_conv1x1_wgrad")
+            need_dx = l > 0 or ctx.needs_input_grad[0]
+            if need_dx:
+                wt = Ws[l].detach().reshape(co, ci).t()
+                if ldy != co:
+                    wt = torch.nn.functional.pad(wt, (0, ldy - co))
+                wt = wt.contiguous()
+                if l > 0:
+                    dx = _empty_rows(P, ci, dev)
+                    _check(lib.pn2_conv1x1_dgrad(a_dz, a_ldz, *a_pool, _p(y), ldy, _p(coef), _p(wt), ldy, _p(Ys[l - 1]),
+                                                 Ys[l - 1].shape[1], _p(affs[l - 1]), _p(dx), dx.shape[1],
+                                                 _p(red[offs[l - 1]:offs[l]]), P, co, ci, st), "pn2_conv1x1_dgrad")
+                    dZ = dx
+                else:
+                    d_rows = torch.zeros(P, ldx, device=dev, dtype=torch.float32) if ldx != ci else \
+                        torch.empty(P, ldx, device=dev, dtype=torch.float32)
+                    _check(lib.pn2_conv1x1_dgrad(a_dz, a_ldz, *a_pool, _p(y), ldy, _p(coef), _p(wt), ldy, None, 0, None,
+                                                 _p(d_rows), ldx, None, P, co, ci, st), "pn2_conv1x1_dgrad")
+            grads[7 * l] = dW.view_as(Ws[l])
+            grads[7 * l + 1] = dbias
+            grads[7 * l + 2] = dgamma
+            grads[7 * l + 3] = dbeta
+        return (d_rows, None, None, None, None) + tuple(grads)
+
+
+def _flat_params(convs, bns):
+    flat, cfg = [], []
+    for conv, bn in zip(convs, bns):
+        if bn.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not supported")
+        flat += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+        cfg.append((float(bn.eps), float(bn.momentum)))
+    return flat, tuple(cfg)
+
+
+def shared_mlp(rows, c_in, convs, bns, pool, training):
+    """rows [P, ld] -> [P/pool, C_out] (pool > 0) or [P, C_out] (pool == 0) through the HIP kernels."""
+    flat, cfg = _flat_params(convs, bns)
+    return _SharedMLP.apply(rows, c_in, pool, training, cfg, *flat)
+
+
+# --------------------------------------------------------------------------------------- grouping API
+
+def _channel_last(t, name):
+    """[B,C,N] (any strides) -> contiguous [B,N,C]; free when t is a channel-first view of channel-last storage."""
+    return _gpu_f32(t.permute(0, 2, 1), name)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
+    """pointnet_util.py:110-137: -> new_xyz [B,S,3], new_points [B,S,K,3+D] (xyz first)."""
+    xyz = _gpu_f32(xyz, "xyz")
+    B, N, C = xyz.shape
+    fps_idx = farthest_point_sample(xyz, npoint)
+    new_xyz = index_points(xyz, fps_idx, _checked=False)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = index_points(xyz, idx)
+    pts = None if points is None else _gpu_f32(points, "points")
+    rows = _Group.apply(xyz, pts, new_xyz, idx, npoint, nsample, True)
+    D = 0 if pts is None else pts.shape[2]
+    new_points = rows.view(B, npoint, nsample, -1)[..., :3 + D]
+    if returnfps:
+        return new_xyz, new_points, grouped_xyz, fps_idx
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """pointnet_util.py:140-157: -> zeros [B,1,3], [B,1,N,3+D] (xyz NOT centred)."""
+    xyz = _gpu_f32(xyz, "xyz")
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    pts = None if points is None else _gpu_f32(points, "points")
+    rows = _Group.apply(xyz, pts, None, None, 1, N, True)
+    D = 0 if pts is None else pts.shape[2]
+    return new_xyz, rows.view(B, 1, N, -1)[..., :3 + D]
+
+
+# --------------------------------------------------------------------------------------- modules
+
+class PointNetSetAbstraction(nn.Module):
+    """Drop-in for model/pointnet_util.py:160-201 (same constructor, forward and state_dict)."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint = npoint
+        self.radius = radius
+        self.nsample = nsample
+        self.mlp_convs = nn.ModuleList()      # parameter containers only: their forward is never called
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        self.group_all = group_all
+        self.in_channel = in_channel
+
+    def forward(self, xyz, points, fps_start=None):
+        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,C',S]."""
+        xyz = _channel_last(xyz, "xyz")
+        pts = None if points is None else _channel_last(points, "points")
+        B, N, _ = xyz.shape
+        if self.group_all:
+            new_xyz = torch.zeros(B, 1, 3, device=xyz.device)
+            rows = _Group.apply(xyz, pts, None, None, 1, N, True)
+            S, K = 1, N
+        else:
+            S, K = self.npoint, self.nsample
+            fps_idx = farthest_point_sample(xyz, S, fps_start)
+            new_xyz = index_points(xyz, fps_idx, _checked=False)
+            idx = query_ball_point(self.radius, K, xyz, new_xyz)
+            rows = _Group.apply(xyz, pts, new_xyz, idx, S, K, True)
+        c_in = 3 + (0 if pts is None else pts.shape[2])
+        if c_in != self.in_channel:
+            raise RuntimeError("expected %d input channels (3 + features), got %d" % (self.in_channel, c_in))
+        out = shared_mlp(rows, c_in, self.mlp_convs, self.mlp_bns, K, self.training)
+        return new_xyz.permute(0, 2, 1), out.view(B, S, -1).permute(0, 2, 1)
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """Drop-in for model/pointnet_util.py:204-261."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super().__init__()
+        self.npoint = npoint
+        self.radius_list = radius_list
+        self.nsample_list = nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for i in range(len(mlp_list)):
+            convs = nn.ModuleList()
+            bns = nn.ModuleList()
+            last_channel = in_channel + 3
+            for out_channel in mlp_list[i]:
+                convs.append(nn.Conv2d(last_channel, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel))
+                last_channel = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+        self.in_channel = in_channel
+
+    def forward(self, xyz, points, fps_start=None):
+        xyz = _channel_last(xyz, "xyz")
+        pts = None if points is None else _channel_last(points, "points")
+        B, N, _ = xyz.shape
+        S = self.npoint
+        new_xyz = index_points(xyz, farthest_point_sample(xyz, S, fps_start), _checked=False)
+        c_in = 3 + (0 if pts is None else pts.shape[2])
+        outs = []
+        for i, radius in enumerate(self.radius_list):
+            K = self.nsample_list[i]
+            idx = query_ball_point(radius, K, xyz, new_xyz)
+            rows = _Group.apply(xyz, pts, new_xyz, idx, S, K, False)          # features first (:247)
+            outs.append(shared_mlp(rows, c_in, self.conv_blocks[i], self.bn_blocks[i], K, self.training))
+        out = torch.cat(outs, dim=1)                                          # [B*S, sum C]
+        return new_xyz.permute(0, 2, 1), out.view(B, S, -1).permute(0, 2, 1)
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """Drop-in for model/pointnet_util.py:264-313."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+        self.in_channel = in_channel
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        """xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D1,N] or None, points2 [B,D2,S] -> [B,D',N]."""
+        x1 = _channel_last(xyz1, "xyz1")
+        x2 = _channel_last(xyz2, "xyz2")
+        p2 = _channel_last(points2, "points2")
+        p1 = None if points1 is None else _channel_last(points1, "points1")
+        B, N, _ = x1.shape
+        S = x2.shape[1]
+        if S == 1:                                      # pointnet_util.py:292-293: broadcast the single feature row
+            interp = p2.expand(B, N, p2.shape[2])
+            rows = interp if p1 is None else torch.cat([p1, interp], dim=-1)
+            c_in = rows.shape[-1]
+            rows = rows.reshape(B * N, c_in)
+            if _r4(c_in) != c_in:
+                rows = torch.nn.functional.pad(rows, (0, _r4(c_in) - c_in))
+            rows = rows.contiguous()
+        else:
+            idx, _, w = three_nn(x1, x2)
+            rows = _InterpCat.apply(p1, p2, idx, w)
+            c_in = p2.shape[2] + (0 if p1 is None else p1.shape[2])
+        if c_in != self.in_channel:
+            raise RuntimeError("expected %d input channels, got %d" % (self.in_channel, c_in))
+        out = shared_mlp(rows, c_in, self.mlp_convs, self.mlp_bns, 0, self.training)
+        return out.view(B, N, -1).permute(0, 2, 1)

@@ -1,0 +1,155 @@
+"""GPU: HIP geometry kernels (through the C ABI) against golden vectors and the oracle -- bit exact."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import geometry as G
+from pointnet12_amd import pointnet_util as U
+from pointnet12_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_fps_golden(dev):
+    g = golden("g1_fps.npz")
+    for tag in g["cases"]:
+        ref = g[tag + "/idx"]
+        mine = U.farthest_point_sample(cu(g[tag + "/xyz"], dev), ref.shape[1], cu(g[tag + "/start"], dev))
+        assert mine.dtype == torch.int64
+        assert (mine.cpu().numpy() == ref).all(), tag
+
+
+@pytest.mark.parametrize("N,S", [(1, 1), (63, 7), (65, 65), (129, 40), (257, 64), (513, 128), (1025, 100),
+                                 (2049, 33), (4097, 64), (8193, 32), (12000, 16), (16385, 8), (20000, 8)])
+def test_fps_every_dispatch_bucket_vs_oracle(dev, N, S):
+    rng = np.random.default_rng(N)
+    xyz = rng.uniform(-1, 1, (3, N, 3)).astype(np.float32)
+    xyz[:, N // 2] = xyz[:, 0]                      # duplicates: ties at zero distance
+    start = rng.integers(0, N, 3)
+    ref = G.farthest_point_sample(xyz, S, start)
+    mine = U.farthest_point_sample(cu(xyz, dev), S, cu(start, dev)).cpu().numpy()
+    assert (mine == ref).all()
+
+
+def test_fps_full_size_property(dev):
+    """B=16 x 4096 -> 1024 (benchmark size): indices distinct until exhaustion, start honoured, oracle-equal."""
+    pts, _ = syn.kitti_batch(0, 16, 4096)
+    xyz = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
+    start = np.arange(16) * 7
+    mine = U.farthest_point_sample(cu(xyz, dev), 1024, cu(start, dev)).cpu().numpy()
+    assert (mine[:, 0] == start).all()
+    assert (mine == G.farthest_point_sample(xyz, 1024, start)).all()
+    for b in range(16):
+        chosen = xyz[b][mine[b]]
+        assert len(np.unique(chosen, axis=0)) == len(chosen)    # never re-picks a location while new ones remain
+
+
+def test_fps_random_start_uses_cpu_generator(dev):
+    xyz = cu(np.random.default_rng(1).uniform(-1, 1, (4, 300, 3)).astype(np.float32), dev)
+    torch.manual_seed(77)
+    a = U.farthest_point_sample(xyz, 5)
+    torch.manual_seed(77)
+    expect = torch.randint(0, 300, (4,), dtype=torch.long)
+    assert (a[:, 0].cpu() == expect).all()
+    with pytest.raises(RuntimeError):
+        U.farthest_point_sample(xyz.double(), 5)
+
+
+def test_ball_query_golden(dev):
+    g = golden("g2_ball.npz")
+    for tag in g["cases"]:
+        fam, rest = tag.split("/")
+        r, k = rest[1:].split("_k")
+        mine = U.query_ball_point(float(r), int(k), cu(g[fam + "/xyz"], dev), cu(g[fam + "/new_xyz"], dev))
+        assert (mine.cpu().numpy() == g[tag]).all(), tag
+    for r in (0.1, 0.2, 0.4, 0.8):
+        pre = "edge/r%g/" % r
+        mine = U.query_ball_point(r, 4, cu(g[pre + "xyz"], dev), cu(g[pre + "new_xyz"], dev))
+        assert (mine.cpu().numpy() == g[pre + "idx"]).all()
+
+
+def test_ball_query_edges(dev):
+    xyz = cu(np.random.default_rng(0).uniform(-1, 1, (1, 50, 3)).astype(np.float32), dev)
+    far = torch.full((1, 1, 3), 9.0, device=dev)
+    idx = U.query_ball_point(0.1, 8, xyz, far)
+    assert (idx == 50).all()                                    # empty ball: N everywhere, as the reference
+    with pytest.raises(IndexError):
+        U.index_points(xyz, idx)                                # and index_points raises on it
+    with pytest.raises(RuntimeError):
+        U.query_ball_point(0.1, 51, xyz, far)
+
+
+def test_ball_query_full_size_vs_oracle(dev):
+    pts, _ = syn.kitti_batch(3, 4, 4096)
+    xyz = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
+    new = xyz[:, ::8].copy()
+    for r, k in [(0.1, 32), (0.4, 128), (0.8, 128)]:
+        mine = U.query_ball_point(r, k, cu(xyz, dev), cu(new, dev)).cpu().numpy()
+        assert (mine == G.query_ball_point(r, k, xyz, new)).all()
+
+
+def test_square_distance_bits(dev):
+    g = golden("g3_sqdist.npz")
+    d = U.square_distance(cu(g["new_xyz"], dev), cu(g["xyz"], dev)).cpu().numpy()
+    assert hashlib.sha256(bits(d).tobytes()).hexdigest() == str(g["sha256"])
+
+
+def test_three_nn_interp_golden(dev):
+    g = golden("g4_interp.npz")
+    for tag in "abc":
+        x1, x2, p2 = cu(g[tag + "/xyz1"], dev), cu(g[tag + "/xyz2"], dev), cu(g[tag + "/points2"], dev)
+        idx, dist, w = U.three_nn(x1, x2)
+        assert (bits(dist.cpu().numpy()) == bits(g[tag + "/dist3"])).all()
+        oi, od = G.three_nn(g[tag + "/xyz1"], g[tag + "/xyz2"])
+        assert (idx.cpu().numpy() == oi).all()
+        assert np.abs(w.cpu().numpy() - G.three_weights(od)).max() <= 1.2e-7
+        rows = U._InterpCat.apply(None, p2, idx, w)
+        out = rows.view(p2.shape[0], -1, rows.shape[1])[..., :p2.shape[2]].cpu().numpy()
+        assert np.abs(out - g[tag + "/interp"]).max() <= 2e-6
+
+
+def test_index_points_and_grouping(dev):
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(2, 100, 7)).astype(np.float32)
+    xyz = rng.normal(size=(2, 100, 3)).astype(np.float32)
+    idx = rng.integers(0, 100, (2, 10, 6))
+    new = xyz[:, :10].copy()
+    assert (U.index_points(cu(pts, dev), cu(idx, dev)).cpu().numpy() == G.index_points(pts, idx)).all()
+    assert (U.index_points(cu(pts, dev), cu(idx[:, :, 0], dev)).cpu().numpy() == G.index_points(pts, idx[:, :, 0])).all()
+    for first in (True, False):
+        rows = U._Group.apply(cu(xyz, dev), cu(pts, dev), cu(new, dev), cu(idx, dev), 10, 6, first)
+        ref = G.group(xyz, pts, new, idx, first, ld=12)
+        assert (rows.cpu().numpy().reshape(ref.shape) == ref).all()
+    # gradient of the gather: scatter-add with repeats
+    p = cu(pts, dev).requires_grad_(True)
+    U.index_points(p, cu(idx, dev)).sum().backward()
+    cnt = np.zeros((2, 100))
+    for b in range(2):
+        np.add.at(cnt[b], idx[b].ravel(), 1)
+    assert np.allclose(p.grad.cpu().numpy(), cnt[..., None].repeat(7, -1))
+
+
+def test_sample_and_group_api(dev):
+    pts, _ = syn.kitti_batch(9, 2, 512)
+    xyz = cu(pts[:, :3].transpose(0, 2, 1), dev)
+    feat = cu(pts[:, 3:].transpose(0, 2, 1), dev)
+    torch.manual_seed(1)
+    new_xyz, new_points, grouped_xyz, fps_idx = U.sample_and_group(64, 0.3, 16, xyz, feat, returnfps=True)
+    assert new_xyz.shape == (2, 64, 3) and new_points.shape == (2, 64, 16, 9) and grouped_xyz.shape == (2, 64, 16, 3)
+    start = fps_idx[:, 0].cpu().numpy()
+    oi = G.farthest_point_sample(xyz.cpu().numpy(), 64, start)
+    assert (fps_idx.cpu().numpy() == oi).all()
+    a, b = U.sample_and_group_all(xyz, feat)
+    assert a.shape == (2, 1, 3) and float(a.abs().max()) == 0 and b.shape == (2, 1, 512, 9)
+    assert torch.equal(b[:, 0, :, :3], xyz) and torch.equal(b[:, 0, :, 3:], feat)

@@ -1,0 +1,95 @@
+"""GPU: the shared-MLP kernels (MFMA GEMM + BN + ReLU + max, forward and backward) against a plain
+PyTorch fp32 (and fp64) statement of the same op on odd shapes the networks never produce."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pointnet12_amd import pointnet_util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_mlp(rows, convs, bns, pool, training, dtype):
+    y = rows.to(dtype)
+    for conv, bn in zip(convs, bns):
+        w = conv.weight.reshape(conv.weight.shape[0], -1).to(dtype)
+        y = F.linear(y, w, conv.bias.to(dtype))
+        if training:
+            mean = y.mean(0)
+            var = y.var(0, unbiased=False)
+        else:
+            mean, var = bn.running_mean.to(dtype), bn.running_var.to(dtype)
+        y = F.relu((y - mean) / torch.sqrt(var + bn.eps) * bn.weight.to(dtype) + bn.bias.to(dtype))
+    if pool:
+        y = y.view(-1, pool, y.shape[1]).max(1)[0]
+    return y
+
+
+@pytest.mark.parametrize("P,pool,chans", [
+    (4096, 32, [12, 32, 32, 64]), (1000, 0, [7, 20, 196]), (640, 64, [323, 128, 196, 256]),
+    (96, 3, [5, 8]), (2048, 16, [67, 64, 300]), (130, 0, [1539, 256, 32]), (32 * 200, 200, [515, 256, 512, 1024]),
+])
+def test_shared_mlp_vs_torch(dev, P, pool, chans):
+    gen = torch.Generator().manual_seed(P + len(chans))
+    c_in = chans[0]
+    ld = (c_in + 3) & ~3
+    rows = torch.zeros(P, ld)
+    rows[:, :c_in] = torch.randn(P, c_in, generator=gen) * 2 + 0.5
+    convs = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])])
+    bns = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]])
+    for bn in bns:
+        bn.weight.data.uniform_(0.5, 1.5, generator=gen)
+        bn.bias.data.uniform_(-0.5, 0.5, generator=gen)
+    convs.to(dev), bns.to(dev)
+    x = rows.to(dev).requires_grad_(True)
+    out = U.shared_mlp(x, c_in, convs, bns, pool, True)
+    gw = torch.randn(out.shape, generator=gen).to(dev)
+    (out * gw).sum().backward()
+    mine = [x.grad[:, :c_in].clone()] + [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())]
+    rm = [bn.running_mean.clone() for bn in bns]
+    rv = [bn.running_var.clone() for bn in bns]
+
+    x64 = rows[:, :c_in].to(dev).double().requires_grad_(True)
+    for p in list(convs.parameters()) + list(bns.parameters()):
+        p.grad = None
+    c64 = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])]).to(dev).double()
+    b64 = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]]).to(dev).double()
+    c64.load_state_dict({k: v.double() for k, v in convs.state_dict().items()})
+    b64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bns.state_dict().items()})
+    ref = torch_mlp(x64, c64, b64, pool, True, torch.float64)
+    (ref * gw.double()).sum().backward()
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    theirs = [x64.grad] + [p.grad for p in list(c64.parameters()) + list(b64.parameters())]
+    names = ["x"] + [n for n, _ in list(convs.named_parameters()) + list(bns.named_parameters())]
+    for n, a, b in zip(names, mine, theirs):
+        if n.endswith("bias") and a.shape[0] in chans[1:] and "bias" in n and a.abs().max() == 0:
+            continue                                  # conv bias before a training-mode BN: exactly 0 here
+        scale = max(float(b.abs().max()), 1e-9)
+        assert float((a.double() - b).abs().max()) <= 3e-5 * scale, n
+    # running statistics: momentum 0.1, unbiased variance
+    y = x64.detach()
+    for l, (conv, bn) in enumerate(zip(c64, b64)):
+        y = F.linear(y, conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
+        assert torch.allclose(rm[l].double(), 0.1 * y.mean(0), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(rv[l].double(), 0.9 + 0.1 * y.var(0, unbiased=True), rtol=1e-5, atol=1e-6)
+        y = F.relu((y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + bn.eps) * bn.weight + bn.bias)
+
+
+def test_eval_mode_with_grad(dev):
+    gen = torch.Generator().manual_seed(0)
+    convs = nn.ModuleList([nn.Conv2d(8, 16, 1), nn.Conv2d(16, 12, 1)]).to(dev)
+    bns = nn.ModuleList([nn.BatchNorm2d(16), nn.BatchNorm2d(12)]).to(dev)
+    for bn in bns:
+        bn.running_mean.uniform_(-0.3, 0.3)
+        bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(512, 8, generator=gen).to(dev).requires_grad_(True)
+    out = U.shared_mlp(x, 8, convs, bns, 8, False)
+    ref = torch_mlp(x, convs, bns, 8, False, torch.float32)
+    assert float((out - ref).abs().max()) <= 1e-5
+    gw = torch.randn(out.shape, generator=gen).to(dev)
+    ga = torch.autograd.grad((out * gw).sum(), [x] + list(convs.parameters()), retain_graph=True)
+    gb = torch.autograd.grad((ref * gw).sum(), [x] + list(convs.parameters()))
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 3e-5 * max(float(b.abs().max()), 1e-9)

@@ -1,0 +1,125 @@
+"""CPU: the oracle (oracle/) against the committed golden vectors produced by the reference."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import geometry as G
+from oracle import torch_ref as T
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_fps_golden():
+    g = golden("g1_fps.npz")
+    for tag in g["cases"]:
+        xyz, start, ref = g[tag + "/xyz"], g[tag + "/start"], g[tag + "/idx"]
+        mine = G.farthest_point_sample(xyz, ref.shape[1], start)
+        assert (mine == ref).all(), tag
+    # exhausted clouds return index 0 forever (only 20 distinct points in 'dups256')
+    assert (g["dups256/idx"][:, 25:] == 0).all()
+
+
+def test_ball_query_golden():
+    g = golden("g2_ball.npz")
+    for tag in g["cases"]:
+        fam, rest = tag.split("/")
+        r, k = rest[1:].split("_k")
+        mine = G.query_ball_point(float(r), int(k), g[fam + "/xyz"], g[fam + "/new_xyz"])
+        assert (mine == g[tag]).all(), tag
+    for r in (0.1, 0.2, 0.4, 0.8):
+        pre = "edge/r%g/" % r
+        mine = G.query_ball_point(r, 4, g[pre + "xyz"], g[pre + "new_xyz"])
+        assert (mine == g[pre + "idx"]).all()
+        assert list(mine[0, 0]) == [1, 2, 1, 1]        # d == r^2 inside, +1 ulp outside
+
+
+def test_ball_query_empty_and_nsample():
+    xyz = np.random.default_rng(0).uniform(-1, 1, (1, 50, 3)).astype(np.float32)
+    far = np.full((1, 1, 3), 9.0, np.float32)
+    assert (G.query_ball_point(0.1, 8, xyz, far) == 50).all()
+    with pytest.raises(RuntimeError):
+        G.query_ball_point(0.1, 51, xyz, far)
+    with pytest.raises(IndexError):
+        G.index_points(xyz, np.full((1, 2), 50))
+
+
+def test_square_distance_bits():
+    g = golden("g3_sqdist.npz")
+    d = G.square_distance(g["new_xyz"], g["xyz"])
+    assert hashlib.sha256(bits(d).tobytes()).hexdigest() == str(g["sha256"])
+    assert (bits(d)[0, ::16, :] == g["sample_bits"]).all()
+    assert d.min() < 0          # the expanded form goes slightly negative at coincident points
+
+
+def test_three_nn_interp_golden():
+    g = golden("g4_interp.npz")
+    for tag in "abc":
+        idx, dist = G.three_nn(g[tag + "/xyz1"], g[tag + "/xyz2"])
+        assert (bits(dist) == bits(g[tag + "/dist3"])).all()
+        out = G.three_interpolate(g[tag + "/points2"], idx, G.three_weights(dist))
+        assert np.abs(out - g[tag + "/interp"]).max() <= 2e-6
+
+
+MODULE_CASES = {
+    "sa": lambda: T.RefSetAbstraction(256, 0.2, 32, 9, [32, 32, 64], False),
+    "sa_nofeat": lambda: T.RefSetAbstraction(128, 0.4, 16, 3, [16, 32], False),
+    "sa_all": lambda: T.RefSetAbstraction(None, None, None, 9, [32, 64], True),
+    "msg": lambda: T.RefSetAbstractionMsg(128, [0.1, 0.2, 0.4], [16, 32, 64], 6, [[16, 32], [32, 48], [32, 196]]),
+    "fp": lambda: T.RefFeaturePropagation(30, [32, 16]),
+    "fp_noskip": lambda: T.RefFeaturePropagation(24, [32, 32, 16]),
+    "fp_s1": lambda: T.RefFeaturePropagation(30, [16]),
+}
+MODULE_INPUTS = {"sa": ["xyz", "points"], "sa_nofeat": ["xyz", "points"], "sa_all": ["xyz", "points"],
+                 "msg": ["xyz", "points"], "fp": ["xyz1", "xyz2", "points1", "points2"],
+                 "fp_noskip": ["xyz1", "xyz2", "points1", "points2"], "fp_s1": ["xyz1", "xyz2", "points1", "points2"]}
+
+
+def module_case(g, tag):
+    """-> (state0 dict, inputs list (None where absent), seed)."""
+    state = {k[len(tag) + 8:]: g[k] for k in g.files if k.startswith(tag + "/state0/")}
+    ins = [g[tag + "/in/" + n] if (tag + "/in/" + n) in g.files else None for n in MODULE_INPUTS[tag]]
+    return state, ins, int(g[tag + "/seed"])
+
+
+@pytest.mark.parametrize("tag", sorted(MODULE_CASES))
+def test_oracle_modules_golden(tag):
+    g = golden("g5_modules.npz")
+    state, ins, seed = module_case(g, tag)
+    mod = MODULE_CASES[tag]()
+    T.load_numpy_state(mod, state)
+    mod.train()
+    names = MODULE_INPUTS[tag]
+    tens = [None if a is None else torch.from_numpy(a).requires_grad_(("gin/" + n) in "".join(
+        k for k in g.files if k.startswith(tag + "/gin/"))) for n, a in zip(names, ins)]
+    torch.manual_seed(seed)
+    y = mod(*tens)
+    ys = y if isinstance(y, tuple) else (y,)
+    for i, t in enumerate(ys):
+        assert np.abs(t.detach().numpy() - g["%s/out/%d" % (tag, i)]).max() <= 5e-6
+    (ys[-1] * torch.from_numpy(g[tag + "/gw"])).sum().backward()
+    for n, t in zip(names, tens):
+        key = "%s/gin/%s" % (tag, n)
+        if key in g.files:
+            ref = g[key]
+            assert np.abs(t.grad.numpy() - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-12)
+    for k, p in mod.named_parameters():
+        if "conv" in k and k.endswith("bias"):
+            continue
+        ref = g["%s/gpar/%s" % (tag, k)]
+        assert np.abs(p.grad.numpy() - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-12), k
+    for k, v in mod.state_dict().items():
+        key = "%s/state1/%s" % (tag, k)
+        if key in g.files:
+            assert np.allclose(v.numpy(), g[key], rtol=1e-5, atol=1e-6), k
+
+
+def test_rng_draw_order():
+    g = golden("g6_nets.npz")
+    torch.manual_seed(int(g["fwd_seed"]))
+    starts = np.stack([T.draw_start(2, n).numpy() for n in (1024, 1024, 256, 64)])
+    assert (starts == g["ssg/starts"]).all()

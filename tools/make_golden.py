@@ -364,6 +364,7 @@ def g6_nets():
         orc = make_orc()
         check(state_digest(ref) == state_digest(orc), tag + ": seeded init of oracle net equals reference net")
         check(T.count_params(ref) == {"ssg": 968173, "msg": 1735001}[tag], tag + ": parameter count")
+        init_digest = state_digest(ref)          # before any forward pass touches the BN buffers
         res = {}
         for which, net in (("ref", ref), ("orc", orc)):
             net.train()
@@ -375,7 +376,7 @@ def g6_nets():
         d = np.abs(res["ref"][0] - res["orc"][0]).max()
         check(d <= 2e-5, "%s: oracle net log-probs within 2e-5 of reference (%.2e)" % (tag, d))
         check(abs(res["ref"][1] - res["orc"][1]) <= 1e-6, "%s: loss" % tag)
-        out[tag + "/init_sha256"] = np.array(state_digest(ref))
+        out[tag + "/init_sha256"] = np.array(init_digest)
         out[tag + "/log_probs"] = res["ref"][0]
         out[tag + "/loss"] = np.float64(res["ref"][1])
         names = sorted(res["ref"][2])
