@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Headline benchmark: points/sec, forward + backward, PointNet++ SemSeg, B=16 x 4096 x (3+6) per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msg|ssg|sa] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path over one batch of synthetic KITTI-shaped clouds already resident in
+HBM: forward (SA/FP stack + head), nll_loss over all B*N points (reference semseg.py:141-143), backward,
+and -- for N > 1 -- the flat gradient all-reduce (RCCL).  Optimizer step excluded.
+Train mode (BatchNorm batch statistics), fp32, dropout as in the reference (p = 0.5 in the head).
+
+For N > 1 the driver launches one rank per GPU through torch.distributed.run; every rank owns its own 16
+clouds (weak scaling, global batch 16*N) and the only collective is the gradient all-reduce.
+
+Rank 0 prints ONE JSON line.  ``roofline`` describes the kernel family that takes the most device time,
+timed live with HIP events around every C-ABI launch in an instrumented pass after the timed region;
+``cpu_baseline`` is the oracle (torch-CPU port of the reference path, oracle/) timed on this host's cores on
+a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+
+WORKLOADS = {
+    "msg": "PointNet2 MSG SemSeg (SetAbstractionMsg 3 radii + FeaturePropagation), B=16x4096x(3+6), fwd+bwd",
+    "ssg": "PointNet2SemSeg (reference SSG, model/pointnet2.py:141-176), B=16x4096x(3+6), fwd+bwd",
+    "sa": "single PointNetSetAbstraction(1024,0.1,32,9,[32,32,64]), B=8x4096, fwd+bwd",
+}
+
+
+def algorithmic_work(name, a):
+    """(flops, bytes) one C-ABI launch has to do at minimum, from its arguments (fp32 = 4 B, idx = 8 B)."""
+    if name == "pn2_conv1x1_fwd":            # X ldx aff W ldw bias Y ldy P K N stats stream
+        P, K, N = a[8], a[9], a[10]
+        return 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K)
+    if name == "pn2_conv1x1_dgrad":          # ... P K N stream   (reads dZ|pooled + Y [P,K], writes [P,N], reads prev_Y)
+        P, K, N = a[18], a[19], a[20]
+        dense = a[0] is not None
+        masked = a[12] is not None
+        return 2.0 * P * K * N, 4.0 * (P * K * (2 if dense else 1) + P * N * (2 if masked else 1) + N * K)
+    if name == "pn2_conv1x1_wgrad":          # ... P M N stream
+        P, M, N = a[16], a[17], a[18]
+        dense = a[0] is not None
+        return 2.0 * P * M * N, 4.0 * (P * M * (2 if dense else 1) + P * N + M * N)
+    if name == "pn2_bn_relu_max":            # Y ldy aff G K C out ldo arg
+        G, K, C = a[3], a[4], a[5]
+        return 3.0 * G * K * C, 4.0 * (G * K * C + 2 * G * C)
+    if name == "pn2_group":                  # xyz points new_xyz idx B N S K D xyz_first ld out
+        B, N, S, K, D, ld = a[4], a[5], a[6], a[7], a[8], a[10]
+        return 0.0, 4.0 * B * S * K * (ld + 3 + D) + 8.0 * B * S * K
+    if name == "pn2_group_bwd":
+        B, N, S, K, D = a[2], a[3], a[4], a[5], a[6]
+        return 0.0, 4.0 * B * S * K * D * 2 + 8.0 * B * S * K
+    if name == "pn2_fps":                    # latency chain: bytes touched once if register resident
+        B, N = a[1], a[2]
+        return 10.0 * B * N * a[4], 12.0 * B * N
+    if name == "pn2_ball_query":
+        B, N, S, ns = a[2], a[3], a[4], a[6]
+        return 11.0 * B * S * N, 12.0 * B * (N + S) + 8.0 * B * S * ns
+    if name == "pn2_three_nn":
+        B, N, S = a[2], a[3], a[4]
+        return 14.0 * B * N * S, 12.0 * B * (N + S) + 48.0 * B * N
+    return 0.0, 0.0
+
+
+def build_net(workload, dev):
+    import torch
+    from pointnet12_amd import pointnet2 as M
+    from pointnet12_amd import pointnet_util as U
+    torch.manual_seed(0)
+    if workload == "msg":
+        net = M.PointNet2SemSegMsg(13, 6)
+    elif workload == "ssg":
+        net = M.PointNet2SemSeg(13, 6)
+    else:
+        net = U.PointNetSetAbstraction(1024, 0.1, 32, 9, [32, 32, 64], False)
+    return net.to(dev).train()
+
+
+def make_step(workload, net, pts, labels, bucket):
+    import torch.nn.functional as F
+
+    def step():
+        bucket.zero()
+        if workload == "sa":
+            _, feat = net(pts[:, :3, :], pts[:, 3:, :])
+            loss = feat.sum()
+        else:
+            lp = net(pts)
+            loss = F.nll_loss(lp.reshape(-1, lp.shape[-1]), labels.reshape(-1))
+        loss.backward()
+        bucket.all_reduce()
+        return loss
+    return step
+
+
+def cpu_baseline(workload, batch):
+    """The oracle (port of the reference's CPU path) on a bounded sample of the same workload."""
+    import torch
+    from oracle import torch_ref as T
+    from pointnet12_amd import synthetic as syn
+    sample_b = min(batch, 4)
+    pts_np, lab_np = syn.kitti_batch(0, sample_b, 4096)
+    pts, lab = torch.from_numpy(pts_np), torch.from_numpy(lab_np)
+    torch.manual_seed(0)
+    if workload == "msg":
+        net = T.RefMSGSemSeg(13, 6)
+    elif workload == "ssg":
+        net = T.RefSSGSemSeg(13, 6)
+    else:
+        net = T.RefSetAbstraction(1024, 0.1, 32, 9, [32, 32, 64], False)
+    net.train()
+
+    def step():
+        net.zero_grad()
+        if workload == "sa":
+            _, f = net(pts[:, :3, :], pts[:, 3:, :])
+            f.sum().backward()
+        else:
+            T.seg_loss(net(pts), lab).backward()
+    torch.manual_seed(1234)
+    step()
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[0]
+    return {"value": sample_b * 4096 / t, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle net (oracle/torch_ref.py), B=%d of the %d clouds x 4096 pts, 1 warm-up + best of 2 steps, "
+                      "%.2f s/step; C geometry + torch CPU conv/BN, all host threads" % (sample_b, batch, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="msg")
+    ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (default 16; 8 for --workload sa)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pointnet12_amd import _lib, parallel
+    from pointnet12_amd import synthetic as syn
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    _lib.load()                              # no HIP library -> raise, never fall back
+
+    batch = args.batch or (8 if args.workload == "sa" else 16)
+    n_points = 4096
+    lo, _ = parallel.shard_range(batch * world, rank, world)
+    pts_np, lab_np = syn.kitti_batch(lo, batch, n_points)
+    pts = torch.from_numpy(pts_np).to(dev)
+    labels = torch.from_numpy(lab_np).to(dev)
+
+    net = build_net(args.workload, dev)
+    parallel.broadcast_module(net)
+    bucket = parallel.FlatGradBucket(net)
+    step = make_step(args.workload, net, pts, labels, bucket)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    torch.manual_seed(1234)                  # FPS start draws
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = batch * world * n_points * args.steps / elapsed
+
+    roofline = None
+    kernels = None
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass: HIP events around every C-ABI launch, on the stream the kernels run on
+        prof_steps = 3
+        with _lib.call_profile() as calls:
+            for _ in range(prof_steps):
+                step()
+            torch.cuda.synchronize()
+            agg = {}
+            for name, a, e0, e1 in calls:
+                ms = e0.elapsed_time(e1)
+                fl, by = algorithmic_work(name, a)
+                d = agg.setdefault(name, [0.0, 0, 0.0, 0.0])
+                d[0] += ms
+                d[1] += 1
+                d[2] += fl
+                d[3] += by
+        kernels = {k: {"ms_per_step": round(v[0] / prof_steps, 4), "launches_per_step": v[1] // prof_steps,
+                       "gflop_per_step": round(v[2] / prof_steps / 1e9, 3), "mb_per_step": round(v[3] / prof_steps / 1e6, 2)}
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        top, v = max(agg.items(), key=lambda kv: kv[1][0])
+        secs = v[0] / 1e3
+        tf = v[2] / secs / 1e12
+        gbs = v[3] / secs / 1e9
+        # the bound that is closer to its peak decides how the kernel is priced
+        if tf / F32_MFMA_PEAK_TF >= gbs / HBM_PEAK_GBS:
+            roofline = {"kernel": top, "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(tf / F32_MFMA_PEAK_TF, 4), "traffic": None}
+        else:
+            roofline = {"kernel": top, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+        roofline["avg_launch_us"] = round(v[0] / v[1] * 1e3, 2)
+        roofline["launches"] = v[1] // prof_steps
+        roofline["device_ms_all_kernels_per_step"] = round(sum(x[0] for x in agg.values()) / prof_steps, 3)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, batch)
+
+    if rank == 0:
+        line = {
+            "metric": "points/sec fwd+bwd, PointNet2 SemSeg B=16x4096 pts", "value": round(value, 1), "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload], "clouds_per_gpu": batch, "points_per_cloud": n_points,
+                       "channels": 9, "global_batch": batch * world, "parallelism": "dp%d" % world,
+                       "grad_bucket_bytes": bucket.nbytes},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,11 +55,51 @@ def build(force=False):
 
 
 _lib = None
+_raw = None
+_profile = None          # None, or a list receiving (name, args, start_event, end_event) per call
+
+
+class _Timed:
+    """Proxy handed out while a call profile is active: brackets every launch with HIP events recorded on
+    the stream the kernel is launched on (torch's current stream, passed as the last argument)."""
+
+    def __getattr__(self, name):
+        fn = getattr(_raw, name)
+        if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes"):
+            return fn
+
+        def timed(*args):
+            import torch
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(*args)
+            b.record()
+            _profile.append((name, args, a, b))
+            return rc
+        return timed
+
+
+class call_profile:
+    """``with call_profile() as calls:`` -> list of (entry point, args, start, end) for every C-ABI call made
+    inside; ``start.elapsed_time(end)`` after a synchronize gives that launch's device time in ms."""
+
+    def __enter__(self):
+        global _lib, _profile
+        load()
+        _profile = []
+        _lib = _Timed()
+        return _profile
+
+    def __exit__(self, *exc):
+        global _lib, _profile
+        _lib = _raw
+        _profile = None
+        return False
 
 
 def load():
     """Load the library and bind every symbol of SIGNATURES; raises if anything is missing."""
-    global _lib
+    global _lib, _raw
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -72,7 +112,7 @@ def load():
         fn.argtypes = args
     if lib.pn2_version() != 1:
         raise Pn2Error("libpn2_hip.so ABI version %d, expected 1" % lib.pn2_version())
-    _lib = lib
+    _lib = _raw = lib
     return lib
 
 
