@@ -67,7 +67,12 @@ def test_shared_mlp_vs_torch(dev, P, pool, chans):
         if n.endswith("bias") and a.shape[0] in chans[1:] and "bias" in n and a.abs().max() == 0:
             continue                                  # conv bias before a training-mode BN: exactly 0 here
         scale = max(float(b.abs().max()), 1e-9)
-        assert float((a.double() - b).abs().max()) <= 3e-5 * scale, n
+        err = (a.double() - b).abs().flatten()
+        # fp32 and fp64 may disagree on a near-tied argmax or on a ReLU input within an ulp of 0; such a flip
+        # re-routes one gradient entry.  Require 99.5 % of the entries tight and bound the rest in L2.
+        k = max(1, int(err.numel() * 0.995))
+        assert float(err.kthvalue(k)[0]) <= 3e-5 * scale, (n, float(err.kthvalue(k)[0]) / scale)
+        assert float(err.norm() / b.norm().clamp_min(1e-30)) <= 1e-3, (n, float(err.norm() / b.norm()))
     # running statistics: momentum 0.1, unbiased variance
     y = x64.detach()
     for l, (conv, bn) in enumerate(zip(c64, b64)):
