@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (default 16; 8 for --workload sa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="per-launch table of the instrumented pass on stderr")
     args = ap.parse_args()
 
     import numpy as np
@@ -212,9 +213,14 @@ def main():
                 step()
             torch.cuda.synchronize()
             agg = {}
-            for name, a, e0, e1 in calls:
+            ncall = len(calls) // prof_steps
+            for i, (name, a, e0, e1) in enumerate(calls):
                 ms = e0.elapsed_time(e1)
                 fl, by = algorithmic_work(name, a)
+                if args.detail and i >= len(calls) - ncall:
+                    dims = [x for x in a if isinstance(x, int) and 0 < x < (1 << 31)][:8]
+                    print("%-22s %8.1f us %7.2f TF %8.1f GB/s  %s" % (name, ms * 1e3, fl / ms / 1e9 if ms else 0,
+                                                                      by / ms / 1e6 if ms else 0, dims), file=sys.stderr)
                 d = agg.setdefault(name, [0.0, 0, 0.0, 0.0])
                 d[0] += ms
                 d[1] += 1

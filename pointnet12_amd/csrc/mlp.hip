@@ -93,21 +93,42 @@ struct LoadDyPooled {
 };
 
 // ----------------------------------------------------------------------------- epilogues (NT GEMM)
+// An epilogue sees the output tile row-wise, 4 consecutive channels at a time (after the accumulators
+// have been staged through LDS), so every global access it makes is a coalesced 16-byte one.
+// apply() returns the 4 values to store and adds this row's contribution to the two per-channel
+// reductions it owns (s0, s1); n is a multiple of 4, n + e >= N lanes must come back as 0.
+
+__device__ __forceinline__ float4 ld4_guard(const float *p, int n, int N) {
+    if (n + 3 < N) return ld4(p + n);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) r.x = p[n];
+    if (n + 1 < N) r.y = p[n + 1];
+    if (n + 2 < N) r.z = p[n + 2];
+    return r;
+}
 
 struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y) -> stats
     float *Y; int ldy; const float *bias; double *stats;
     static constexpr bool kHasStats = true;
     __device__ __forceinline__ bool want_stats() const { return stats != nullptr; }
-    __device__ __forceinline__ void prep(int n, bool nvalid, float (&c)[4]) const { c[0] = nvalid ? bias[n] : 0.f; }
-    __device__ __forceinline__ void elem(int64_t m, int n, float acc, const float (&c)[4], float &s0, float &s1) const {
-        float y = acc + c[0];
-        Y[m * ldy + n] = y;
-        s0 += y;
-        s1 = __builtin_fmaf(y, y, s1);
+    __device__ __forceinline__ void prep(int n, int N, float4 (&c)[4]) const { c[0] = ld4_guard(bias, n, N); }
+    __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], float4 &s0,
+                                          float4 &s1) const {
+        float4 y;
+        y.x = acc.x + c[0].x; y.y = acc.y + c[0].y; y.z = acc.z + c[0].z; y.w = acc.w + c[0].w;
+        if (n + 3 >= N) {       // zero the pad lanes so the pad columns of Y stay zero
+            if (n + 1 >= N) y.y = 0.f;
+            if (n + 2 >= N) y.z = 0.f;
+            y.w = 0.f;
+        }
+        *reinterpret_cast<float4 *>(Y + m * ldy + n) = y;
+        s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
+        s1.x = __builtin_fmaf(y.x, y.x, s1.x); s1.y = __builtin_fmaf(y.y, y.y, s1.y);
+        s1.z = __builtin_fmaf(y.z, y.z, s1.z); s1.w = __builtin_fmaf(y.w, y.w, s1.w);
     }
-    __device__ __forceinline__ void flush(int n, int N, double s0, double s1) const {
-        atomicAdd(stats + n, s0);
-        atomicAdd(stats + N + n, s1);
+    __device__ __forceinline__ void flush(int n, int N, double a0, double a1) const {
+        atomicAdd(stats + n, a0);
+        atomicAdd(stats + N + n, a1);
     }
 };
 
@@ -115,67 +136,123 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
     float *dX; int ldx; const float *prevY; int ldp; const float *aff; int lda; double *red;
     static constexpr bool kHasStats = true;
     __device__ __forceinline__ bool want_stats() const { return red != nullptr; }
-    __device__ __forceinline__ void prep(int n, bool nvalid, float (&c)[4]) const {
-        Affine a(aff, lda);
-        c[0] = nvalid ? a.mean[n] : 0.f; c[1] = nvalid ? a.scale[n] : 0.f;
-        c[2] = nvalid ? a.beta[n] : 0.f; c[3] = nvalid ? a.invstd[n] : 0.f;
+    __device__ __forceinline__ void prep(int n, int N, float4 (&c)[4]) const {
+        Affine a(aff, lda);     // affine blocks are padded to a multiple of 4 with zeros
+        c[0] = ld4(a.mean + n); c[1] = ld4(a.scale + n); c[2] = ld4(a.beta + n); c[3] = ld4(a.invstd + n);
     }
-    __device__ __forceinline__ void elem(int64_t m, int n, float acc, const float (&c)[4], float &s0, float &s1) const {
-        float y = prevY[m * ldp + n];
-        float dz = bn_act(y, c[0], c[1], c[2]) > 0.f ? acc : 0.f;
-        dX[m * ldx + n] = dz;
-        s0 += dz;
-        s1 = __builtin_fmaf(dz, (y - c[0]) * c[3], s1);
+    __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], float4 &s0,
+                                          float4 &s1) const {
+        float4 y = ld4(prevY + m * ldp + n);
+        float4 dz;
+        dz.x = bn_act(y.x, c[0].x, c[1].x, c[2].x) > 0.f ? acc.x : 0.f;
+        dz.y = bn_act(y.y, c[0].y, c[1].y, c[2].y) > 0.f ? acc.y : 0.f;
+        dz.z = bn_act(y.z, c[0].z, c[1].z, c[2].z) > 0.f ? acc.z : 0.f;
+        dz.w = bn_act(y.w, c[0].w, c[1].w, c[2].w) > 0.f ? acc.w : 0.f;
+        *reinterpret_cast<float4 *>(dX + m * ldx + n) = dz;     // pad lanes: scale = beta = 0 -> 0
+        s0.x += dz.x; s0.y += dz.y; s0.z += dz.z; s0.w += dz.w;
+        s1.x = __builtin_fmaf(dz.x, (y.x - c[0].x) * c[3].x, s1.x);
+        s1.y = __builtin_fmaf(dz.y, (y.y - c[0].y) * c[3].y, s1.y);
+        s1.z = __builtin_fmaf(dz.z, (y.z - c[0].z) * c[3].z, s1.z);
+        s1.w = __builtin_fmaf(dz.w, (y.w - c[0].w) * c[3].w, s1.w);
     }
-    __device__ __forceinline__ void flush(int n, int N, double s0, double s1) const {
-        atomicAdd(red + n, s0);
-        atomicAdd(red + N + n, s1);
+    __device__ __forceinline__ void flush(int n, int N, double a0, double a1) const {
+        atomicAdd(red + n, a0);
+        atomicAdd(red + N + n, a1);
     }
 };
 
-struct EpiStore {           // first layer: dX0 = acc
+struct EpiStore {           // first layer: dX0 = acc (pad lanes are exact zeros: the W^T pad rows are zero)
     float *dX; int ldx;
     static constexpr bool kHasStats = false;
     __device__ __forceinline__ bool want_stats() const { return false; }
-    __device__ __forceinline__ void prep(int, bool, float (&)[4]) const {}
-    __device__ __forceinline__ void elem(int64_t m, int n, float acc, const float (&)[4], float &, float &) const {
-        dX[m * ldx + n] = acc;
+    __device__ __forceinline__ void prep(int, int, float4 (&)[4]) const {}
+    __device__ __forceinline__ void apply(int64_t m, int n, int, float4 acc, const float4 (&)[4], float4 &,
+                                          float4 &) const {
+        *reinterpret_cast<float4 *>(dX + m * ldx + n) = acc;
     }
     __device__ __forceinline__ void flush(int, int, double, double) const {}
 };
 
 // ----------------------------------------------------------------------------- NT GEMM core
-// C[P,N] = A[P,K] * Bw[N,K]^T.  A rows come from a loader, Bw is a plain padded matrix.
-// 4 waves as WR x WC, wave tile (BM/WR) x (BN/WC) built from 32x32 MFMA tiles.
-// Each workgroup walks row tiles blockIdx.x, +gridDim.x, ... so per-channel reductions are
-// kept in registers across tiles and flushed once (one fp64 atomic per channel per workgroup).
+// C[P,N] = A[P,K] * Bw[N,K]^T for a tall, skinny problem (P ~ 1e5..1e6 rows, K and N <= a few hundred):
+// A rows come from a loader functor, Bw is a plain zero-padded matrix, the output goes through an
+// epilogue functor.  4 waves as WR x WC, wave tile (BM/WR) x (BN/WC) built from 32x32x2 f32 MFMA tiles.
+//
+//  * Persistent: gridDim.x <= ~2 workgroups per CU walk the row tiles, so the per-channel reductions
+//    stay in registers across tiles and are flushed once per workgroup (LDS combine, then one fp64
+//    atomic per channel) -- with one workgroup per tile the 2048-deep same-address atomic queue cost more
+//    than the GEMM itself.
+//  * Software pipeline over the flattened (row tile, k-step) sequence: the global loads of step s+1 are
+//    issued right after the LDS stores of step s and fly under its MFMAs (and under the epilogue at a
+//    tile boundary); LDS is double buffered, ONE barrier per k-step.
+//  * Epilogue through LDS: the accumulators (column on the lane, rows in registers) are staged into a
+//    [BM][BN+4] image aliasing the operand buffers and read back row-wise, so Y / dX / prevY are moved
+//    with 16-byte coalesced accesses instead of 64 strided dword stores per lane.
 //
 // LDS operands are K-contiguous.  One ds_read_b128 gives a lane 4 k-values (k = 8*kb + 4*(lane>>5) + e);
-// MFMA e of the group consumes element e from both operands, i.e. the k-order inside an
-// 8-block is permuted identically for A and B, which leaves every product pair intact.
+// MFMA e of the group consumes element e from both operands, i.e. the k-order inside an 8-block is
+// permuted identically for A and B, which leaves every product pair intact.
+template <int BM, int BN>
+struct NtLds {
+    static constexpr int kOperands = 2 * (BM + BN) * LDP;            // floats, double buffered
+    static constexpr int kStage = BM * (BN + 4);                      // floats, aliases the operands
+    static constexpr int kReduce = NTHREADS * 8 * 2;                  // floats (256 x 8 doubles)
+    static constexpr int kFloats = kOperands > kStage ? (kOperands > kReduce ? kOperands : kReduce)
+                                                      : (kStage > kReduce ? kStage : kReduce);
+};
+
 template <int BM, int BN, int WR, int WC, class ALoad, class Epi>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad aload, const float *__restrict__ Bw, int ldb,
-                                                           int64_t P, int K4, int N, Epi epi) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad aload, const float *__restrict__ Bw, int ldb,
+                                                              int64_t P, int K4, int N, Epi epi) {
     static_assert(WR * WC == 4, "four waves");
     constexpr int WTM = BM / WR, WTN = BN / WC;      // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;      // MFMA tiles per wave
     constexpr int A_IT = BM * (BK / 4) / NTHREADS, B_IT = BN * (BK / 4) / NTHREADS;
+    constexpr int CG = BN / 4;                       // float4 column groups of the output tile
+    constexpr int RPP = NTHREADS / CG;               // rows per epilogue pass
+    constexpr int LDC = BN + 4;
     static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 loader threads");
 
-    __shared__ float As[BM * LDP];
-    __shared__ float Bs[BN * LDP];
+    __shared__ __attribute__((aligned(16))) float lds[NtLds<BM, BN>::kFloats];
+    float *As = lds;                                  // [2][BM*LDP]
+    float *Bs = lds + 2 * BM * LDP;                   // [2][BN*LDP]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const int l31 = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const int64_t tiles_m = (P + BM - 1) / BM;
+    const int nk = (K4 + BK - 1) / BK;
+    const int lrow = t >> 3, lkq = (t & 7) * 4;       // loader coordinates: 8 threads per 32-float row segment
+    const int ecg = t % CG, erow = t / CG;            // epilogue coordinates
+    const int en = n0 + ecg * 4;
 
-    double st0[TN], st1[TN];
+    float4 ec[4];
+    if (en < ((N + 3) & ~3)) epi.prep(en, N, ec);
+    double st[8];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { st0[j] = 0.0; st1[j] = 0.0; }
+    for (int e = 0; e < 8; ++e) st[e] = 0.0;
 
-    for (int64_t tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
+    float4 ra[A_IT], rb[B_IT];
+    auto fetch = [&](int64_t tile, int ks) {
+        const int64_t m0 = tile * BM;
+        const int k = ks * BK + lkq;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int64_t m = m0 + lrow + i * 32;
+            ra[i] = (m < P && k < K4) ? aload(m, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = n0 + lrow + i * 32;
+            rb[i] = (n < N && k < K4) ? ld4(Bw + (int64_t)n * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    int64_t tile = blockIdx.x;
+    if (tile < tiles_m) fetch(tile, 0);
+    int buf = 0;
+    for (; tile < tiles_m; tile += gridDim.x) {
         const int64_t m0 = tile * BM;
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -185,41 +262,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad aload, const fl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        for (int k0 = 0; k0 < K4; k0 += BK) {
-            float4 ra[A_IT], rb[B_IT];
+        for (int ks = 0; ks < nk; ++ks) {
+            float *Ab = As + buf * (BM * LDP), *Bb = Bs + buf * (BN * LDP);
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                int f = t + i * NTHREADS, row = f >> 3, kq = (f & 7) * 4;
-                int64_t m = m0 + row;
-                ra[i] = (m < P && k0 + kq < K4) ? aload(m, k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4 *>(&Ab[(lrow + i * 32) * LDP + lkq]) = ra[i];
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                int f = t + i * NTHREADS, row = f >> 3, kq = (f & 7) * 4;
-                int n = n0 + row;
-                rb[i] = (n < N && k0 + kq < K4) ? ld4(Bw + (int64_t)n * ldb + k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                int f = t + i * NTHREADS, row = f >> 3, kq = (f & 7) * 4;
-                *reinterpret_cast<float4 *>(&As[row * LDP + kq]) = ra[i];
-            }
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                int f = t + i * NTHREADS, row = f >> 3, kq = (f & 7) * 4;
-                *reinterpret_cast<float4 *>(&Bs[row * LDP + kq]) = rb[i];
-            }
+            for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4 *>(&Bb[(lrow + i * 32) * LDP + lkq]) = rb[i];
+            // next step's operands: same tile, or the first k-step of this workgroup's next tile
+            if (ks + 1 < nk) fetch(tile, ks + 1);
+            else if (tile + gridDim.x < tiles_m) fetch(tile + gridDim.x, 0);
             __syncthreads();
 #pragma unroll
             for (int kb = 0; kb < BK / 8; ++kb) {
                 float4 a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    a[i] = *reinterpret_cast<const float4 *>(&As[(wr * WTM + i * 32 + l31) * LDP + kb * 8 + lh * 4]);
+                    a[i] = *reinterpret_cast<const float4 *>(&Ab[(wr * WTM + i * 32 + l31) * LDP + kb * 8 + lh * 4]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    b[j] = *reinterpret_cast<const float4 *>(&Bs[(wc * WTN + j * 32 + l31) * LDP + kb * 8 + lh * 4]);
+                    b[j] = *reinterpret_cast<const float4 *>(&Bb[(wc * WTN + j * 32 + l31) * LDP + kb * 8 + lh * 4]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -230,47 +291,68 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(ALoad aload, const fl
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                     }
             }
+            buf ^= 1;
         }
 
-        // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // ---- epilogue: accumulators -> LDS image [BM][LDC] (aliases the operand buffers) -> rows
+        __syncthreads();                                   // every wave is done reading the operands
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * WTN + j * 32 + l31;
-            const bool nvalid = n < N;
-            float c[4];
-            epi.prep(n, nvalid, c);
-            float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (nvalid && m < P) epi.elem(m, n, acc[i][j][r], c, s0, s1);
-                }
+                for (int r = 0; r < 16; ++r)               // D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                    lds[(wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wc * WTN + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        if (en < ((N + 3) & ~3)) {
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+#pragma unroll 4
+            for (int r = erow; r < BM; r += RPP) {
+                const int64_t m = m0 + r;
+                if (m < P) epi.apply(m, en, N, *reinterpret_cast<const float4 *>(&lds[r * LDC + ecg * 4]), ec, s0, s1);
             }
-            if (Epi::kHasStats) { st0[j] += (double)s0; st1[j] += (double)s1; }
+            if (Epi::kHasStats) {
+                st[0] += (double)s0.x; st[1] += (double)s0.y; st[2] += (double)s0.z; st[3] += (double)s0.w;
+                st[4] += (double)s1.x; st[5] += (double)s1.y; st[6] += (double)s1.z; st[7] += (double)s1.w;
+            }
         }
+        __syncthreads();                                   // image consumed before the next tile's operands land
     }
 
-    if (Epi::kHasStats && epi.want_stats()) {
+    if (Epi::kHasStats && epi.want_stats()) {              // combine the RPP row-threads of each column, flush once
+        double *red = reinterpret_cast<double *>(lds);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            double a0 = st0[j] + __shfl_xor(st0[j], 32, 64);
-            double a1 = st1[j] + __shfl_xor(st1[j], 32, 64);
-            const int n = n0 + wc * WTN + j * 32 + l31;
-            if (lh == 0 && n < N) epi.flush(n, N, a0, a1);
+        for (int e = 0; e < 8; ++e) red[t * 8 + e] = st[e];
+        __syncthreads();
+        if (t < BN) {
+            const int cg = t >> 2, e = t & 3;
+            double a0 = 0.0, a1 = 0.0;
+            for (int j = 0; j < RPP; ++j) {
+                a0 += red[(j * CG + cg) * 8 + e];
+                a1 += red[(j * CG + cg) * 8 + 4 + e];
+            }
+            if (n0 + t < N) epi.flush(n0 + t, N, a0, a1);
         }
     }
+}
+
+inline int pn2_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
 }
 
 template <int BM, int BN, int WR, int WC, class ALoad, class Epi>
 int launch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     int64_t tiles_m = pn2_cdiv(P, BM);
     unsigned tiles_n = (unsigned)pn2_cdiv(N, BN);
-    // enough workgroups to fill 256 CUs several times over, few enough that the per-workgroup
-    // statistics flush stays negligible
-    int64_t cap = 2048 / tiles_n;
-    if (cap < 256) cap = 256;
+    int64_t cap = (int64_t)pn2_num_cus() * 2 / tiles_n;     // two resident workgroups per CU in total
+    if (cap < 1) cap = 1;
     unsigned gx = (unsigned)(tiles_m < cap ? tiles_m : cap);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WR, WC, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS), 0, s, aload, Bw,
                        ldb, P, K4, N, epi);
@@ -281,27 +363,28 @@ template <class ALoad, class Epi>
 int dispatch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     if (N <= 32) return launch_nt<128, 32, 4, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     if (N <= 64) return launch_nt<128, 64, 2, 2>(aload, Bw, ldb, P, K4, N, epi, s);
-    if (N <= 128 || N > 256) return launch_nt<128, 128, 2, 2>(aload, Bw, ldb, P, K4, N, epi, s);
-    return launch_nt<64, 256, 1, 4>(aload, Bw, ldb, P, K4, N, epi, s);
+    return launch_nt<128, 128, 2, 2>(aload, Bw, ldb, P, K4, N, epi, s);
 }
 
 // ----------------------------------------------------------------------------- TN GEMM (wgrad)
 // dW[M,N] += sum_p dY[p,m] * X[p,n]: both operands arrive position-major and are consumed
 // "down the columns" (ds_read_b32, consecutive lanes on consecutive channels: conflict free).
-// Split over P across gridDim.z; partial tiles are combined with fp32 atomics (256-B contiguous
-// per wave-instruction).
+// Split over P across gridDim.z; each workgroup pipelines its position steps exactly like the NT
+// core (register prefetch under the MFMAs, double-buffered LDS, one barrier per step) and adds its
+// partial tile with fp32 atomics (256 contiguous bytes per wave-instruction).
 constexpr int WG_BP = 32;     // positions per LDS stage
 
 template <int BM, int BN, int WR, int WC, class DyLoad, class XLoad>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk, int M,
-                                                           int N, float *__restrict__ dW, int lddw,
-                                                           float *__restrict__ dbias) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk,
+                                                              int M, int N, float *__restrict__ dW, int lddw,
+                                                              float *__restrict__ dbias) {
     constexpr int WTM = BM / WR, WTN = BN / WC;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_IT = WG_BP * (BM / 4) / NTHREADS, B_IT = WG_BP * (BN / 4) / NTHREADS;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
     static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
-    __shared__ float As[WG_BP * (BM + 4)];
-    __shared__ float Bs[WG_BP * (BN + 4)];
+    __shared__ __attribute__((aligned(16))) float As[2][WG_BP * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_BP * LDB];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -309,6 +392,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(DyLoad dyload, XLoad 
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int64_t p_begin = (int64_t)blockIdx.z * chunk;
     const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
+    const int arow = t / (BM / 4), acq = (t % (BM / 4)) * 4;      // loader coordinates (fixed per thread)
+    const int brow = t / (BN / 4), bcq = (t % (BN / 4)) * 4;
+    constexpr int AR = NTHREADS / (BM / 4), BR = NTHREADS / (BN / 4);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -317,50 +403,49 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(DyLoad dyload, XLoad 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum[A_IT][4];
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) bsum[i][0] = bsum[i][1] = bsum[i][2] = bsum[i][3] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    float4 ra[A_IT], rb[B_IT];
+    auto fetch = [&](int64_t p0) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int64_t p = p0 + arow + i * AR;
+            ra[i] = (p < p_end && m0 + acq < M) ? dyload(p, m0 + acq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int64_t p = p0 + brow + i * BR;
+            rb[i] = (p < p_end && n0 + bcq < N) ? xload(p, n0 + bcq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    if (p_begin < p_end) fetch(p_begin);
+    int buf = 0;
     for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_BP) {
-        float4 ra[A_IT], rb[B_IT];
+        float *Ab = As[buf], *Bb = Bs[buf];
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            int f = t + i * NTHREADS, row = f / (BM / 4), cq = (f % (BM / 4)) * 4;
-            int64_t p = p0 + row;
-            ra[i] = (p < p_end && m0 + cq < M) ? dyload(p, m0 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bsum[i][0] += ra[i].x; bsum[i][1] += ra[i].y; bsum[i][2] += ra[i].z; bsum[i][3] += ra[i].w;
+            *reinterpret_cast<float4 *>(&Ab[(arow + i * AR) * LDA + acq]) = ra[i];
+            bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w;
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            int f = t + i * NTHREADS, row = f / (BN / 4), cq = (f % (BN / 4)) * 4;
-            int64_t p = p0 + row;
-            rb[i] = (p < p_end && n0 + cq < N) ? xload(p, n0 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            int f = t + i * NTHREADS, row = f / (BM / 4), cq = (f % (BM / 4)) * 4;
-            *reinterpret_cast<float4 *>(&As[row * (BM + 4) + cq]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            int f = t + i * NTHREADS, row = f / (BN / 4), cq = (f % (BN / 4)) * 4;
-            *reinterpret_cast<float4 *>(&Bs[row * (BN + 4) + cq]) = rb[i];
-        }
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4 *>(&Bb[(brow + i * BR) * LDB + bcq]) = rb[i];
+        if (p0 + WG_BP < p_end) fetch(p0 + WG_BP);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < WG_BP / 2; ++kk) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[(kk * 2 + lh) * (BM + 4) + wr * WTM + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[i] = Ab[(kk * 2 + lh) * LDA + wr * WTM + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk * 2 + lh) * (BN + 4) + wc * WTN + j * 32 + l31];
+            for (int j = 0; j < TN; ++j) b[j] = Bb[(kk * 2 + lh) * LDB + wc * WTN + j * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        buf ^= 1;
     }
 
 #pragma unroll
@@ -375,20 +460,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(DyLoad dyload, XLoad 
             }
         }
     if (dbias != nullptr && blockIdx.y == 0) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            int f = t + i * NTHREADS, cq = (f % (BM / 4)) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (m0 + cq + e < M) atomicAdd(dbias + m0 + cq + e, bsum[i][e]);
-        }
+        if (m0 + acq < M) atomicAdd(dbias + m0 + acq, bsum.x);
+        if (m0 + acq + 1 < M) atomicAdd(dbias + m0 + acq + 1, bsum.y);
+        if (m0 + acq + 2 < M) atomicAdd(dbias + m0 + acq + 2, bsum.z);
+        if (m0 + acq + 3 < M) atomicAdd(dbias + m0 + acq + 3, bsum.w);
     }
 }
 
 template <int BM, int BN, int WR, int WC, class DyLoad, class XLoad>
 int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
     unsigned tm = (unsigned)pn2_cdiv(M, BM), tn = (unsigned)pn2_cdiv(N, BN);
-    int64_t want = 2048 / ((int64_t)tm * tn);
+    int64_t want = (int64_t)pn2_num_cus() * 4 / ((int64_t)tm * tn);
     if (want < 1) want = 1;
     int64_t max_split = pn2_cdiv(P, 8 * WG_BP);
     int64_t split = want < max_split ? want : max_split;

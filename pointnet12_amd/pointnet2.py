@@ -6,14 +6,16 @@ the same ``state_dict`` keys, so reference checkpoints (``module.``-prefixed, mo
 load with :func:`load_reference_state`.  ``PointNet2SemSegMsg`` is the MSG-SemSeg benchmark
 network of SURVEY.md §8(d): ``PointNet2PartSegMsg_one_hot`` without the one-hot class label.
 
-The classification / segmentation heads (Linear / Conv1d + BatchNorm1d + Dropout + log_softmax,
-model/pointnet2.py:29-46, :154-175) sit outside the hot path and run as stock PyTorch-ROCm ops.
+The segmentation head (Conv1d + BatchNorm1d + ReLU + Dropout + Conv1d + log_softmax,
+model/pointnet2.py:154-175) reuses the HIP shared-MLP kernels for conv1/bn1/relu; the classification
+head (three Linear layers on a [B,1024] vector, model/pointnet2.py:29-46) is stock PyTorch-ROCm.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .pointnet_util import PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg
+from .pointnet_util import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg,
+                            shared_mlp)
 
 
 class _ClsHead(nn.Module):
@@ -41,9 +43,17 @@ class _SegHead(nn.Module):
         self.conv2 = nn.Conv1d(128, num_classes, 1)
 
     def _seg_head(self, l0_points):
-        feat = F.relu(self.bn1(self.conv1(l0_points)))
-        x = self.conv2(self.drop1(feat))
-        return F.log_softmax(x, dim=1).permute(0, 2, 1), feat
+        """conv1 + bn1 + relu + drop1 + conv2 + log_softmax (model/pointnet2.py:172-175) on position-major rows.
+
+        l0_points [B,128,N] is a channel-first view of channel-last storage, so the rows view is free;
+        conv1/bn1/relu run through the same HIP shared-MLP kernels as the SA/FP stacks, conv2 (128 -> classes)
+        is a plain library GEMM, and the result is already in the reference's [B, N, classes] output layout.
+        """
+        B, C, N = l0_points.shape
+        rows = l0_points.permute(0, 2, 1).reshape(B * N, C)
+        feat = shared_mlp(rows, C, [self.conv1], [self.bn1], 0, self.training)
+        x = F.linear(self.drop1(feat), self.conv2.weight.reshape(self.conv2.weight.shape[0], -1), self.conv2.bias)
+        return F.log_softmax(x, dim=-1).view(B, N, -1), feat.view(B, N, -1).permute(0, 2, 1)
 
 
 class PointNet2ClsMsg(_ClsHead):

@@ -355,6 +355,9 @@ def _flat_params(convs, bns):
 def shared_mlp(rows, c_in, convs, bns, pool, training):
     """rows [P, ld] -> [P/pool, C_out] (pool > 0) or [P, C_out] (pool == 0) through the HIP kernels."""
     flat, cfg = _flat_params(convs, bns)
+    rows = _gpu_f32(rows, "rows")
+    if rows.dim() != 2 or rows.shape[1] != _r4(c_in):
+        raise RuntimeError("rows must be [P, round4(c_in)] with zero pad columns")
     return _SharedMLP.apply(rows, c_in, pool, training, cfg, *flat)
 
 

@@ -62,17 +62,28 @@ def test_shared_mlp_vs_torch(dev, P, pool, chans):
     (ref * gw.double()).sum().backward()
     assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
     theirs = [x64.grad] + [p.grad for p in list(c64.parameters()) + list(b64.parameters())]
+    # yardstick: the same op in plain torch fp32 on the GPU, measured against the same fp64 answer
+    x32 = rows[:, :c_in].to(dev).requires_grad_(True)
+    c32 = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])]).to(dev)
+    b32 = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]]).to(dev)
+    c32.load_state_dict(convs.state_dict())
+    b32.load_state_dict(b64.state_dict())
+    (torch_mlp(x32, c32, b32, pool, True, torch.float32) * gw).sum().backward()
+    plain = [x32.grad] + [p.grad for p in list(c32.parameters()) + list(b32.parameters())]
     names = ["x"] + [n for n, _ in list(convs.named_parameters()) + list(bns.named_parameters())]
-    for n, a, b in zip(names, mine, theirs):
-        if n.endswith("bias") and a.shape[0] in chans[1:] and "bias" in n and a.abs().max() == 0:
+    for n, a, b, c in zip(names, mine, theirs, plain):
+        if n.endswith("bias") and float(a.abs().max()) == 0:
             continue                                  # conv bias before a training-mode BN: exactly 0 here
         scale = max(float(b.abs().max()), 1e-9)
         err = (a.double() - b).abs().flatten()
-        # fp32 and fp64 may disagree on a near-tied argmax or on a ReLU input within an ulp of 0; such a flip
-        # re-routes one gradient entry.  Require 99.5 % of the entries tight and bound the rest in L2.
+        err32 = (c.double() - b).abs().flatten()
+        # fp32 and fp64 may disagree on a near-tied argmax or on a ReLU input within an ulp of 0 (a flip re-routes
+        # one gradient entry), and deep small-batch BN stacks are ill-conditioned in fp32 altogether: be as close
+        # to fp64 as 3e-5 of the tensor's max, or within 4x of what plain torch fp32 manages on the same input.
         k = max(1, int(err.numel() * 0.995))
-        assert float(err.kthvalue(k)[0]) <= 3e-5 * scale, (n, float(err.kthvalue(k)[0]) / scale)
-        assert float(err.norm() / b.norm().clamp_min(1e-30)) <= 1e-3, (n, float(err.norm() / b.norm()))
+        q, q32 = float(err.kthvalue(k)[0]), float(err32.kthvalue(k)[0])
+        assert q <= max(3e-5 * scale, 4 * q32), (n, q / scale, q32 / scale)
+        assert float(err.norm()) <= max(1e-3 * float(b.norm()), 4 * float(err32.norm())), n
     # running statistics: momentum 0.1, unbiased variance
     y = x64.detach()
     for l, (conv, bn) in enumerate(zip(c64, b64)):
