@@ -267,16 +267,23 @@ class _SharedMLP(torch.autograd.Function):
         _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), out.shape[1], _p(arg), st),
                "pn2_bn_relu_max")
         ctx.meta = (chans, pool, bool(training), P)
-        ctx.tensors = (rows, Ys, affs, out, arg, [flat[7 * l] for l in range(L)], [flat[7 * l + 2] for l in range(L)])
+        # save_for_backward (not ctx attributes): `out` is this node's own output, and holding it on ctx would close a
+        # reference cycle that only the cyclic GC breaks -- gigabytes of saved activations would pile up for several
+        # steps and the caching allocator would stall in hipMalloc/hipFree in the middle of a step.
+        ctx.save_for_backward(rows, out, arg, *Ys, *affs, *[flat[7 * l] for l in range(L)],
+                              *[flat[7 * l + 2] for l in range(L)])
         return out[:, :cl] if out.shape[1] != cl else out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib, st = _lib.load(), _lib.stream()
         chans, pool, training, P = ctx.meta
-        rows, Ys, affs, out, arg, Ws, gammas = ctx.tensors
+        saved = ctx.saved_tensors
+        L = len(chans) - 1
+        rows, out, arg = saved[0], saved[1], saved[2]
+        Ys, affs = saved[3:3 + L], saved[3 + L:3 + 2 * L]
+        Ws, gammas = saved[3 + 2 * L:3 + 3 * L], saved[3 + 3 * L:3 + 4 * L]
         dev = rows.device
-        L = len(Ys)
         cl = chans[-1]
         ldo = out.shape[1]
         if ldo != cl:
