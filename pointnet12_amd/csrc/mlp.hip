@@ -6,13 +6,12 @@
 // Activations are position-major: row p = one grouped position, channels contiguous.
 // Replaces model/pointnet_util.py:194-199, :251-256, :309-312 and their autograd.
 #include "pn2_common.h"
+#include <stdlib.h>
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 32;        // k-depth of one LDS stage
-constexpr int LDP = BK + 4;   // LDS row pitch in floats: 16 consecutive rows cover all 64 banks once
 constexpr int NTHREADS = 256; // 4 waves
 
 // relu(bn(y)) exactly as every consumer applies it: the ReLU mask of the backward pass must
@@ -121,7 +120,9 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
             if (n + 2 >= N) y.z = 0.f;
             y.w = 0.f;
         }
+#ifndef PN2_X_NOSTORE
         *reinterpret_cast<float4 *>(Y + m * ldy + n) = y;
+#endif
         s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
         s1.x = __builtin_fmaf(y.x, y.x, s1.x); s1.y = __builtin_fmaf(y.y, y.y, s1.y);
         s1.z = __builtin_fmaf(y.z, y.z, s1.z); s1.w = __builtin_fmaf(y.w, y.w, s1.w);
@@ -192,28 +193,44 @@ struct EpiStore {           // first layer: dX0 = acc (pad lanes are exact zeros
 // LDS operands are K-contiguous.  One ds_read_b128 gives a lane 4 k-values (k = 8*kb + 4*(lane>>5) + e);
 // MFMA e of the group consumes element e from both operands, i.e. the k-order inside an 8-block is
 // permuted identically for A and B, which leaves every product pair intact.
-template <int BM, int BN>
+#ifdef PN2_STAMP
+// Diagnostic build only (make STAMP=1): per-phase shader-cycle sums of wave 0 of every workgroup of the last
+// NT GEMM launch, read back with pn2_debug_stamps().  Never compiled into the shipped library.
+__device__ unsigned long long pn2_stamp_buf[8 * 2048];
+#define STAMP_DECL unsigned long long stamp_t = clock64(), stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = clock64(); stamp_acc[i] += n_ - stamp_t; stamp_t = n_; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_FLUSH if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048) { for (int i_ = 0; i_ < 8; ++i_) pn2_stamp_buf[blockIdx.x * 8 + i_] = stamp_acc[i_]; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+template <int BM, int BN, int BK>
 struct NtLds {
-    static constexpr int kOperands = 2 * (BM + BN) * LDP;            // floats, double buffered
+    static constexpr int kOperands = 2 * (BM + BN) * (BK + 4);       // floats, double buffered
     static constexpr int kStage = BM * (BN + 4);                      // floats, aliases the operands
     static constexpr int kReduce = NTHREADS * 8 * 2;                  // floats (256 x 8 doubles)
     static constexpr int kFloats = kOperands > kStage ? (kOperands > kReduce ? kOperands : kReduce)
                                                       : (kStage > kReduce ? kStage : kReduce);
 };
 
-template <int BM, int BN, int WR, int WC, class ALoad, class Epi>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad aload, const float *__restrict__ Bw, int ldb,
+template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, class ALoad, class Epi>
+__global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, const float *__restrict__ Bw, int ldb,
                                                               int64_t P, int K4, int N, Epi epi) {
     static_assert(WR * WC == 4, "four waves");
     constexpr int WTM = BM / WR, WTN = BN / WC;      // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;      // MFMA tiles per wave
-    constexpr int A_IT = BM * (BK / 4) / NTHREADS, B_IT = BN * (BK / 4) / NTHREADS;
+    constexpr int LDP = BK + 4;                      // LDS row pitch: 16 consecutive rows cover all 64 banks once
+    constexpr int TPR = BK / 4;                      // loader threads per row segment
+    constexpr int RPL = NTHREADS / TPR;              // rows per loader pass
+    constexpr int A_IT = BM / RPL, B_IT = BN / RPL;
     constexpr int CG = BN / 4;                       // float4 column groups of the output tile
     constexpr int RPP = NTHREADS / CG;               // rows per epilogue pass
     constexpr int LDC = BN + 4;
     static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 loader threads");
 
-    __shared__ __attribute__((aligned(16))) float lds[NtLds<BM, BN>::kFloats];
+    __shared__ __attribute__((aligned(16))) float lds[NtLds<BM, BN, BK>::kFloats];
     float *As = lds;                                  // [2][BM*LDP]
     float *Bs = lds + 2 * BM * LDP;                   // [2][BN*LDP]
 
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad aload, const
     const int n0 = blockIdx.y * BN;
     const int64_t tiles_m = (P + BM - 1) / BM;
     const int nk = (K4 + BK - 1) / BK;
-    const int lrow = t >> 3, lkq = (t & 7) * 4;       // loader coordinates: 8 threads per 32-float row segment
+    const int lrow = t / TPR, lkq = (t % TPR) * 4;    // loader coordinates
     const int ecg = t % CG, erow = t / CG;            // epilogue coordinates
     const int en = n0 + ecg * 4;
 
@@ -233,45 +250,65 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad aload, const
 #pragma unroll
     for (int e = 0; e < 8; ++e) st[e] = 0.0;
 
-    float4 ra[A_IT], rb[B_IT];
-    auto fetch = [&](int64_t tile, int ks) {
+    // Register ring of DEPTH prefetched k-steps: the operands of step s+DEPTH are requested right after the
+    // LDS stores of step s, so DEPTH-1 further steps of MFMA work (and a tile's epilogue) cover their latency.
+    float4 ra[DEPTH][A_IT], rb[DEPTH][B_IT];
+    auto fetch = [&](float4 (&qa)[A_IT], float4 (&qb)[B_IT], int64_t tile, int ks) {
         const int64_t m0 = tile * BM;
         const int k = ks * BK + lkq;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int64_t m = m0 + lrow + i * 32;
-            ra[i] = (m < P && k < K4) ? aload(m, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int64_t m = m0 + lrow + i * RPL;
+#ifdef PN2_X_NOALOAD
+            qa[i] = make_float4((float)m, 0.f, 0.f, 1.f);
+#else
+            qa[i] = (m < P && k < K4) ? aload(m, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + lrow + i * 32;
-            rb[i] = (n < N && k < K4) ? ld4(Bw + (int64_t)n * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = n0 + lrow + i * RPL;
+#ifdef PN2_X_NOBLOAD
+            qb[i] = make_float4(1.f, 0.f, 0.f, 0.f);
+#else
+            qb[i] = (n < N && k < K4 && tile < tiles_m) ? ld4(Bw + (int64_t)n * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
     };
 
-    int64_t tile = blockIdx.x;
-    if (tile < tiles_m) fetch(tile, 0);
+    int64_t tile = blockIdx.x, ptile = blockIdx.x;   // current step and prefetch cursor over (tile, ks)
+    int ks = 0, pks = 0;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        fetch(ra[d], rb[d], ptile, pks);             // beyond the last tile every lane is predicated off (m >= P)
+        if (++pks == nk) { pks = 0; ptile += gridDim.x; }
+    }
     int buf = 0;
-    for (; tile < tiles_m; tile += gridDim.x) {
-        const int64_t m0 = tile * BM;
-        f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN];
+    STAMP_DECL
+    while (tile < tiles_m) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int d = 0; d < DEPTH; ++d) {
+            if (tile >= tiles_m) break;
+            const int64_t m0 = tile * BM;
+            if (ks == 0) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        for (int ks = 0; ks < nk; ++ks) {
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
             float *Ab = As + buf * (BM * LDP), *Bb = Bs + buf * (BN * LDP);
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4 *>(&Ab[(lrow + i * 32) * LDP + lkq]) = ra[i];
+            for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) = ra[d][i];
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4 *>(&Bb[(lrow + i * 32) * LDP + lkq]) = rb[i];
-            // next step's operands: same tile, or the first k-step of this workgroup's next tile
-            if (ks + 1 < nk) fetch(tile, ks + 1);
-            else if (tile + gridDim.x < tiles_m) fetch(tile + gridDim.x, 0);
+            for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4 *>(&Bb[(lrow + i * RPL) * LDP + lkq]) = rb[d][i];
+            fetch(ra[d], rb[d], ptile, pks);
+            if (++pks == nk) { pks = 0; ptile += gridDim.x; }
+            STAMP(0)
             __syncthreads();
+            STAMP(1)
 #pragma unroll
             for (int kb = 0; kb < BK / 8; ++kb) {
                 float4 a[TM], b[TN];
@@ -292,32 +329,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(ALoad aload, const
                     }
             }
             buf ^= 1;
-        }
+            STAMP(2)
+            if (++ks < nk) continue;
+            ks = 0;
 
-        // ---- epilogue: accumulators -> LDS image [BM][LDC] (aliases the operand buffers) -> rows
-        __syncthreads();                                   // every wave is done reading the operands
+            // ---- epilogue: accumulators -> LDS image [BM][LDC] (aliases the operand buffers) -> rows
+            __syncthreads();                               // every wave is done reading the operands
+            STAMP(3)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)               // D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                    lds[(wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wc * WTN + j * 32 + l31] = acc[i][j][r];
-        __syncthreads();
-        if (en < ((N + 3) & ~3)) {
-            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+                    for (int r = 0; r < 16; ++r)           // D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                        lds[(wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wc * WTN + j * 32 + l31] = acc[i][j][r];
+            STAMP(4)
+            __syncthreads();
+            STAMP(5)
+            if (en < ((N + 3) & ~3)) {
+                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
 #pragma unroll 4
-            for (int r = erow; r < BM; r += RPP) {
-                const int64_t m = m0 + r;
-                if (m < P) epi.apply(m, en, N, *reinterpret_cast<const float4 *>(&lds[r * LDC + ecg * 4]), ec, s0, s1);
+                for (int r = erow; r < BM; r += RPP) {
+                    const int64_t m = m0 + r;
+                    if (m < P) epi.apply(m, en, N, *reinterpret_cast<const float4 *>(&lds[r * LDC + ecg * 4]), ec, s0, s1);
+                }
+                if (Epi::kHasStats) {
+                    st[0] += (double)s0.x; st[1] += (double)s0.y; st[2] += (double)s0.z; st[3] += (double)s0.w;
+                    st[4] += (double)s1.x; st[5] += (double)s1.y; st[6] += (double)s1.z; st[7] += (double)s1.w;
+                }
             }
-            if (Epi::kHasStats) {
-                st[0] += (double)s0.x; st[1] += (double)s0.y; st[2] += (double)s0.z; st[3] += (double)s0.w;
-                st[4] += (double)s1.x; st[5] += (double)s1.y; st[6] += (double)s1.z; st[7] += (double)s1.w;
-            }
+            STAMP(6)
+            __syncthreads();                               // image consumed before the next tile's operands land
+            STAMP(7)
+            tile += gridDim.x;
         }
-        __syncthreads();                                   // image consumed before the next tile's operands land
     }
+    STAMP_FLUSH
 
     if (Epi::kHasStats && epi.want_stats()) {              // combine the RPP row-threads of each column, flush once
         double *red = reinterpret_cast<double *>(lds);
@@ -347,23 +394,33 @@ inline int pn2_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int WR, int WC, class ALoad, class Epi>
+template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, class ALoad, class Epi>
 int launch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     int64_t tiles_m = pn2_cdiv(P, BM);
     unsigned tiles_n = (unsigned)pn2_cdiv(N, BN);
-    int64_t cap = (int64_t)pn2_num_cus() * 2 / tiles_n;     // two resident workgroups per CU in total
+    int64_t cap = (int64_t)pn2_num_cus() * MINB / tiles_n;  // MINB resident workgroups per CU in total
     if (cap < 1) cap = 1;
     unsigned gx = (unsigned)(tiles_m < cap ? tiles_m : cap);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WR, WC, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS), 0, s, aload, Bw,
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS), 0, s, aload, Bw,
                        ldb, P, K4, N, epi);
     return pn2_launch_status();
 }
 
+inline int pn2_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <class ALoad, class Epi>
 int dispatch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
-    if (N <= 32) return launch_nt<128, 32, 4, 1>(aload, Bw, ldb, P, K4, N, epi, s);
-    if (N <= 64) return launch_nt<128, 64, 2, 2>(aload, Bw, ldb, P, K4, N, epi, s);
-    return launch_nt<128, 128, 2, 2>(aload, Bw, ldb, P, K4, N, epi, s);
+    static const int cfg = pn2_env_int("PN2_NT_CFG", 0);     // tuning hook (tools/bench_kernels.py)
+    if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (cfg == 1) return launch_nt<128, 128, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (cfg == 2) return launch_nt<64, 128, 16, 2, 2, 4, 2>(aload, Bw, ldb, P, K4, N, epi, s);
+    // 64x128 tiles, 16-deep k-steps, four resident workgroups per CU: +10..17 % over 128x128x32 at two per CU
+    // (more independent waves hide the operand stream's latency; measured in tools/bench_kernels.py)
+    return launch_nt<64, 128, 16, 2, 2, 4, 1>(aload, Bw, ldb, P, K4, N, epi, s);
 }
 
 // ----------------------------------------------------------------------------- TN GEMM (wgrad)
@@ -488,6 +545,8 @@ int dispatch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, 
     if (N <= 32) return launch_tn<128, 32, 4, 1>(dyload, xload, P, M, N, dW, lddw, dbias, s);
     if (M <= 32) return launch_tn<32, 128, 1, 4>(dyload, xload, P, M, N, dW, lddw, dbias, s);
     if (M <= 64 && N <= 64) return launch_tn<64, 64, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    if (N <= 64 || (N > 128 && N % 128 <= 64 && N % 128 != 0 && N < 256)) return launch_tn<128, 64, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    if (M <= 64) return launch_tn<64, 128, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
     return launch_tn<128, 128, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
 }
 
@@ -623,6 +682,13 @@ __global__ void bn_bwd_coef_kernel(const double *__restrict__ red, double inv_p,
 inline int round4(int x) { return (x + 3) & ~3; }
 
 }  // namespace
+
+#ifdef PN2_STAMP
+extern "C" int pn2_debug_stamps(unsigned long long *host_out, int n) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pn2_stamp_buf), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" {
 

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the shared-MLP GEMM entry points on the layer shapes of MSG-SemSeg (B=16 x 4096).
+
+    python tools/bench_kernels.py [fwd|dgrad|wgrad|all] [--reps 20]
+
+Prints per shape: time, TFLOP/s (2*P*K*N), algorithmic GB/s, and the larger of the two roofline fractions.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+
+from pointnet12_amd import _lib
+from pointnet12_amd._lib import ptr as p
+
+FWD = [(1048576, 9, 64), (1048576, 64, 96), (1048576, 96, 128), (524288, 64, 64), (524288, 64, 128), (262144, 323, 128),
+       (262144, 128, 196), (262144, 196, 256), (131072, 323, 128), (131072, 128, 256), (262144, 32, 64), (65536, 128, 128)]
+# backward shapes: (P, C_l, C_{l-1}, pooled K or 0)
+BWD = [(1048576, 128, 96, 128), (1048576, 96, 64, 0), (262144, 256, 196, 128), (262144, 196, 128, 0), (262144, 128, 323, 0),
+       (524288, 128, 64, 64), (524288, 64, 64, 0), (131072, 256, 128, 64), (65536, 128, 128, 0)]
+
+
+def r4(c):
+    return (c + 3) & ~3
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+def report(tag, shape, secs, flops, nbytes):
+    tf, gbs = flops / secs / 1e12, nbytes / secs / 1e9
+    print("%-6s %-28s %8.1f us %7.2f TF %8.1f GB/s  frac %.3f" % (tag, shape, secs * 1e6, tf, gbs, max(tf / 157.3, gbs / 8000)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="?", default="all")
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def rnd(*s):
+        return torch.randn(*s, device=dev, generator=g)
+
+    def affine(c):
+        a = torch.zeros(4 * r4(c), device=dev)
+        a[:c] = rnd(c) * 0.1
+        a[r4(c):r4(c) + c] = 1.0 + rnd(c) * 0.1
+        a[2 * r4(c):2 * r4(c) + c] = rnd(c) * 0.1
+        a[3 * r4(c):3 * r4(c) + c] = 1.0
+        return a
+
+    if args.which in ("fwd", "all"):
+        for P, K, N in FWD:
+            X = torch.zeros(P, r4(K), device=dev)
+            X[:, :K] = rnd(P, K)
+            W = torch.zeros(N, r4(K), device=dev)
+            W[:, :K] = rnd(N, K)
+            bias, Y = rnd(N), torch.empty(P, r4(N), device=dev)
+            stats = torch.zeros(2 * N, device=dev, dtype=torch.float64)
+            aff = affine(K) if K > 12 else None
+
+            def fn():
+                rc = lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), r4(K), p(bias), p(Y), r4(N), P, K, N, p(stats), st)
+                assert rc == 0
+            report("fwd", (P, K, N), timeit(fn, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
+            del X, Y
+
+    for which in ("dgrad", "wgrad"):
+        if args.which not in (which, "all"):
+            continue
+        for P, Cl, Cp, Kp in BWD:
+            Y, Yp = rnd(P, r4(Cl)), rnd(P, r4(Cp))
+            coef, affp = affine(Cl), affine(Cp)
+            Wt = torch.zeros(Cp, r4(Cl), device=dev)
+            Wt[:, :Cl] = rnd(Cp, Cl)
+            if Kp:
+                G = P // Kp
+                dOut, out = rnd(G, r4(Cl)), rnd(G, r4(Cl))
+                arg = torch.randint(0, Kp, (G, r4(Cl)), device=dev, dtype=torch.int32, generator=g)
+                dz = (None, 0, p(dOut), r4(Cl), p(out), p(arg), Kp)
+                dy_bytes = P * Cl
+            else:
+                dZ = rnd(P, r4(Cl))
+                dz = (p(dZ), r4(Cl), None, 0, None, None, 0)
+                dy_bytes = 2 * P * Cl
+            if which == "dgrad":
+                dX = torch.empty(P, r4(Cp), device=dev)
+                red = torch.zeros(2 * Cp, device=dev, dtype=torch.float64)
+
+                def fn():
+                    rc = lib.pn2_conv1x1_dgrad(*dz, p(Y), r4(Cl), p(coef), p(Wt), r4(Cl), p(Yp), r4(Cp), p(affp), p(dX), r4(Cp),
+                                               p(red), P, Cl, Cp, st)
+                    assert rc == 0
+                report("dgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
+            else:
+                dW = torch.zeros(Cl, Cp, device=dev)
+
+                def fn():
+                    rc = lib.pn2_conv1x1_wgrad(*dz, p(Y), r4(Cl), p(coef), p(Yp), r4(Cp), p(affp), p(dW), Cp, None, P, Cl, Cp, st)
+                    assert rc == 0
+                report("wgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + P * Cp))
+
+
+if __name__ == "__main__":
+    main()
