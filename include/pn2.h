@@ -89,6 +89,21 @@ int pn2_group(const float *xyz, const float *points, const float *new_xyz, const
 int pn2_group_bwd(const float *grad_rows, const int64_t *idx, int B, int N, int S, int K, int D, int xyz_first,
                   int ld, float *grad_points, pn2_stream_t stream);
 
+/* Factorised first MLP layer of a set-abstraction level (replaces gather + cat + the first 1x1 conv,
+ * model/pointnet_util.py:127-131,:197 / :243-247,:254, for that layer only):
+ *   Y[p, c] = Zf[b, idx[p], c] + sum_a Wx[c, a] * (xyz[b, idx[p], a] - new_xyz[b, s, a]),  p = (b, s, k)
+ * with Zf [B*N, ldz] = W_f f + bias precomputed per SOURCE point (one small pn2_conv1x1_fwd) and
+ * Wx [C, 3] the xyz columns of the layer's weight.  stats as in pn2_conv1x1_fwd (double[2*C], may be NULL). */
+int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float *new_xyz, const int64_t *idx,
+                         const float *Wx, int B, int N, int S, int K, int C, float *Y, int ldy, double *stats,
+                         pn2_stream_t stream);
+/* backward: dY = c0*dZ + q1*(y-mean) + q0 (coef from pn2_bn_bwd_coef) is scattered to the source points,
+ * G[b*N + idx[p], :] += dY[p, :] (G [B*N, ldg], caller zeroes), and dWx[c, a] += dY[p, c] * (xyz - centre)[a]
+ * (dWx [C, 3], caller zeroes). */
+int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
+                         const float *new_xyz, const int64_t *idx, int B, int N, int S, int K, int C, float *G, int ldg,
+                         float *dWx, pn2_stream_t stream);
+
 /* Inverse-distance interpolation, model/pointnet_util.py:301: out[b,n,col0+c] =
  * ((p2[i0,c]*w0 + p2[i1,c]*w1) + p2[i2,c]*w2).  points2 [B,S,D]; out rows of pitch ld
  * (so the result lands directly inside the concatenated FP input, :305). */

@@ -1,0 +1,178 @@
+// Factorised first layer of a set-abstraction MLP.
+//
+// The grouped input row of position p = (b, s, k) is [f_j, xyz_j - c_s] with j = idx[p], so the first
+// 1x1 convolution splits into a per-SOURCE-POINT part and a 3-term geometric part:
+//     y[p, :] = (W_f f_j + bias)  +  W_x (xyz_j - c_s)  =  Zf[b, j, :] + W_x (xyz_j - c_s)
+// Zf is one small GEMM over the B*N source points instead of the B*S*K grouped positions (K = 32..128
+// times fewer rows), the grouped tensor [P, 3+D] is never materialised, and the forward kernel is a row
+// gather of Zf plus three FMAs per output with the exactly centred coordinates (the subtraction happens
+// before the multiply, as in the reference, pointnet_util.py:128,244 -- no cancellation).
+// Replaces, for the first layer only: index_points + cat (pointnet_util.py:127-131, :243-247) and
+// nn.Conv2d (pointnet_util.py:197, :254), and their autograd.
+#include "pn2_common.h"
+
+namespace {
+
+// Per-channel sum(y), sum(y*y) for the training-mode BatchNorm are accumulated like in the GEMM epilogue:
+// fp32 per 64 rows -> fp64 registers -> LDS -> one fp64 atomic per channel per workgroup.
+__global__ __launch_bounds__(256) void group_affine_fwd_kernel(const float *__restrict__ Zf, int ldz,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ new_xyz,
+                                                               const int64_t *__restrict__ idx,
+                                                               const float *__restrict__ Wx, int N, int S, int K,
+                                                               int C, int64_t P, float *__restrict__ Y, int ldy,
+                                                               double *__restrict__ stats) {
+    __shared__ double red[256 * 8];
+    const int CG = (C + 3) >> 2;                  // float4 column groups per row
+    const int RPB = 256 / CG;                     // rows per pass
+    const int t = threadIdx.x, cg = t % CG, r = t / CG;
+    const bool live = r < RPB;
+    const int c = cg * 4;
+    float wx[4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) wx[e][a] = (live && c + e < C) ? Wx[(c + e) * 3 + a] : 0.f;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int since = 0;
+    if (live) {
+        for (int64_t p = (int64_t)blockIdx.x * RPB + r; p < P; p += (int64_t)gridDim.x * RPB) {
+            const int64_t g = p / K, b = g / S;
+            const int64_t j = idx[p];
+            const float *q = xyz + (b * N + j) * 3, *ctr = new_xyz + g * 3;
+            const float dx = q[0] - ctr[0], dy = q[1] - ctr[1], dz = q[2] - ctr[2];
+            const float4 z = *reinterpret_cast<const float4 *>(Zf + (b * N + j) * ldz + c);
+            float y[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = __builtin_fmaf(wx[e][0], dx, y[e]);
+                y[e] = __builtin_fmaf(wx[e][1], dy, y[e]);
+                y[e] = __builtin_fmaf(wx[e][2], dz, y[e]);
+                if (c + e >= C) y[e] = 0.f;
+                s0[e] += y[e];
+                s1[e] = __builtin_fmaf(y[e], y[e], s1[e]);
+            }
+            *reinterpret_cast<float4 *>(Y + p * ldy + c) = make_float4(y[0], y[1], y[2], y[3]);
+            if (++since == 64) {              // fold the fp32 partials into fp64 every 64 rows
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[e] += (double)s0[e]; st[4 + e] += (double)s1[e];
+                    s0[e] = 0.f; s1[e] = 0.f;
+                }
+                since = 0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st[e] += (double)s0[e]; st[4 + e] += (double)s1[e]; }
+    }
+    if (stats == nullptr) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[t * 8 + e] = st[e];
+    __syncthreads();
+    for (int ch = t; ch < C; ch += 256) {
+        const int g4 = ch >> 2, e = ch & 3;
+        double a0 = 0.0, a1 = 0.0;
+        for (int rr = 0; rr < RPB; ++rr) {
+            a0 += red[(rr * CG + g4) * 8 + e];
+            a1 += red[(rr * CG + g4) * 8 + 4 + e];
+        }
+        atomicAdd(stats + ch, a0);
+        atomicAdd(stats + C + ch, a1);
+    }
+}
+
+// Backward: dY = c0*dZ + q1*(y-mean) + q0 (BatchNorm backward folded into `coef`, see mlp.hip) is
+// scattered back to the source points, G[b, j, :] += dY[p, :], and contracted with the centred
+// coordinates, dWx[c, a] += dY[p, c] * (xyz_j - c_s)[a].  The weight / feature gradients then come from
+// two small GEMMs over the B*N source points (dW_f = G^T F, dF = G W_f).
+__global__ __launch_bounds__(256) void group_affine_bwd_kernel(const float *__restrict__ dZ, int ldz,
+                                                               const float *__restrict__ Y, int ldy,
+                                                               const float *__restrict__ coef, int ldc,
+                                                               const float *__restrict__ xyz,
+                                                               const float *__restrict__ new_xyz,
+                                                               const int64_t *__restrict__ idx, int N, int S, int K,
+                                                               int C, int64_t P, float *__restrict__ G, int ldg,
+                                                               float *__restrict__ dWx) {
+    __shared__ float red[256 * 12];
+    const int CG = (C + 3) >> 2;
+    const int RPB = 256 / CG;
+    const int t = threadIdx.x, cg = t % CG, r = t / CG;
+    const bool live = r < RPB;
+    const int c = cg * 4;
+    float acc[4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
+    if (live) {
+        const float4 c0 = *reinterpret_cast<const float4 *>(coef + c);
+        const float4 q1 = *reinterpret_cast<const float4 *>(coef + ldc + c);
+        const float4 q0 = *reinterpret_cast<const float4 *>(coef + 2 * ldc + c);
+        const float4 mu = *reinterpret_cast<const float4 *>(coef + 3 * ldc + c);
+        for (int64_t p = (int64_t)blockIdx.x * RPB + r; p < P; p += (int64_t)gridDim.x * RPB) {
+            const int64_t g = p / K, b = g / S;
+            const int64_t j = idx[p];
+            const float *q = xyz + (b * N + j) * 3, *ctr = new_xyz + g * 3;
+            const float d[3] = {q[0] - ctr[0], q[1] - ctr[1], q[2] - ctr[2]};
+            const float4 dz = *reinterpret_cast<const float4 *>(dZ + p * ldz + c);
+            const float4 y = *reinterpret_cast<const float4 *>(Y + p * ldy + c);
+            float dy[4];
+            dy[0] = __builtin_fmaf(c0.x, dz.x, __builtin_fmaf(q1.x, y.x - mu.x, q0.x));
+            dy[1] = __builtin_fmaf(c0.y, dz.y, __builtin_fmaf(q1.y, y.y - mu.y, q0.y));
+            dy[2] = __builtin_fmaf(c0.z, dz.z, __builtin_fmaf(q1.z, y.z - mu.z, q0.z));
+            dy[3] = __builtin_fmaf(c0.w, dz.w, __builtin_fmaf(q1.w, y.w - mu.w, q0.w));
+            float *gr = G + (b * N + j) * ldg + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (c + e < C) atomicAdd(gr + e, dy[e]);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[e][a] = __builtin_fmaf(dy[e], d[a], acc[e][a]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) red[t * 12 + e * 3 + a] = acc[e][a];
+    __syncthreads();
+    for (int o = t; o < C * 3; o += 256) {         // o = channel*3 + axis
+        const int ch = o / 3, a = o % 3, g4 = ch >> 2, e = ch & 3;
+        float sum = 0.f;
+        for (int rr = 0; rr < RPB; ++rr) sum += red[(rr * CG + g4) * 12 + e * 3 + a];
+        atomicAdd(dWx + o, sum);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float *new_xyz, const int64_t *idx,
+                         const float *Wx, int B, int N, int S, int K, int C, float *Y, int ldy, double *stats,
+                         pn2_stream_t stream) {
+    PN2_CHECK_ARG(Zf && xyz && new_xyz && idx && Wx && Y && B > 0 && N > 0 && S > 0 && K > 0 && C > 0 && C <= 1024);
+    PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldz >= ((C + 3) & ~3) && ldy >= ((C + 3) & ~3));
+    const int64_t P = (int64_t)B * S * K;
+    const int rpb = 256 / ((C + 3) >> 2);
+    int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(group_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), Zf, ldz, xyz, new_xyz, idx,
+                       Wx, N, S, K, C, P, Y, ldy, stats);
+    return pn2_launch_status();
+}
+
+int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
+                         const float *new_xyz, const int64_t *idx, int B, int N, int S, int K, int C, float *G, int ldg,
+                         float *dWx, pn2_stream_t stream) {
+    PN2_CHECK_ARG(dZ && Y && coef && xyz && new_xyz && idx && G && dWx && B > 0 && N > 0 && S > 0 && K > 0 && C > 0 &&
+                  C <= 1024);
+    PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldg % 4 == 0);
+    const int64_t P = (int64_t)B * S * K;
+    const int rpb = 256 / ((C + 3) >> 2);
+    int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(group_affine_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), dZ, ldz, Y, ldy, coef,
+                       (C + 3) & ~3, xyz, new_xyz, idx, N, S, K, C, P, G, ldg, dWx);
+    return pn2_launch_status();
+}
+
+}  // extern "C"

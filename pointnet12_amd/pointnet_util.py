@@ -223,33 +223,61 @@ class _InterpCat(torch.autograd.Function):
 class _SharedMLP(torch.autograd.Function):
     """L x (1x1 conv + BatchNorm + ReLU) on position-major rows, then max over ``pool`` consecutive rows.
 
-    forward(rows [P, ld0], c_in, pool, training, bn_cfg, *flat) with ``flat`` = per layer
+    forward(rows [P, ld0], c_in, pool, training, bn_cfg, geom, *flat) with ``flat`` = per layer
     (weight, bias, gamma, beta, running_mean, running_var, num_batches_tracked) and
     ``bn_cfg`` = per layer (eps, momentum).  pool == 0: no pooling, output [P, C_L] (FP);
     pool == K: output [P/K, C_L] (SA).  Pre-BN activations of every layer are kept for backward.
+
+    ``geom`` = None, or (xyz [B,N,3], new_xyz [B,S,3], idx [B,S,K], xyz_first) for the FACTORISED first layer:
+    ``rows`` is then the un-grouped feature tensor [B,N,D] and layer 1 is evaluated as
+    ``Zf[b, idx] + W_x (xyz[idx] - centre)`` with ``Zf = W_f f + bias`` computed once per source point
+    (csrc/grouped.hip) -- the grouped [P, 3+D] tensor never exists and the K-fold redundant GEMM rows vanish.
     """
 
     @staticmethod
-    def forward(ctx, rows, c_in, pool, training, bn_cfg, *flat):
+    def forward(ctx, rows, c_in, pool, training, bn_cfg, geom, *flat):
         lib, st = _lib.load(), _lib.stream()
         dev = rows.device
         L = len(flat) // 7
-        P = rows.shape[0]
+        if geom is None:
+            P = rows.shape[0]
+        else:
+            g_xyz, g_new, g_idx, g_first = geom
+            gB, gN, gD = rows.shape
+            gS, gK = g_idx.shape[1], g_idx.shape[2]
+            P = gB * gS * gK
         chans = [c_in] + [flat[7 * l].shape[0] for l in range(L)]
         stats = torch.zeros(2 * sum(chans[1:]), device=dev, dtype=torch.float64) if training else None
         Ys, affs, Wps = [], [], []
-        x, ldx, x_aff, off = rows, rows.shape[1], None, 0
+        x, ldx, x_aff, off = rows, rows.shape[-1], None, 0
         for l in range(L):
             w, b, gamma, beta, rmean, rvar, nbt = flat[7 * l:7 * l + 7]
             co, ci = chans[l + 1], chans[l]
-            wp = w.detach().reshape(co, ci)
-            if ldx != ci:
-                wp = torch.nn.functional.pad(wp, (0, ldx - ci))
-            wp = wp.contiguous()
             y = _empty_rows(P, co, dev)
             st_l = stats[off:off + 2 * co] if training else None
-            _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(wp), ldx, _p(b), _p(y), y.shape[1], P, ci, co,
-                                       _p(st_l), st), "pn2_conv1x1_fwd")
+            if l == 0 and geom is not None:
+                w2 = w.detach().reshape(co, ci)
+                wx = (w2[:, :3] if g_first else w2[:, gD:]).contiguous()
+                wf = w2[:, 3:] if g_first else w2[:, :gD]
+                ldd = _r4(gD)
+                feat = rows.reshape(gB * gN, gD)
+                if ldd != gD:
+                    feat = torch.nn.functional.pad(feat, (0, ldd - gD))
+                    wf = torch.nn.functional.pad(wf, (0, ldd - gD))
+                wf = wf.contiguous()
+                zf = _empty_rows(gB * gN, co, dev)
+                _check(lib.pn2_conv1x1_fwd(_p(feat), ldd, None, _p(wf), ldd, _p(b), _p(zf), zf.shape[1], gB * gN, gD, co,
+                                           None, st), "pn2_conv1x1_fwd")
+                _check(lib.pn2_group_affine_fwd(_p(zf), zf.shape[1], _p(g_xyz), _p(g_new), _p(g_idx), _p(wx), gB, gN, gS, gK,
+                                                co, _p(y), y.shape[1], _p(st_l), st), "pn2_group_affine_fwd")
+                wp = wf
+            else:
+                wp = w.detach().reshape(co, ci)
+                if ldx != ci:
+                    wp = torch.nn.functional.pad(wp, (0, ldx - ci))
+                wp = wp.contiguous()
+                _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(wp), ldx, _p(b), _p(y), y.shape[1], P, ci, co,
+                                           _p(st_l), st), "pn2_conv1x1_fwd")
             aff = torch.zeros(4 * _r4(co), device=dev, dtype=torch.float32)
             eps, mom = bn_cfg[l]
             _check(lib.pn2_bn_finalize(_p(st_l), P, co, _p(gamma), _p(beta), eps, mom, int(training),
@@ -267,6 +295,7 @@ class _SharedMLP(torch.autograd.Function):
         _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), out.shape[1], _p(arg), st),
                "pn2_bn_relu_max")
         ctx.meta = (chans, pool, bool(training), P)
+        ctx.geom = None if geom is None else (g_xyz, g_new, g_idx, bool(g_first))   # index/coordinate tensors: no cycle
         # save_for_backward (not ctx attributes): `out` is this node's own output, and holding it on ctx would close a
         # reference cycle that only the cyclic GC breaks -- gigabytes of saved activations would pile up for several
         # steps and the caching allocator would stall in hipMalloc/hipFree in the middle of a step.
@@ -315,11 +344,15 @@ class _SharedMLP(torch.autograd.Function):
             dbeta = torch.empty(co, device=dev, dtype=torch.float32)
             _check(lib.pn2_bn_bwd_coef(_p(red[offs[l]:offs[l + 1]]), P, co, _p(gammas[l]), _p(aff), int(training),
                                        _p(coef), _p(dgamma), _p(dbeta), st), "pn2_bn_bwd_coef")
+            dbias = torch.zeros(co, device=dev, dtype=torch.float32)
+            if l == 0 and ctx.geom is not None:
+                d_rows, dW = _SharedMLP._first_layer_bwd(ctx, rows, Ws[0], dZ, y, coef, co, ctx.needs_input_grad[0])
+                grads[0], grads[1], grads[2], grads[3] = dW, dbias, dgamma, dbeta
+                continue
             x = rows if l == 0 else Ys[l - 1]
             x_aff = None if l == 0 else affs[l - 1]
             ldx = x.shape[1]
             dW = torch.zeros(co, ci, device=dev, dtype=torch.float32)
-            dbias = torch.zeros(co, device=dev, dtype=torch.float32)
             pooled = dZ is None
             a_dz, a_ldz = (None, 0) if pooled else (_p(dZ), dZ.shape[1])
             a_pool = (_p(grad_out), ldo, _p(out), _p(arg), K) if pooled else (None, 0, None, None, 0)
@@ -346,7 +379,42 @@ class _SharedMLP(torch.autograd.Function):
             grads[7 * l + 1] = dbias
             grads[7 * l + 2] = dgamma
             grads[7 * l + 3] = dbeta
-        return (d_rows, None, None, None, None) + tuple(grads)
+        return (d_rows, None, None, None, None, None) + tuple(grads)
+
+    @staticmethod
+    def _first_layer_bwd(ctx, feats, w, dZ, y, coef, co, need_dfeat):
+        """Backward of the factorised first layer: scatter dY to the source points, then two small GEMMs."""
+        lib, st = _lib.load(), _lib.stream()
+        g_xyz, g_new, g_idx, g_first = ctx.geom
+        B, N, D = feats.shape
+        S, K = g_idx.shape[1], g_idx.shape[2]
+        dev = feats.device
+        ldc, ldd = _r4(co), _r4(D)
+        G = torch.zeros(B * N, ldc, device=dev, dtype=torch.float32)
+        dWx = torch.zeros(co, 3, device=dev, dtype=torch.float32)
+        _check(lib.pn2_group_affine_bwd(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new), _p(g_idx),
+                                        B, N, S, K, co, _p(G), ldc, _p(dWx), st), "pn2_group_affine_bwd")
+        ident = torch.zeros(4 * ldc, device=dev, dtype=torch.float32)      # dY := 1*G + 0*(y-0) + 0
+        ident[:co] = 1.0
+        feat = feats.reshape(B * N, D)
+        if ldd != D:
+            feat = torch.nn.functional.pad(feat, (0, ldd - D)).contiguous()
+        dWf = torch.zeros(co, D, device=dev, dtype=torch.float32)
+        _check(lib.pn2_conv1x1_wgrad(_p(G), ldc, None, 0, None, None, 0, _p(G), ldc, _p(ident), _p(feat), ldd, None, _p(dWf), D,
+                                     None, B * N, co, D, st), "pn2_conv1x1_wgrad")
+        dW = torch.cat([dWx, dWf], 1) if g_first else torch.cat([dWf, dWx], 1)
+        d_feats = None
+        if need_dfeat:
+            w2 = w.detach().reshape(co, 3 + D)
+            wt = (w2[:, 3:] if g_first else w2[:, :D]).t()
+            if ldc != co:
+                wt = torch.nn.functional.pad(wt, (0, ldc - co))
+            wt = wt.contiguous()
+            dF = _empty_rows(B * N, D, dev)
+            _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, None, 0, _p(G), ldc, _p(ident), _p(wt), ldc, None, 0, None,
+                                         _p(dF), ldd, None, B * N, co, D, st), "pn2_conv1x1_dgrad")
+            d_feats = (dF[:, :D] if ldd != D else dF).reshape(B, N, D)
+        return d_feats, dW.view_as(w)
 
 
 def _flat_params(convs, bns):
@@ -365,7 +433,25 @@ def shared_mlp(rows, c_in, convs, bns, pool, training):
     rows = _gpu_f32(rows, "rows")
     if rows.dim() != 2 or rows.shape[1] != _r4(c_in):
         raise RuntimeError("rows must be [P, round4(c_in)] with zero pad columns")
-    return _SharedMLP.apply(rows, c_in, pool, training, cfg, *flat)
+    return _SharedMLP.apply(rows, c_in, pool, training, cfg, None, *flat)
+
+
+FACTORISE_MIN_FEATURES = 32      # below this the grouped rows are narrower than the gathered layer-1 output
+
+
+def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training):
+    """Group + shared MLP + max over the K neighbours of one SA scale -> [B*S, C_out].
+
+    With enough input features (and a trainable stack of >= 2 layers) the first layer runs factorised over
+    the source points (see _SharedMLP); otherwise the grouped [P, 3+D] matrix is built and fed to the GEMMs.
+    """
+    B, S, K = idx.shape
+    D = 0 if points is None else points.shape[2]
+    if D >= FACTORISE_MIN_FEATURES and len(convs) >= 2 and training:
+        flat, cfg = _flat_params(convs, bns)
+        return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx, xyz_first), *flat)
+    rows = _Group.apply(xyz, points, new_xyz, idx, S, K, xyz_first)
+    return shared_mlp(rows, 3 + D, convs, bns, K, training)
 
 
 # --------------------------------------------------------------------------------------- grouping API
@@ -437,11 +523,14 @@ class PointNetSetAbstraction(nn.Module):
             fps_idx = farthest_point_sample(xyz, S, fps_start)
             new_xyz = index_points(xyz, fps_idx, _checked=False)
             idx = query_ball_point(self.radius, K, xyz, new_xyz)
-            rows = _Group.apply(xyz, pts, new_xyz, idx, S, K, True)
+            rows = None
         c_in = 3 + (0 if pts is None else pts.shape[2])
         if c_in != self.in_channel:
             raise RuntimeError("expected %d input channels (3 + features), got %d" % (self.in_channel, c_in))
-        out = shared_mlp(rows, c_in, self.mlp_convs, self.mlp_bns, K, self.training)
+        if rows is None:
+            out = grouped_mlp(xyz, pts, new_xyz, idx, True, self.mlp_convs, self.mlp_bns, self.training)
+        else:
+            out = shared_mlp(rows, c_in, self.mlp_convs, self.mlp_bns, K, self.training)
         return new_xyz.permute(0, 2, 1), out.view(B, S, -1).permute(0, 2, 1)
 
 
@@ -478,8 +567,8 @@ class PointNetSetAbstractionMsg(nn.Module):
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             idx = query_ball_point(radius, K, xyz, new_xyz)
-            rows = _Group.apply(xyz, pts, new_xyz, idx, S, K, False)          # features first (:247)
-            outs.append(shared_mlp(rows, c_in, self.conv_blocks[i], self.bn_blocks[i], K, self.training))
+            outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
+                                    self.training))                           # features first (:247)
         out = torch.cat(outs, dim=1)                                          # [B*S, sum C]
         return new_xyz.permute(0, 2, 1), out.view(B, S, -1).permute(0, 2, 1)
 

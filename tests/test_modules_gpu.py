@@ -134,3 +134,42 @@ def test_reference_checkpoint_keys_load(dev):
     res = M.load_reference_state(M.PointNet2SemSeg(19, 1), sd)
     assert not res.missing_keys and not res.unexpected_keys
     assert len(sd) == 156
+
+
+@pytest.mark.parametrize("kind,D", [("ssg", 40), ("ssg", 33), ("msg", 64)])
+def test_factorised_first_layer_matches_oracle(dev, kind, D):
+    """D >= 32 features: layer 1 runs as Zf[idx] + W_x (xyz - centre) (csrc/grouped.hip); compare the whole module,
+    forward and backward, with the oracle module on the same state and inputs."""
+    from oracle import torch_ref as T
+    from pointnet12_amd import synthetic as syn
+    assert D >= U.FACTORISE_MIN_FEATURES
+    pts = torch.from_numpy(syn.kitti_batch(500, 2, 1024)[0])
+    xyz = pts[:, :3].contiguous()
+    feat = torch.randn(2, D, 1024, generator=torch.Generator().manual_seed(D))
+    torch.manual_seed(D)
+    if kind == "ssg":
+        orc = T.RefSetAbstraction(128, 0.3, 32, D + 3, [48, 64], False)
+        mod = U.PointNetSetAbstraction(128, 0.3, 32, D + 3, [48, 64], False)
+    else:
+        orc = T.RefSetAbstractionMsg(128, [0.2, 0.4], [16, 32], D, [[32, 64], [48, 96, 128]])
+        mod = U.PointNetSetAbstractionMsg(128, [0.2, 0.4], [16, 32], D, [[32, 64], [48, 96, 128]])
+    mod.load_state_dict(orc.state_dict())
+    mod.to(dev).train()
+    orc.train()
+    f_ref = feat.clone().requires_grad_(True)
+    f_gpu = feat.clone().to(dev).requires_grad_(True)
+    torch.manual_seed(9)
+    _, a = orc(xyz, f_ref)
+    torch.manual_seed(9)
+    _, b = mod(xyz.to(dev), f_gpu)
+    assert float((a.detach() - b.detach().cpu()).abs().max()) <= FWD_TOL
+    gw = torch.randn(a.shape, generator=torch.Generator().manual_seed(1))
+    (a * gw).sum().backward()
+    (b * gw.to(dev)).sum().backward()
+    assert relmax(f_gpu.grad.cpu().numpy(), f_ref.grad.numpy()) <= 1e-4
+    for (n, p), (_, q) in zip(orc.named_parameters(), mod.named_parameters()):
+        if "conv" in n and n.endswith("bias"):
+            continue
+        assert relmax(q.grad.cpu().numpy(), p.grad.numpy()) <= 1e-4, n
+    for (n, u), (_, v) in zip(orc.named_buffers(), mod.named_buffers()):
+        assert np.allclose(v.cpu().numpy(), u.numpy(), rtol=1e-5, atol=1e-6), n
