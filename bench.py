@@ -97,7 +97,6 @@ def make_step(workload, net, pts, labels, bucket):
             lp = net(pts)
             loss = F.nll_loss(lp.reshape(-1, lp.shape[-1]), labels.reshape(-1))
         loss.backward()
-        bucket.all_reduce()
         return loss
     return step
 
@@ -149,6 +148,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-launch table of the instrumented pass on stderr")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     import numpy as np
@@ -180,7 +180,18 @@ def main():
     net = build_net(args.workload, dev)
     parallel.broadcast_module(net)
     bucket = parallel.FlatGradBucket(net)
-    step = make_step(args.workload, net, pts, labels, bucket)
+    compute = make_step(args.workload, net, pts, labels, bucket)     # zero grads + forward + loss + backward
+    if not args.no_graph:
+        from pointnet12_amd.graph import GraphedStep
+        torch.manual_seed(4321)
+        graphed = GraphedStep(compute, dev)         # one hipGraph launch per step (capture failures raise)
+    else:
+        graphed = compute
+
+    def step():
+        loss = graphed()
+        bucket.all_reduce()                          # the only collective of the path (no-op on one GPU)
+        return loss
 
     def fence():
         if world > 1:
@@ -208,9 +219,9 @@ def main():
     if rank == 0 and not args.no_roofline:
         # instrumented pass: HIP events around every C-ABI launch, on the stream the kernels run on
         prof_steps = 3
-        with _lib.call_profile() as calls:
+        with _lib.call_profile() as calls:           # eager launches: every C-ABI call bracketed by HIP events
             for _ in range(prof_steps):
-                step()
+                compute()
             torch.cuda.synchronize()
             agg = {}
             ncall = len(calls) // prof_steps
@@ -255,6 +266,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "clouds_per_gpu": batch, "points_per_cloud": n_points,
                        "channels": 9, "global_batch": batch * world, "parallelism": "dp%d" % world,
+                       "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
                        "grad_bucket_bytes": bucket.nbytes},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

@@ -1,0 +1,83 @@
+"""Whole-step hipGraph capture: forward + loss + backward of a PointNet++ network as ONE graph launch.
+
+A training step of MSG-SemSeg is ~400 kernel launches (SSG ~470), most of them tens of microseconds long; issued
+one by one from Python the host becomes the bottleneck as soon as the kernels are fast (SSG-SemSeg B=16: 7 ms of
+device work per step, 10 ms of launching).  MI355X-first means HIP streams and graphs, not a tracing compiler:
+the step is captured once (``torch.cuda.graph`` drives hipStreamBeginCapture; the C-ABI launches of
+libpn2_hip.so go to torch's current stream and are recorded like any other kernel) and replayed per step.
+
+The only per-step host input of the path is the FPS start index (reference pointnet_util.py:75: one
+``torch.randint`` on the CPU generator per sampling call).  ``FpsStartFeed`` keeps that contract under replay:
+during capture every draw site receives a slice of one device buffer; before each replay the host draws the
+same ``randint(0, N, (B,))`` sequence, in the same order, into a pinned staging buffer and enqueues one H2D
+copy ahead of the graph.
+"""
+import torch
+
+from . import pointnet_util as U
+
+
+class FpsStartFeed:
+    def __init__(self, device, capacity=4096, ring=4):
+        self.device = device
+        self.dev = torch.zeros(capacity, dtype=torch.int64, device=device)
+        self.host = [torch.zeros(capacity, dtype=torch.int64).pin_memory() for _ in range(ring)]
+        self.events = [None] * ring
+        self.slots = []            # (offset, B, N) in draw order
+        self.used = 0
+        self.turn = 0
+
+    def take(self, B, N, device):
+        """Called at capture time from draw_fps_start: reserve B slots, return their device view."""
+        if self.used + B > self.dev.numel():
+            raise RuntimeError("FpsStartFeed capacity exceeded")
+        off = self.used
+        self.slots.append((off, B, N))
+        self.used += B
+        return self.dev[off:off + B]
+
+    def stage(self):
+        """Draw this step's start indices (CPU generator, reference order) and enqueue their upload."""
+        h = self.host[self.turn]
+        if self.events[self.turn] is not None:
+            self.events[self.turn].synchronize()       # the copy that last read this staging buffer is done
+        for off, B, N in self.slots:
+            h[off:off + B] = torch.randint(0, N, (B,), dtype=torch.long)
+        if self.used:
+            self.dev[:self.used].copy_(h[:self.used], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[self.turn] = ev
+        self.turn = (self.turn + 1) % len(self.host)
+
+
+class GraphedStep:
+    """``step = GraphedStep(fn)``; ``loss = step()`` replays ``fn`` (zero grads + forward + loss + backward).
+
+    ``fn`` must be capture-safe: static input tensors, no host synchronisation, gradients accumulated into
+    pre-existing ``.grad`` tensors (parallel.FlatGradBucket does that).  The returned loss tensor is static
+    (overwritten by every replay).
+    """
+
+    def __init__(self, fn, device, warmup=3):
+        self.fn = fn
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):                  # eager warm-up off the default stream (allocator, lazy inits)
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.feed = FpsStartFeed(device)
+        self.graph = torch.cuda.CUDAGraph()
+        U.set_fps_start_feed(self.feed)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = fn()
+        finally:
+            U.set_fps_start_feed(None)
+
+    def __call__(self):
+        self.feed.stage()
+        self.graph.replay()
+        return self.loss

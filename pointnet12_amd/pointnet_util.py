@@ -102,8 +102,22 @@ def index_points(points, idx, _checked=True):
     return _GatherRows.apply(points, idx, _checked)
 
 
+_fps_start_feed = None
+
+
+def set_fps_start_feed(feed):
+    """Route the FPS start draws through ``feed.take(B, N, device)`` (pointnet12_amd.graph) or back to eager (None)."""
+    global _fps_start_feed
+    _fps_start_feed = feed
+
+
 def draw_fps_start(B, N, device):
-    """The start draw of pointnet_util.py:75: one CPU-generator randint per FPS call, then H2D."""
+    """The start draw of pointnet_util.py:75: one CPU-generator randint per FPS call, then H2D.
+
+    While a hipGraph of the step is being captured the draw is deferred: the feed hands out a slice of a device
+    buffer that is refilled before every replay from the SAME CPU generator, in the same call order."""
+    if _fps_start_feed is not None:
+        return _fps_start_feed.take(B, N, device)
     return torch.randint(0, N, (B,), dtype=torch.long).to(device, non_blocking=True)
 
 
