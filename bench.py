@@ -42,12 +42,12 @@ def algorithmic_work(name, a):
         P, K, N = a[8], a[9], a[10]
         return 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K)
     if name == "pn2_conv1x1_dgrad":          # ... P K N stream   (reads dZ|pooled + Y [P,K], writes [P,N], reads prev_Y)
-        P, K, N = a[18], a[19], a[20]
+        P, K, N = a[17], a[18], a[19]
         dense = a[0] is not None
-        masked = a[12] is not None
+        masked = a[11] is not None
         return 2.0 * P * K * N, 4.0 * (P * K * (2 if dense else 1) + P * N * (2 if masked else 1) + N * K)
     if name == "pn2_conv1x1_wgrad":          # ... P M N stream
-        P, M, N = a[16], a[17], a[18]
+        P, M, N = a[15], a[16], a[17]
         dense = a[0] is not None
         return 2.0 * P * M * N, 4.0 * (P * M * (2 if dense else 1) + P * N + M * N)
     if name == "pn2_bn_relu_max":            # Y ldy aff G K C out ldo arg

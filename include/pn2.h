@@ -149,10 +149,11 @@ int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, c
 int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int K, int C, float *out, int ldo,
                     int32_t *arg, pn2_stream_t stream);
 
-/* Backward, last layer after max-pool: red[0..C) = sum dZ, red[C..2C) = sum dZ*yhat with
- * dZ[g*K+k,c] = (k==arg[g,c] && out[g,c]>0) ? dOut[g,c] : 0.   red is double[2*C], caller zeroes. */
+/* Backward, last layer after max-pool: dZp[g,c] = out[g,c] > 0 ? dOut[g,c] : 0 (pitch ldo, pad lanes zero),
+ * red[0..C) = sum dZ, red[C..2C) = sum dZ*yhat with dZ[g*K+k,c] = (k == arg[g,c]) ? dZp[g,c] : 0.
+ * red is double[2*C], caller zeroes. */
 int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
-                        const float *affine, int64_t G, int K, int C, double *red, pn2_stream_t stream);
+                        const float *affine, int64_t G, int K, int C, float *dZp, double *red, pn2_stream_t stream);
 /* Backward, dense (FP) last layer: dZ = dOut * (out > 0) written to dZ [P, ldz]; same reductions. */
 int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,
                         int64_t P, int C, float *dZ, int ldz, double *red, pn2_stream_t stream);
@@ -165,11 +166,11 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
 
 /* dgrad: dXact[P,N] = dY[P,K] * Wt[N,K]^T with dY formed on the fly from (dZ or the pooled
  * pair dOut/arg, Y, coef); K = C_l, N = C_{l-1}; Wt = W^T padded to pitch ldw.
- *   dZ != NULL: dense dZ [P, ldz];  dZ == NULL: pooled form (dOut [G,ldo], out, arg, Kpool).
+ *   dZ != NULL: dense dZ [P, ldz];  dZ == NULL: pooled form (dZp [G,ldo] from pn2_pool_bwd_reduce, arg, Kpool).
  * Epilogue, prev_Y != NULL: dZprev = dXact * (bn_relu(prev_Y) > 0) -> dXout, and
  *   prev_red (double[2*N], caller zeroes) += sum dZprev, sum dZprev*yhat_prev;
  * prev_Y == NULL (first layer): dXout = dXact. */
-int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dOut, int ldo, const float *out, const int32_t *arg,
+int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg,
                       int Kpool, const float *Y, int ldy, const float *coef, const float *Wt, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
                       double *prev_red, int64_t P, int K, int N, pn2_stream_t stream);
@@ -177,7 +178,7 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dOut, int ldo, cons
 /* wgrad: dW[M,N] (pitch lddw, caller zeroes) += sum_p dY[p,m] * Xact[p,n]; M = C_l, N = C_{l-1}.
  * dY formed as in dgrad; Xact = bn_relu(prev_Y) when prev_affine != NULL, else X as is.
  * dbias (may be NULL, caller zeroes) += sum_p dY[p,m]. */
-int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dOut, int ldo, const float *out, const int32_t *arg,
+int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg,
                       int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       pn2_stream_t stream);

@@ -29,65 +29,145 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 __device__ __forceinline__ int4 ld4i(const int32_t *p) { return *reinterpret_cast<const int4 *>(p); }
 
 // ----------------------------------------------------------------------------- operand loaders
-// Each loader returns 4 consecutive k-values of one row of the (virtual) GEMM operand.
+// A loader produces 4 consecutive k-values of one row of the (virtual) GEMM operand in two halves:
+//   issue()  requests the raw global data (and the per-channel constants of those 4 columns) -- nothing
+//            is computed, so the requests stay in flight while the previous k-step's MFMAs run;
+//   finish() turns the raw registers into operand values right before they are written to LDS.
+// (Computing the transform inside the load, as a first version did, makes the loaded value live
+// immediately: the wave then waits out the full HBM latency every k-step with no MFMA work to cover it --
+// 58 % of the workgroup's cycles, measured with the in-kernel stamps.)
+// Rows of one loader thread are m + i*stride, i < IT, all at the same 4 columns k..k+3.
+
+const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};
+
+// The per-channel constants of a loader's 4 columns are (re)loaded by params() at finish time -- they hit L1/L2,
+// and keeping them out of the in-flight register set is what lets the kernels run at 3-4 workgroups per CU
+// without spilling.
 
 struct LoadPlain {          // X as stored
     const float *X; int ldx;
-    __device__ __forceinline__ float4 operator()(int64_t m, int k) const { return ld4(X + m * ldx + k); }
+    static constexpr int kRegs = 4;
+    template <int IT> struct Raw { float4 x[IT]; };
+    struct Params {};
+    template <int IT>
+    __device__ __forceinline__ void issue(Raw<IT> &r, int64_t m, int stride, int k, int64_t rows, bool kvalid) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int64_t mi = m + (int64_t)i * stride;
+            r.x[i] = (kvalid && mi < rows) ? ld4(X + mi * ldx + k) : kZero4;
+        }
+    }
+    __device__ __forceinline__ Params params(int, bool) const { return Params(); }
+    template <int IT>
+    __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool, const Params &) const { return r.x[i]; }
 };
 
-struct LoadBnRelu {         // relu(bn(Y_prev)) formed on the fly from the pre-BN tensor
+struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
     const float *X; int ldx; const float *aff;
-    __device__ __forceinline__ float4 operator()(int64_t m, int k) const {
-        float4 x = ld4(X + m * ldx + k);
+    static constexpr int kRegs = 4;
+    template <int IT> struct Raw { float4 x[IT]; float4 mu, sc, be; };   // 12 constant registers: fits at 4 WG/CU
+    struct Params {};
+    template <int IT>
+    __device__ __forceinline__ void issue(Raw<IT> &r, int64_t m, int stride, int k, int64_t rows, bool kvalid) const {
         Affine a(aff, ldx);
-        float4 mu = ld4(a.mean + k), sc = ld4(a.scale + k), be = ld4(a.beta + k);
-        float4 r;
-        r.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
-        r.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
-        r.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
-        r.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
-        return r;
+        r.mu = kvalid ? ld4(a.mean + k) : kZero4;      // pad / invalid columns: scale = beta = 0 -> operand 0
+        r.sc = kvalid ? ld4(a.scale + k) : kZero4;
+        r.be = kvalid ? ld4(a.beta + k) : kZero4;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int64_t mi = m + (int64_t)i * stride;
+            r.x[i] = (kvalid && mi < rows) ? ld4(X + mi * ldx + k) : kZero4;
+        }
+    }
+    __device__ __forceinline__ Params params(int, bool) const { return Params(); }
+    template <int IT>
+    __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool valid, const Params &) const {
+        const float4 x = r.x[i];
+        float4 o;
+        o.x = fmaxf(bn_act(x.x, r.mu.x, r.sc.x, r.be.x), 0.f);
+        o.y = fmaxf(bn_act(x.y, r.mu.y, r.sc.y, r.be.y), 0.f);
+        o.z = fmaxf(bn_act(x.z, r.mu.z, r.sc.z, r.be.z), 0.f);
+        o.w = fmaxf(bn_act(x.w, r.mu.w, r.sc.w, r.be.w), 0.f);
+        return valid ? o : kZero4;                      // rows past the end must contribute nothing
     }
 };
+
+struct DyParams { float4 c0, q1, q0, mu; };
+
+__device__ __forceinline__ DyParams dy_params(const float *coef, int ldc, int k, bool kvalid) {
+    DyParams q;
+    q.c0 = kvalid ? ld4(coef + k) : kZero4;
+    q.q1 = kvalid ? ld4(coef + ldc + k) : kZero4;
+    q.q0 = kvalid ? ld4(coef + 2 * ldc + k) : kZero4;
+    q.mu = kvalid ? ld4(coef + 3 * ldc + k) : kZero4;
+    return q;
+}
 
 // dY = c0*dZ + q1*(y-mean) + q0   (BatchNorm backward folded into per-channel coefficients)
+__device__ __forceinline__ float4 dy_from(const float4 dz, const float4 y, const DyParams &q) {
+    float4 o;
+    o.x = __builtin_fmaf(q.c0.x, dz.x, __builtin_fmaf(q.q1.x, y.x - q.mu.x, q.q0.x));
+    o.y = __builtin_fmaf(q.c0.y, dz.y, __builtin_fmaf(q.q1.y, y.y - q.mu.y, q.q0.y));
+    o.z = __builtin_fmaf(q.c0.z, dz.z, __builtin_fmaf(q.q1.z, y.z - q.mu.z, q.q0.z));
+    o.w = __builtin_fmaf(q.c0.w, dz.w, __builtin_fmaf(q.q1.w, y.w - q.mu.w, q.q0.w));
+    return o;
+}
+
 struct LoadDyDense {
     const float *dZ; int ldz; const float *Y; int ldy; const float *coef; int ldc;
-    __device__ __forceinline__ float4 operator()(int64_t m, int k) const {
-        float4 dz = ld4(dZ + m * ldz + k), y = ld4(Y + m * ldy + k);
-        float4 c0 = ld4(coef + k), q1 = ld4(coef + ldc + k), q0 = ld4(coef + 2 * ldc + k), mu = ld4(coef + 3 * ldc + k);
-        float4 r;
-        r.x = __builtin_fmaf(c0.x, dz.x, __builtin_fmaf(q1.x, y.x - mu.x, q0.x));
-        r.y = __builtin_fmaf(c0.y, dz.y, __builtin_fmaf(q1.y, y.y - mu.y, q0.y));
-        r.z = __builtin_fmaf(c0.z, dz.z, __builtin_fmaf(q1.z, y.z - mu.z, q0.z));
-        r.w = __builtin_fmaf(c0.w, dz.w, __builtin_fmaf(q1.w, y.w - mu.w, q0.w));
-        return r;
+    static constexpr int kRegs = 8;
+    template <int IT> struct Raw { float4 dz[IT], y[IT]; };
+    typedef DyParams Params;
+    template <int IT>
+    __device__ __forceinline__ void issue(Raw<IT> &r, int64_t m, int stride, int k, int64_t rows, bool kvalid) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int64_t mi = m + (int64_t)i * stride;
+            const bool v = kvalid && mi < rows;
+            r.dz[i] = v ? ld4(dZ + mi * ldz + k) : kZero4;
+            r.y[i] = v ? ld4(Y + mi * ldy + k) : kZero4;
+        }
+    }
+    __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid); }
+    template <int IT>
+    __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool valid, const Params &q) const {
+        return valid ? dy_from(r.dz[i], r.y[i], q) : kZero4;
     }
 };
 
-// Same, with dZ implied by the max-pool: dZ[g*Kp+kk, c] = dOut[g,c] if kk == arg[g,c] and out[g,c] > 0.
+// Same, with dZ implied by the max-pool: dZ[g*Kp+kk, c] = dZp[g,c] if kk == arg[g,c], where
+// dZp = dOut * (out > 0) was written once by pn2_pool_bwd_reduce (keeps this loader at 3 requests per row).
 struct LoadDyPooled {
-    const float *dOut; int ldo; const float *out; const int32_t *arg; int Kp;
+    const float *dZp; int ldo; const int32_t *arg; int Kp;
     const float *Y; int ldy; const float *coef; int ldc;
-    __device__ __forceinline__ float4 operator()(int64_t m, int k) const {
-        int64_t g = m / Kp;
-        int kk = (int)(m - g * Kp);
-        float4 go = ld4(dOut + g * ldo + k), o = ld4(out + g * ldo + k);
-        int4 a = ld4i(arg + g * ldo + k);
-        float4 y = ld4(Y + m * ldy + k);
-        float4 c0 = ld4(coef + k), q1 = ld4(coef + ldc + k), q0 = ld4(coef + 2 * ldc + k), mu = ld4(coef + 3 * ldc + k);
+    static constexpr int kRegs = 13;
+    template <int IT> struct Raw { float4 go[IT], y[IT]; int4 a[IT]; int kk[IT]; };
+    typedef DyParams Params;
+    template <int IT>
+    __device__ __forceinline__ void issue(Raw<IT> &r, int64_t m, int stride, int k, int64_t rows, bool kvalid) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int64_t mi = m + (int64_t)i * stride;
+            const bool v = kvalid && mi < rows;
+            const unsigned g = (unsigned)mi / (unsigned)Kp;         // P < 2^31 (checked by the host wrapper)
+            r.kk[i] = (int)((unsigned)mi - g * (unsigned)Kp);
+            r.go[i] = v ? ld4(dZp + (int64_t)g * ldo + k) : kZero4;
+            r.a[i] = v ? ld4i(arg + (int64_t)g * ldo + k) : make_int4(-1, -1, -1, -1);
+            r.y[i] = v ? ld4(Y + mi * ldy + k) : kZero4;
+        }
+    }
+    __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid); }
+    template <int IT>
+    __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool valid, const Params &q) const {
+        const float4 go = r.go[i];
+        const int4 a = r.a[i];
+        const int kk = r.kk[i];
         float4 dz;
-        dz.x = (a.x == kk && o.x > 0.f) ? go.x : 0.f;
-        dz.y = (a.y == kk && o.y > 0.f) ? go.y : 0.f;
-        dz.z = (a.z == kk && o.z > 0.f) ? go.z : 0.f;
-        dz.w = (a.w == kk && o.w > 0.f) ? go.w : 0.f;
-        float4 r;
-        r.x = __builtin_fmaf(c0.x, dz.x, __builtin_fmaf(q1.x, y.x - mu.x, q0.x));
-        r.y = __builtin_fmaf(c0.y, dz.y, __builtin_fmaf(q1.y, y.y - mu.y, q0.y));
-        r.z = __builtin_fmaf(c0.z, dz.z, __builtin_fmaf(q1.z, y.z - mu.z, q0.z));
-        r.w = __builtin_fmaf(c0.w, dz.w, __builtin_fmaf(q1.w, y.w - mu.w, q0.w));
-        return r;
+        dz.x = a.x == kk ? go.x : 0.f;
+        dz.y = a.y == kk ? go.y : 0.f;
+        dz.z = a.z == kk ? go.z : 0.f;
+        dz.w = a.w == kk ? go.w : 0.f;
+        return valid ? dy_from(dz, r.y[i], q) : kZero4;
     }
 };
 
@@ -250,29 +330,19 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
 #pragma unroll
     for (int e = 0; e < 8; ++e) st[e] = 0.0;
 
-    // Register ring of DEPTH prefetched k-steps: the operands of step s+DEPTH are requested right after the
-    // LDS stores of step s, so DEPTH-1 further steps of MFMA work (and a tile's epilogue) cover their latency.
-    float4 ra[DEPTH][A_IT], rb[DEPTH][B_IT];
-    auto fetch = [&](float4 (&qa)[A_IT], float4 (&qb)[B_IT], int64_t tile, int ks) {
-        const int64_t m0 = tile * BM;
+    // Register ring of DEPTH prefetched k-steps: the RAW operands of step s+DEPTH are requested right after the
+    // LDS stores of step s; they are only turned into operand values (finish) when their own step comes up, so the
+    // requests stay in flight under DEPTH steps of MFMA work (and a tile's epilogue).
+    typename ALoad::template Raw<A_IT> ra[DEPTH];
+    float4 rb[DEPTH][B_IT];
+    auto fetch = [&](typename ALoad::template Raw<A_IT> &qa, float4 (&qb)[B_IT], int64_t tile, int ks) {
         const int k = ks * BK + lkq;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int64_t m = m0 + lrow + i * RPL;
-#ifdef PN2_X_NOALOAD
-            qa[i] = make_float4((float)m, 0.f, 0.f, 1.f);
-#else
-            qa[i] = (m < P && k < K4) ? aload(m, k) : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-        }
+        const bool kvalid = k < K4 && tile < tiles_m;
+        aload.template issue<A_IT>(qa, tile * BM + lrow, RPL, k, P, kvalid);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int n = n0 + lrow + i * RPL;
-#ifdef PN2_X_NOBLOAD
-            qb[i] = make_float4(1.f, 0.f, 0.f, 0.f);
-#else
-            qb[i] = (n < N && k < K4 && tile < tiles_m) ? ld4(Bw + (int64_t)n * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
+            qb[i] = (n < N && kvalid) ? ld4(Bw + (int64_t)n * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -300,8 +370,12 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
                         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
             float *Ab = As + buf * (BM * LDP), *Bb = Bs + buf * (BN * LDP);
+            const bool kv = ks * BK + lkq < K4;
+            const typename ALoad::Params ap = aload.params(ks * BK + lkq, kv);
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) = ra[d][i];
+            for (int i = 0; i < A_IT; ++i)
+                *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) =
+                    aload.template finish<A_IT>(ra[d], i, kv && (m0 + lrow + i * RPL < P), ap);
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4 *>(&Bb[(lrow + i * RPL) * LDP + lkq]) = rb[d][i];
             fetch(ra[d], rb[d], ptile, pks);
@@ -417,9 +491,10 @@ int dispatch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N,
     if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     if (cfg == 1) return launch_nt<128, 128, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
-    if (cfg == 2) return launch_nt<64, 128, 16, 2, 2, 4, 2>(aload, Bw, ldb, P, K4, N, epi, s);
-    // 64x128 tiles, 16-deep k-steps, four resident workgroups per CU: +10..17 % over 128x128x32 at two per CU
-    // (more independent waves hide the operand stream's latency; measured in tools/bench_kernels.py)
+    // 64x128 tiles, 16-deep k-steps: more, smaller workgroups per CU hide the operand stream's latency better than
+    // 128x128x32 at two per CU (+10..17 %, tools/bench_kernels.py).  Loaders with a large in-flight register set
+    // (two or three tensors per operand row) get a 168-VGPR budget (3 per CU) instead of 128 (4 per CU): no spills.
+    if (ALoad::kRegs >= 8 || cfg == 2) return launch_nt<64, 128, 16, 2, 2, 3, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     return launch_nt<64, 128, 16, 2, 2, 4, 1>(aload, Bw, ldb, P, K4, N, epi, s);
 }
 
@@ -429,10 +504,9 @@ int dispatch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N,
 // Split over P across gridDim.z; each workgroup pipelines its position steps exactly like the NT
 // core (register prefetch under the MFMAs, double-buffered LDS, one barrier per step) and adds its
 // partial tile with fp32 atomics (256 contiguous bytes per wave-instruction).
-constexpr int WG_BP = 32;     // positions per LDS stage
 
-template <int BM, int BN, int WR, int WC, class DyLoad, class XLoad>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk,
+template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad>
+__global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk,
                                                               int M, int N, float *__restrict__ dW, int lddw,
                                                               float *__restrict__ dbias) {
     constexpr int WTM = BM / WR, WTN = BN / WC;
@@ -462,31 +536,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(DyLoad dyload, XLo
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 ra[A_IT], rb[B_IT];
+    typename DyLoad::template Raw<A_IT> ra;          // raw operands of the next stage (see the loader comment)
+    typename XLoad::template Raw<B_IT> rb;
     auto fetch = [&](int64_t p0) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int64_t p = p0 + arow + i * AR;
-            ra[i] = (p < p_end && m0 + acq < M) ? dyload(p, m0 + acq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int64_t p = p0 + brow + i * BR;
-            rb[i] = (p < p_end && n0 + bcq < N) ? xload(p, n0 + bcq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        dyload.template issue<A_IT>(ra, p0 + arow, AR, m0 + acq, p_end, m0 + acq < M);
+        xload.template issue<B_IT>(rb, p0 + brow, BR, n0 + bcq, p_end, n0 + bcq < N);
     };
 
     if (p_begin < p_end) fetch(p_begin);
     int buf = 0;
     for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_BP) {
         float *Ab = As[buf], *Bb = Bs[buf];
+        const typename DyLoad::Params dp = dyload.params(m0 + acq, m0 + acq < M);
+        const typename XLoad::Params xp = xload.params(n0 + bcq, n0 + bcq < N);
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            *reinterpret_cast<float4 *>(&Ab[(arow + i * AR) * LDA + acq]) = ra[i];
-            bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w;
+            const float4 v = dyload.template finish<A_IT>(ra, i, (p0 + arow + i * AR < p_end) && (m0 + acq < M), dp);
+            *reinterpret_cast<float4 *>(&Ab[(arow + i * AR) * LDA + acq]) = v;
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4 *>(&Bb[(brow + i * BR) * LDB + bcq]) = rb[i];
+        for (int i = 0; i < B_IT; ++i)
+            *reinterpret_cast<float4 *>(&Bb[(brow + i * BR) * LDB + bcq]) =
+                xload.template finish<B_IT>(rb, i, (p0 + brow + i * BR < p_end) && (n0 + bcq < N), xp);
         if (p0 + WG_BP < p_end) fetch(p0 + WG_BP);
         __syncthreads();
 #pragma unroll
@@ -524,10 +596,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(DyLoad dyload, XLo
     }
 }
 
-template <int BM, int BN, int WR, int WC, class DyLoad, class XLoad>
+template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad>
 int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
     unsigned tm = (unsigned)pn2_cdiv(M, BM), tn = (unsigned)pn2_cdiv(N, BN);
-    int64_t want = (int64_t)pn2_num_cus() * 4 / ((int64_t)tm * tn);
+    int64_t want = (int64_t)pn2_num_cus() * MINB / ((int64_t)tm * tn);   // MINB resident workgroups per CU
     if (want < 1) want = 1;
     int64_t max_split = pn2_cdiv(P, 8 * WG_BP);
     int64_t split = want < max_split ? want : max_split;
@@ -535,19 +607,30 @@ int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, in
     if (split > 65535) split = 65535;
     int64_t chunk = pn2_cdiv(pn2_cdiv(P, split), WG_BP) * WG_BP;
     split = pn2_cdiv(P, chunk);
-    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WR, WC, DyLoad, XLoad>), dim3(tm, tn, (unsigned)split), dim3(NTHREADS), 0, s,
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad>), dim3(tm, tn, (unsigned)split), dim3(NTHREADS), 0, s,
                        dyload, xload, P, chunk, M, N, dW, lddw, dbias);
     return pn2_launch_status();
 }
 
 template <class DyLoad, class XLoad>
 int dispatch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
-    if (N <= 32) return launch_tn<128, 32, 4, 1>(dyload, xload, P, M, N, dW, lddw, dbias, s);
-    if (M <= 32) return launch_tn<32, 128, 1, 4>(dyload, xload, P, M, N, dW, lddw, dbias, s);
-    if (M <= 64 && N <= 64) return launch_tn<64, 64, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
-    if (N <= 64 || (N > 128 && N % 128 <= 64 && N % 128 != 0 && N < 256)) return launch_tn<128, 64, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
-    if (M <= 64) return launch_tn<64, 128, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
-    return launch_tn<128, 128, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    static const int cfg = pn2_env_int("PN2_TN_CFG", 0);     // tuning hook (tools/bench_kernels.py)
+    if (N <= 32) return launch_tn<128, 32, 32, 4, 1, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    if (M <= 32) return launch_tn<32, 128, 32, 1, 4, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    if (M <= 64 && N <= 64) return launch_tn<64, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    const bool narrow_n = N <= 64 || (N > 128 && N < 256 && N % 128 != 0 && N % 128 <= 64);
+    // measured (tools/bench_kernels.py wgrad): 16-position stages at 3-4 workgroups per CU beat 32 at 2 by
+    // 10-30 % on the long reductions; short ones (P < 128 k) prefer fewer, fatter workgroups.  The pooled dY
+    // loader keeps three tensors per row in flight and gets one workgroup per CU less (register budget).
+    constexpr bool heavy = DyLoad::kRegs >= 13;
+    if (cfg == 1 || P < 131072) {
+        if (narrow_n) return launch_tn<128, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+        if (M <= 64) return launch_tn<64, 128, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+        return launch_tn<128, 128, 16, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    }
+    if (narrow_n) return launch_tn<128, 64, 16, 2, 2, heavy ? 3 : 4>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    if (M <= 64) return launch_tn<64, 128, 16, 2, 2, heavy ? 3 : 4>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    return launch_tn<128, 128, 16, 2, 2, heavy ? 2 : 3>(dyload, xload, P, M, N, dW, lddw, dbias, s);
 }
 
 // ----------------------------------------------------------------------------- small kernels
@@ -604,16 +687,18 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
                                                               const int32_t *__restrict__ arg,
                                                               const float *__restrict__ Y, int ldy,
                                                               const float *__restrict__ aff, int lda, int64_t G, int K,
-                                                              int C, double *__restrict__ red) {
+                                                              int C, float *__restrict__ dZp, double *__restrict__ red) {
     __shared__ double sh[2][4][64];
     const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s0 = 0.0, s1 = 0.0;
-    if (c < C) {
+    if (c < lda) {                                   // pad columns included: dZp's pad lanes must be zero
         Affine a(aff, lda);
-        const float mu = a.mean[c], is = a.invstd[c];
+        const bool real = c < C;
+        const float mu = real ? a.mean[c] : 0.f, is = real ? a.invstd[c] : 0.f;
         for (int64_t g = (int64_t)blockIdx.y * 4 + gl; g < G; g += (int64_t)gridDim.y * 4) {
-            float o = out[g * ldo + c];
+            float o = real ? out[g * ldo + c] : 0.f;
+            dZp[g * ldo + c] = o > 0.f ? dOut[g * ldo + c] : 0.f;
             if (o > 0.f) {
                 float dz = dOut[g * ldo + c];
                 float y = Y[(g * K + arg[g * ldo + c]) * ldy + c];
@@ -739,12 +824,12 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
 }
 
 int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
-                        const float *affine, int64_t G, int K, int C, double *red, pn2_stream_t stream) {
-    PN2_CHECK_ARG(dOut && out && arg && Y && affine && red && G > 0 && K > 0 && C > 0);
+                        const float *affine, int64_t G, int K, int C, float *dZp, double *red, pn2_stream_t stream) {
+    PN2_CHECK_ARG(dOut && out && arg && Y && affine && dZp && red && G > 0 && K > 0 && C > 0 && ldo >= ((C + 3) & ~3));
     int64_t gy = pn2_cdiv(G, 4 * 16);
     if (gy > 256) gy = 256;
-    hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((unsigned)pn2_cdiv(C, 64), (unsigned)gy), dim3(256), 0, pn2_s(stream), dOut,
-                       ldo, out, arg, Y, ldy, affine, (C + 3) & ~3, G, K, C, red);
+    hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((unsigned)pn2_cdiv((C + 3) & ~3, 64), (unsigned)gy), dim3(256), 0, pn2_s(stream), dOut,
+                       ldo, out, arg, Y, ldy, affine, (C + 3) & ~3, G, K, C, dZp, red);
     return pn2_launch_status();
 }
 
@@ -766,12 +851,11 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
     return pn2_launch_status();
 }
 
-int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dOut, int ldo, const float *out, const int32_t *arg,
-                      int Kpool, const float *Y, int ldy, const float *coef, const float *Wt, int ldw,
+int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *Wt, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
                       double *prev_red, int64_t P, int K, int N, pn2_stream_t stream) {
     PN2_CHECK_ARG(Y && coef && Wt && dXout && P > 0 && K > 0 && N > 0);
-    PN2_CHECK_ARG(dZ != nullptr || (dOut && out && arg && Kpool > 0));
+    PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
     PN2_CHECK_ARG(ldw % 4 == 0 && ldw >= round4(K) && ldy % 4 == 0 && ldy >= round4(K) && ldxo >= N);
     PN2_CHECK_ARG(prev_Y == nullptr || prev_affine != nullptr);
     const int K4 = round4(K), ldc = round4(K);
@@ -785,19 +869,18 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dOut, int ldo, cons
         return dispatch_nt(ld, Wt, ldw, P, K4, N, EpiStore{dXout, ldxo}, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= K4);
-    LoadDyPooled ld{dOut, ldo, out, arg, Kpool, Y, ldy, coef, ldc};
+    LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc};
     if (prev_Y)
         return dispatch_nt(ld, Wt, ldw, P, K4, N, EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red},
                            s);
     return dispatch_nt(ld, Wt, ldw, P, K4, N, EpiStore{dXout, ldxo}, s);
 }
 
-int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dOut, int ldo, const float *out, const int32_t *arg,
-                      int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
+int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       pn2_stream_t stream) {
     PN2_CHECK_ARG(Y && coef && X && dW && P > 0 && M > 0 && N > 0);
-    PN2_CHECK_ARG(dZ != nullptr || (dOut && out && arg && Kpool > 0));
+    PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
     PN2_CHECK_ARG(ldy % 4 == 0 && ldy >= round4(M) && ldx % 4 == 0 && ldx >= round4(N) && lddw >= N);
     const int ldc = round4(M);
     hipStream_t s = pn2_s(stream);
@@ -808,7 +891,7 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dOut, int ldo, cons
         return dispatch_tn(dy, LoadPlain{X, ldx}, P, M, N, dW, lddw, dbias, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= round4(M));
-    LoadDyPooled dy{dOut, ldo, out, arg, Kpool, Y, ldy, coef, ldc};
+    LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc};
     if (x_affine) return dispatch_tn(dy, LoadBnRelu{X, ldx, x_affine}, P, M, N, dW, lddw, dbias, s);
     return dispatch_tn(dy, LoadPlain{X, ldx}, P, M, N, dW, lddw, dbias, s);
 }

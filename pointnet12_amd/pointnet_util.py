@@ -340,9 +340,11 @@ class _SharedMLP(torch.autograd.Function):
         G = P // K
         dZ = None
         red_L = red[offs[L - 1]:offs[L]]
+        dzp = None
         if pool:
+            dzp = torch.empty_like(out)          # dOut masked by out > 0: the pooled form of dZ_L the GEMM loaders read
             _check(lib.pn2_pool_bwd_reduce(_p(grad_out), ldo, _p(out), _p(arg), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]),
-                                           G, K, cl, _p(red_L), st), "pn2_pool_bwd_reduce")
+                                           G, K, cl, _p(dzp), _p(red_L), st), "pn2_pool_bwd_reduce")
         else:
             dZ = _empty_rows(P, cl, dev)
             _check(lib.pn2_relu_bwd_reduce(_p(grad_out), ldo, _p(out), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), P, cl,
@@ -369,7 +371,7 @@ class _SharedMLP(torch.autograd.Function):
             dW = torch.zeros(co, ci, device=dev, dtype=torch.float32)
             pooled = dZ is None
             a_dz, a_ldz = (None, 0) if pooled else (_p(dZ), dZ.shape[1])
-            a_pool = (_p(grad_out), ldo, _p(out), _p(arg), K) if pooled else (None, 0, None, None, 0)
+            a_pool = (_p(dzp), ldo, _p(arg), K) if pooled else (None, 0, None, 0)
             _check(lib.pn2_conv1x1_wgrad(a_dz, a_ldz, *a_pool, _p(y), ldy, _p(coef), _p(x), ldx, _p(x_aff), _p(dW), ci,
                                          None if training else _p(dbias), P, co, ci, st), "pn2_conv1x1_wgrad")
             need_dx = l > 0 or ctx.needs_input_grad[0]
@@ -414,7 +416,7 @@ class _SharedMLP(torch.autograd.Function):
         if ldd != D:
             feat = torch.nn.functional.pad(feat, (0, ldd - D)).contiguous()
         dWf = torch.zeros(co, D, device=dev, dtype=torch.float32)
-        _check(lib.pn2_conv1x1_wgrad(_p(G), ldc, None, 0, None, None, 0, _p(G), ldc, _p(ident), _p(feat), ldd, None, _p(dWf), D,
+        _check(lib.pn2_conv1x1_wgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), _p(feat), ldd, None, _p(dWf), D,
                                      None, B * N, co, D, st), "pn2_conv1x1_wgrad")
         dW = torch.cat([dWx, dWf], 1) if g_first else torch.cat([dWf, dWx], 1)
         d_feats = None
@@ -425,7 +427,7 @@ class _SharedMLP(torch.autograd.Function):
                 wt = torch.nn.functional.pad(wt, (0, ldc - co))
             wt = wt.contiguous()
             dF = _empty_rows(B * N, D, dev)
-            _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, None, 0, _p(G), ldc, _p(ident), _p(wt), ldc, None, 0, None,
+            _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), _p(wt), ldc, None, 0, None,
                                          _p(dF), ldd, None, B * N, co, D, st), "pn2_conv1x1_dgrad")
             d_feats = (dF[:, :D] if ldd != D else dF).reshape(B, N, D)
         return d_feats, dW.view_as(w)

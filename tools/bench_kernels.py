@@ -94,11 +94,11 @@ def main():
                 G = P // Kp
                 dOut, out = rnd(G, r4(Cl)), rnd(G, r4(Cl))
                 arg = torch.randint(0, Kp, (G, r4(Cl)), device=dev, dtype=torch.int32, generator=g)
-                dz = (None, 0, p(dOut), r4(Cl), p(out), p(arg), Kp)
+                dz = (None, 0, p(dOut), r4(Cl), p(arg), Kp)
                 dy_bytes = P * Cl
             else:
                 dZ = rnd(P, r4(Cl))
-                dz = (p(dZ), r4(Cl), None, 0, None, None, 0)
+                dz = (p(dZ), r4(Cl), None, 0, None, 0)
                 dy_bytes = 2 * P * Cl
             if which == "dgrad":
                 dX = torch.empty(P, r4(Cp), device=dev)
