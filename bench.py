@@ -165,9 +165,23 @@ def main():
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # RCCL prints its version banner on stdout when NCCL_DEBUG=VERSION is set in the environment: keep stdout
+        # for the ONE JSON line by pointing fd 1 at stderr while the communicator comes up.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     _lib.load()                              # no HIP library -> raise, never fall back
 
     batch = args.batch or (8 if args.workload == "sa" else 16)
@@ -194,7 +208,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -207,7 +221,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -273,7 +287,7 @@ def main():
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -31,7 +31,7 @@ __device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float n
 // live in registers (PPT points per thread, point j = t + i*THREADS), the cloud is mirrored in
 // LDS as float4 so the winner's coordinates are one broadcast ds_read_b128 away.
 // Each of the npoint dependent iterations costs: PPT distance updates, a per-thread argmax,
-// a 64-lane shuffle max on a packed (distance bits, ~index) key -- distances are >= 0 so their
+// a 64-lane DPP max on a packed (distance bits, ~index) key -- distances are >= 0 so their
 // fp32 bit patterns order like unsigned ints and "largest key" = largest distance, lowest
 // index -- one LDS slot per wave and ONE barrier (slots are double-buffered by iteration
 // parity).  pointnet_util.py:77-83.
@@ -88,17 +88,13 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         }
         unsigned long long key = bm < 0.f ? 0ull
                                           : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
-        key = pn2_wave_max_u64(key);
+        key = pn2_wave_max_u64_dpp(key);
         if (NW > 1) {
             unsigned long long *s = slots + (it & 1) * NW;
             if (lane == 0) s[wave] = key;
             __syncthreads();
-            key = s[lane & (NW - 1)];
-#pragma unroll
-            for (int m = NW >> 1; m >= 1; m >>= 1) {
-                unsigned long long other = __shfl_xor(key, m, 64);
-                key = other > key ? other : key;
-            }
+            // NW <= 16 slots replicated over each row of 16 lanes: one more DPP row reduction combines them
+            key = pn2_row_max_u64(s[lane & (NW - 1)]);
         }
         far = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
     }

@@ -94,51 +94,43 @@ __global__ __launch_bounds__(256) void group_affine_bwd_kernel(const float *__re
                                                                const int64_t *__restrict__ idx, int N, int S, int K,
                                                                int C, int64_t P, float *__restrict__ G, int ldg,
                                                                float *__restrict__ dWx) {
-    __shared__ float red[256 * 12];
-    const int CG = (C + 3) >> 2;
-    const int RPB = 256 / CG;
-    const int t = threadIdx.x, cg = t % CG, r = t / CG;
+    // One lane per CHANNEL (not per float4): every atomic wave-instruction then adds 64 consecutive floats of one
+    // G row -- the 256-byte contiguous shape the memory-side float atomics run at full rate with; the float4
+    // mapping issued four 16-byte-strided instructions per row segment and ran ~4x slower.
+    __shared__ float red[256 * 3];
+    const int t = threadIdx.x;
+    const int CT = C < 256 ? C : 256;             // threads per row
+    const int RPB = 256 / CT;                     // rows per pass (1 when C >= 129)
+    const int r = t / CT, cl = t % CT;
     const bool live = r < RPB;
-    const int c = cg * 4;
-    float acc[4][3];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
-    if (live) {
-        const float4 c0 = *reinterpret_cast<const float4 *>(coef + c);
-        const float4 q1 = *reinterpret_cast<const float4 *>(coef + ldc + c);
-        const float4 q0 = *reinterpret_cast<const float4 *>(coef + 2 * ldc + c);
-        const float4 mu = *reinterpret_cast<const float4 *>(coef + 3 * ldc + c);
-        for (int64_t p = (int64_t)blockIdx.x * RPB + r; p < P; p += (int64_t)gridDim.x * RPB) {
-            const int64_t g = p / K, b = g / S;
-            const int64_t j = idx[p];
-            const float *q = xyz + (b * N + j) * 3, *ctr = new_xyz + g * 3;
-            const float d[3] = {q[0] - ctr[0], q[1] - ctr[1], q[2] - ctr[2]};
-            const float4 dz = *reinterpret_cast<const float4 *>(dZ + p * ldz + c);
-            const float4 y = *reinterpret_cast<const float4 *>(Y + p * ldy + c);
-            float dy[4];
-            dy[0] = __builtin_fmaf(c0.x, dz.x, __builtin_fmaf(q1.x, y.x - mu.x, q0.x));
-            dy[1] = __builtin_fmaf(c0.y, dz.y, __builtin_fmaf(q1.y, y.y - mu.y, q0.y));
-            dy[2] = __builtin_fmaf(c0.z, dz.z, __builtin_fmaf(q1.z, y.z - mu.z, q0.z));
-            dy[3] = __builtin_fmaf(c0.w, dz.w, __builtin_fmaf(q1.w, y.w - mu.w, q0.w));
-            float *gr = G + (b * N + j) * ldg + c;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (c + e < C) atomicAdd(gr + e, dy[e]);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) acc[e][a] = __builtin_fmaf(dy[e], d[a], acc[e][a]);
+    for (int cb = 0; cb < C; cb += CT) {          // C > 256: a thread owns channels cl, cl + 256, ... (uniform trip count)
+        const int c = cb + cl;
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (live && c < C) {
+            const float c0 = coef[c], q1 = coef[ldc + c], q0 = coef[2 * ldc + c], mu = coef[3 * ldc + c];
+            for (int64_t p = (int64_t)blockIdx.x * RPB + r; p < P; p += (int64_t)gridDim.x * RPB) {
+                const int64_t g = p / K, b = g / S;
+                const int64_t j = idx[p];
+                const float *q = xyz + (b * N + j) * 3, *ctr = new_xyz + g * 3;
+                const float dy = __builtin_fmaf(c0, dZ[p * ldz + c], __builtin_fmaf(q1, Y[p * ldy + c] - mu, q0));
+                atomicAdd(G + (b * N + j) * ldg + c, dy);
+                acc[0] = __builtin_fmaf(dy, q[0] - ctr[0], acc[0]);
+                acc[1] = __builtin_fmaf(dy, q[1] - ctr[1], acc[1]);
+                acc[2] = __builtin_fmaf(dy, q[2] - ctr[2], acc[2]);
             }
         }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) red[t * 12 + e * 3 + a] = acc[e][a];
-    __syncthreads();
-    for (int o = t; o < C * 3; o += 256) {         // o = channel*3 + axis
-        const int ch = o / 3, a = o % 3, g4 = ch >> 2, e = ch & 3;
-        float sum = 0.f;
-        for (int rr = 0; rr < RPB; ++rr) sum += red[(rr * CG + g4) * 12 + e * 3 + a];
-        atomicAdd(dWx + o, sum);
+        red[t * 3] = acc[0]; red[t * 3 + 1] = acc[1]; red[t * 3 + 2] = acc[2];
+        __syncthreads();
+        if (t < CT && c < C) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int rr = 0; rr < RPB; ++rr) {
+                s0 += red[(rr * CT + t) * 3]; s1 += red[(rr * CT + t) * 3 + 1]; s2 += red[(rr * CT + t) * 3 + 2];
+            }
+            atomicAdd(dWx + c * 3, s0);
+            atomicAdd(dWx + c * 3 + 1, s1);
+            atomicAdd(dWx + c * 3 + 2, s2);
+        }
+        __syncthreads();
     }
 }
 
@@ -167,9 +159,9 @@ int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, cons
                   C <= 1024);
     PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldg % 4 == 0);
     const int64_t P = (int64_t)B * S * K;
-    const int rpb = 256 / ((C + 3) >> 2);
-    int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 8);
-    if (blocks > 2048) blocks = 2048;
+    const int rpb = C < 256 ? 256 / C : 1;
+    int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 16);
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(group_affine_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), dZ, ldz, Y, ldy, coef,
                        (C + 3) & ~3, xyz, new_xyz, idx, N, S, K, C, P, G, ldg, dWx);
     return pn2_launch_status();

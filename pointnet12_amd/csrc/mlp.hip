@@ -494,6 +494,8 @@ int dispatch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N,
     // 64x128 tiles, 16-deep k-steps: more, smaller workgroups per CU hide the operand stream's latency better than
     // 128x128x32 at two per CU (+10..17 %, tools/bench_kernels.py).  Loaders with a large in-flight register set
     // (two or three tensors per operand row) get a 168-VGPR budget (3 per CU) instead of 128 (4 per CU): no spills.
+    if (cfg == 3) return launch_nt<64, 128, 16, 2, 2, 3, 2>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (cfg == 4) return launch_nt<64, 128, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     if (ALoad::kRegs >= 8 || cfg == 2) return launch_nt<64, 128, 16, 2, 2, 3, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     return launch_nt<64, 128, 16, 2, 2, 4, 1>(aload, Bw, ldb, P, K4, N, epi, s);
 }

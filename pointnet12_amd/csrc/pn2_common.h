@@ -27,6 +27,39 @@ __device__ __forceinline__ unsigned long long pn2_wave_max_u64(unsigned long lon
     return v;
 }
 
+// 64-bit max over each row of 16 lanes with DPP (no LDS round trip): xor-1 and xor-2 inside the quads
+// (quad_perm), then row_half_mirror and row_mirror fold the quads; every lane of the row ends with the row max.
+__device__ __forceinline__ unsigned long long pn2_row_max_u64(unsigned long long v) {
+#define PN2_DPP_MAX_STEP(ctrl)                                                                  \
+    {                                                                                           \
+        const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);                         \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false); \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false); \
+        const unsigned long long o = ((unsigned long long)ohi << 32) | olo;                     \
+        v = o > v ? o : v;                                                                      \
+    }
+    PN2_DPP_MAX_STEP(0xB1)    // quad_perm [1,0,3,2]
+    PN2_DPP_MAX_STEP(0x4E)    // quad_perm [2,3,0,1]
+    PN2_DPP_MAX_STEP(0x141)   // row_half_mirror
+    PN2_DPP_MAX_STEP(0x140)   // row_mirror
+#undef PN2_DPP_MAX_STEP
+    return v;
+}
+
+// 64-bit max over the wave, result uniform (SGPRs): DPP inside the four rows, then four readlanes.
+__device__ __forceinline__ unsigned long long pn2_wave_max_u64_dpp(unsigned long long v) {
+    v = pn2_row_max_u64(v);
+    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    unsigned long long best = 0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned long long r = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, row * 16) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane(lo, row * 16);
+        best = r > best ? r : best;
+    }
+    return best;
+}
+
 __device__ __forceinline__ double pn2_wave_sum_f64(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

@@ -8,8 +8,17 @@ the only exchange is ONE all-reduce (AVG) of a flat fp32 gradient bucket (3.87 M
 losses over equal shards, AVG reproduces DataParallel's global-mean gradient; BN stays per replica, which
 is exactly the reference's semantics.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _skip_collectives(group=None):
+    """No process group, or a single rank (unless PN2_FORCE_COLLECTIVES=1: lets a 1-GPU box exercise RCCL)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get("PN2_FORCE_COLLECTIVES") != "1"
 
 
 class FlatGradBucket:
@@ -42,7 +51,7 @@ class FlatGradBucket:
 
     def all_reduce(self, group=None):
         """Average the bucket over ranks (no-op for world size 1 / uninitialised process group)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if _skip_collectives(group):
             return None
         if dist.get_backend(group) == "gloo":          # gloo has no AVG
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -54,7 +63,7 @@ class FlatGradBucket:
 
 def broadcast_module(module, src=0, group=None):
     """Rank ``src``'s parameters and buffers to every rank (DataParallel's per-forward replicate, done once)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _skip_collectives(group):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
