@@ -99,10 +99,11 @@ int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float
                          pn2_stream_t stream);
 /* backward: dY = c0*dZ + q1*(y-mean) + q0 (coef from pn2_bn_bwd_coef) is scattered to the source points,
  * G[b*N + idx[p], :] += dY[p, :] (G [B*N, ldg], caller zeroes), and dWx[c, a] += dY[p, c] * (xyz - centre)[a]
- * (dWx [C, 3], caller zeroes). */
+ * (dWx [C, 3] with row pitch ldwx >= 3 -- it may point at the xyz columns of the full weight gradient --
+ * caller zeroes or accumulates). */
 int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
                          const float *new_xyz, const int64_t *idx, int B, int N, int S, int K, int C, float *G, int ldg,
-                         float *dWx, pn2_stream_t stream);
+                         float *dWx, int ldwx, pn2_stream_t stream);
 
 /* Inverse-distance interpolation, model/pointnet_util.py:301: out[b,n,col0+c] =
  * ((p2[i0,c]*w0 + p2[i1,c]*w1) + p2[i2,c]*w2).  points2 [B,S,D]; out rows of pitch ld
@@ -160,9 +161,10 @@ int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const floa
 
 /* Per-channel BN-backward coefficients from the reductions: coef float[4*C] =
  * [c0 = gamma*invstd, q1 = -c0*invstd*red1/P, q0 = -c0*red0/P, mean]; dgamma = red1, dbeta = red0.
- * dY = c0*dZ + q1*(y-mean) + q0.  use_batch_stats == 0 (eval-mode BN): q1 = q0 = 0. */
+ * dY = c0*dZ + q1*(y-mean) + q0.  use_batch_stats == 0 (eval-mode BN): q1 = q0 = 0.
+ * accumulate != 0: dgamma/dbeta are added to (they alias existing .grad storage) instead of overwritten. */
 int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, const float *affine,
-                    int use_batch_stats, float *coef, float *dgamma, float *dbeta, pn2_stream_t stream);
+                    int use_batch_stats, float *coef, float *dgamma, float *dbeta, int accumulate, pn2_stream_t stream);
 
 /* dgrad: dXact[P,N] = dY[P,K] * Wt[N,K]^T with dY formed on the fly from (dZ or the pooled
  * pair dOut/arg, Y, coef); K = C_l, N = C_{l-1}; Wt = W^T padded to pitch ldw.

@@ -27,7 +27,7 @@ SIGNATURES = {
     "pn2_group": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pn2_group_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "pn2_group_affine_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
-    "pn2_group_affine_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "pn2_group_affine_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "pn2_three_interp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "pn2_three_interp_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_copy_cols": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
@@ -36,7 +36,7 @@ SIGNATURES = {
     "pn2_bn_relu_max": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
     "pn2_pool_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "pn2_relu_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp]),
-    "pn2_bn_bwd_coef": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pn2_bn_bwd_coef": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pn2_conv1x1_dgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp,
                                _i64, _i, _i, _vp]),
     "pn2_conv1x1_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void group_affine_bwd_kernel(const float *__re
                                                                const float *__restrict__ new_xyz,
                                                                const int64_t *__restrict__ idx, int N, int S, int K,
                                                                int C, int64_t P, float *__restrict__ G, int ldg,
-                                                               float *__restrict__ dWx) {
+                                                               float *__restrict__ dWx, int ldwx) {
     // One lane per CHANNEL (not per float4): every atomic wave-instruction then adds 64 consecutive floats of one
     // G row -- the 256-byte contiguous shape the memory-side float atomics run at full rate with; the float4
     // mapping issued four 16-byte-strided instructions per row segment and ran ~4x slower.
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void group_affine_bwd_kernel(const float *__re
             for (int rr = 0; rr < RPB; ++rr) {
                 s0 += red[(rr * CT + t) * 3]; s1 += red[(rr * CT + t) * 3 + 1]; s2 += red[(rr * CT + t) * 3 + 2];
             }
-            atomicAdd(dWx + c * 3, s0);
-            atomicAdd(dWx + c * 3 + 1, s1);
-            atomicAdd(dWx + c * 3 + 2, s2);
+            atomicAdd(dWx + c * ldwx, s0);
+            atomicAdd(dWx + c * ldwx + 1, s1);
+            atomicAdd(dWx + c * ldwx + 2, s2);
         }
         __syncthreads();
     }
@@ -154,16 +154,16 @@ int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float
 
 int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
                          const float *new_xyz, const int64_t *idx, int B, int N, int S, int K, int C, float *G, int ldg,
-                         float *dWx, pn2_stream_t stream) {
+                         float *dWx, int ldwx, pn2_stream_t stream) {
     PN2_CHECK_ARG(dZ && Y && coef && xyz && new_xyz && idx && G && dWx && B > 0 && N > 0 && S > 0 && K > 0 && C > 0 &&
                   C <= 1024);
-    PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldg % 4 == 0);
+    PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldg % 4 == 0 && ldwx >= 3);
     const int64_t P = (int64_t)B * S * K;
     const int rpb = C < 256 ? 256 / C : 1;
     int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 16);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(group_affine_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), dZ, ldz, Y, ldy, coef,
-                       (C + 3) & ~3, xyz, new_xyz, idx, N, S, K, C, P, G, ldg, dWx);
+                       (C + 3) & ~3, xyz, new_xyz, idx, N, S, K, C, P, G, ldg, dWx, ldwx);
     return pn2_launch_status();
 }
 

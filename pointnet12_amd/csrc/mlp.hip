@@ -752,7 +752,8 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
 
 __global__ void bn_bwd_coef_kernel(const double *__restrict__ red, double inv_p, int C, int ld,
                                    const float *__restrict__ gamma, const float *__restrict__ aff, int use_batch,
-                                   float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                   float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                   int accumulate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     Affine a(aff, ld);
@@ -762,8 +763,8 @@ __global__ void bn_bwd_coef_kernel(const double *__restrict__ red, double inv_p,
     coef[ld + c] = use_batch ? (float)(-c0 * (double)a.invstd[c] * r1 * inv_p) : 0.f;
     coef[2 * ld + c] = use_batch ? (float)(-c0 * r0 * inv_p) : 0.f;
     coef[3 * ld + c] = a.mean[c];
-    if (dgamma) dgamma[c] = (float)r1;
-    if (dbeta) dbeta[c] = (float)r0;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)r1 : (float)r1;     // one writer per channel
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)r0 : (float)r0;
 }
 
 inline int round4(int x) { return (x + 3) & ~3; }
@@ -846,10 +847,10 @@ int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const floa
 }
 
 int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, const float *affine, int use_batch_stats,
-                    float *coef, float *dgamma, float *dbeta, pn2_stream_t stream) {
+                    float *coef, float *dgamma, float *dbeta, int accumulate, pn2_stream_t stream) {
     PN2_CHECK_ARG(red && gamma && affine && coef && P > 0 && C > 0);
     hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((unsigned)pn2_cdiv(C, 128)), dim3(128), 0, pn2_s(stream), red, 1.0 / (double)P,
-                       C, (C + 3) & ~3, gamma, affine, use_batch_stats, coef, dgamma, dbeta);
+                       C, (C + 3) & ~3, gamma, affine, use_batch_stats, coef, dgamma, dbeta, accumulate);
     return pn2_launch_status();
 }
 

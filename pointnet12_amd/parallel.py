@@ -29,7 +29,9 @@ class FlatGradBucket:
     no flatten/unflatten copies.
     """
 
-    def __init__(self, module):
+    def __init__(self, module, direct=False):
+        """``direct=True`` additionally lets the HIP backward add weight / BatchNorm gradients straight into the bucket
+        (pointnet_util.set_direct_grad_accumulation): no per-layer gradient tensors, no per-parameter add kernels."""
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("module has no trainable parameters")
@@ -41,6 +43,9 @@ class FlatGradBucket:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        if direct:
+            from . import pointnet_util
+            pointnet_util.set_direct_grad_accumulation(True)
 
     @property
     def nbytes(self):

@@ -234,6 +234,29 @@ class _InterpCat(torch.autograd.Function):
 
 # --------------------------------------------------------------------------------------- shared MLP
 
+_DIRECT_GRADS = False
+
+
+def set_direct_grad_accumulation(enabled):
+    """When enabled, the MLP backward adds weight / BatchNorm gradients straight into existing ``param.grad`` tensors
+    (the wgrad kernel's atomics and the BN-coefficient kernel write there) and returns None for them, instead of
+    materialising per-layer gradient tensors that autograd then adds with ~100 tiny kernels per step.
+    ``parallel.FlatGradBucket(..., direct=True)`` turns this on: every ``.grad`` is then a slice of one flat buffer
+    that is zeroed once per step.  Parameters without a pre-existing contiguous fp32 ``.grad`` fall back to autograd."""
+    global _DIRECT_GRADS
+    _DIRECT_GRADS = bool(enabled)
+
+
+def _direct_ok(params):
+    if not _DIRECT_GRADS:
+        return False
+    for q in params:
+        g = q.grad
+        if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.device != q.device:
+            return False
+    return True
+
+
 class _SharedMLP(torch.autograd.Function):
     """L x (1x1 conv + BatchNorm + ReLU) on position-major rows, then max over ``pool`` consecutive rows.
 
@@ -263,6 +286,8 @@ class _SharedMLP(torch.autograd.Function):
         chans = [c_in] + [flat[7 * l].shape[0] for l in range(L)]
         stats = torch.zeros(2 * sum(chans[1:]), device=dev, dtype=torch.float64) if training else None
         Ys, affs, Wps = [], [], []
+        aff_all = torch.zeros(4 * sum(_r4(c) for c in chans[1:]), device=dev, dtype=torch.float32)
+        aff_off = 0
         x, ldx, x_aff, off = rows, rows.shape[-1], None, 0
         for l in range(L):
             w, b, gamma, beta, rmean, rvar, nbt = flat[7 * l:7 * l + 7]
@@ -292,7 +317,8 @@ class _SharedMLP(torch.autograd.Function):
                 wp = wp.contiguous()
                 _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(wp), ldx, _p(b), _p(y), y.shape[1], P, ci, co,
                                            _p(st_l), st), "pn2_conv1x1_fwd")
-            aff = torch.zeros(4 * _r4(co), device=dev, dtype=torch.float32)
+            aff = aff_all[aff_off:aff_off + 4 * _r4(co)]
+            aff_off += 4 * _r4(co)
             eps, mom = bn_cfg[l]
             _check(lib.pn2_bn_finalize(_p(st_l), P, co, _p(gamma), _p(beta), eps, mom, int(training),
                                        _p(rmean), _p(rvar), _p(nbt), _p(aff), st), "pn2_bn_finalize")
@@ -310,6 +336,7 @@ class _SharedMLP(torch.autograd.Function):
                "pn2_bn_relu_max")
         ctx.meta = (chans, pool, bool(training), P)
         ctx.geom = None if geom is None else (g_xyz, g_new, g_idx, bool(g_first))   # index/coordinate tensors: no cycle
+        ctx.params = flat                       # leaf parameters / buffers (no grad_fn): no cycle either
         # save_for_backward (not ctx attributes): `out` is this node's own output, and holding it on ctx would close a
         # reference cycle that only the cyclic GC breaks -- gigabytes of saved activations would pile up for several
         # steps and the caching allocator would stall in hipMalloc/hipFree in the middle of a step.
@@ -351,29 +378,47 @@ class _SharedMLP(torch.autograd.Function):
                                            _p(dZ), dZ.shape[1], _p(red_L), st), "pn2_relu_bwd_reduce")
         grads = [None] * (7 * L)
         d_rows = None
+        flat = ctx.params
+        direct = _direct_ok([flat[7 * l + j] for l in range(L) for j in (0, 2, 3)])
+        # one zeroed scratch buffer per call: BN-backward coefficient blocks (+ the gradient tensors in autograd mode)
+        sizes = [4 * _r4(chans[l + 1]) + (0 if direct else chans[l + 1] * chans[l] + chans[l + 1]) for l in range(L)]
+        zbuf = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        zoff = np.cumsum([0] + sizes)
         for l in range(L - 1, -1, -1):
             co, ci = chans[l + 1], chans[l]
             y, aff = Ys[l], affs[l]
             ldy = y.shape[1]
-            coef = torch.zeros(4 * _r4(co), device=dev, dtype=torch.float32)
-            dgamma = torch.empty(co, device=dev, dtype=torch.float32)
-            dbeta = torch.empty(co, device=dev, dtype=torch.float32)
+            z0 = int(zoff[l])
+            coef = zbuf[z0:z0 + 4 * _r4(co)]
+            w_p, g_p, b_p = flat[7 * l], flat[7 * l + 2], flat[7 * l + 3]
+            if direct:
+                dgamma, dbeta, dW, dbias = g_p.grad, b_p.grad, w_p.grad, None
+            else:
+                dgamma = torch.empty(co, device=dev, dtype=torch.float32)
+                dbeta = torch.empty(co, device=dev, dtype=torch.float32)
+                dW = zbuf[z0 + 4 * _r4(co):z0 + 4 * _r4(co) + co * ci].view(co, ci)
+                dbias = zbuf[z0 + 4 * _r4(co) + co * ci:z0 + 4 * _r4(co) + co * ci + co]
             _check(lib.pn2_bn_bwd_coef(_p(red[offs[l]:offs[l + 1]]), P, co, _p(gammas[l]), _p(aff), int(training),
-                                       _p(coef), _p(dgamma), _p(dbeta), st), "pn2_bn_bwd_coef")
-            dbias = torch.zeros(co, device=dev, dtype=torch.float32)
+                                       _p(coef), _p(dgamma), _p(dbeta), int(direct), st), "pn2_bn_bwd_coef")
+            if not direct:
+                grads[7 * l + 1], grads[7 * l + 2], grads[7 * l + 3] = dbias, dgamma, dbeta
             if l == 0 and ctx.geom is not None:
-                d_rows, dW = _SharedMLP._first_layer_bwd(ctx, rows, Ws[0], dZ, y, coef, co, ctx.needs_input_grad[0])
-                grads[0], grads[1], grads[2], grads[3] = dW, dbias, dgamma, dbeta
+                d_rows, dW0 = _SharedMLP._first_layer_bwd(ctx, rows, Ws[0], dZ, y, coef, co, ctx.needs_input_grad[0],
+                                                          w_p.grad if direct else None)
+                grads[0] = dW0
                 continue
             x = rows if l == 0 else Ys[l - 1]
             x_aff = None if l == 0 else affs[l - 1]
             ldx = x.shape[1]
-            dW = torch.zeros(co, ci, device=dev, dtype=torch.float32)
             pooled = dZ is None
             a_dz, a_ldz = (None, 0) if pooled else (_p(dZ), dZ.shape[1])
             a_pool = (_p(dzp), ldo, _p(arg), K) if pooled else (None, 0, None, 0)
+            if not training and direct:
+                raise NotImplementedError("direct gradient accumulation with eval-mode BatchNorm: use autograd mode")
             _check(lib.pn2_conv1x1_wgrad(a_dz, a_ldz, *a_pool, _p(y), ldy, _p(coef), _p(x), ldx, _p(x_aff), _p(dW), ci,
                                          None if training else _p(dbias), P, co, ci, st), "pn2_conv1x1_wgrad")
+            if not direct:
+                grads[7 * l] = dW.view_as(Ws[l])
             need_dx = l > 0 or ctx.needs_input_grad[0]
             if need_dx:
                 wt = Ws[l].detach().reshape(co, ci).t()
@@ -391,34 +436,33 @@ class _SharedMLP(torch.autograd.Function):
                         torch.empty(P, ldx, device=dev, dtype=torch.float32)
                     _check(lib.pn2_conv1x1_dgrad(a_dz, a_ldz, *a_pool, _p(y), ldy, _p(coef), _p(wt), ldy, None, 0, None,
                                                  _p(d_rows), ldx, None, P, co, ci, st), "pn2_conv1x1_dgrad")
-            grads[7 * l] = dW.view_as(Ws[l])
-            grads[7 * l + 1] = dbias
-            grads[7 * l + 2] = dgamma
-            grads[7 * l + 3] = dbeta
         return (d_rows, None, None, None, None, None) + tuple(grads)
 
     @staticmethod
-    def _first_layer_bwd(ctx, feats, w, dZ, y, coef, co, need_dfeat):
-        """Backward of the factorised first layer: scatter dY to the source points, then two small GEMMs."""
+    def _first_layer_bwd(ctx, feats, w, dZ, y, coef, co, need_dfeat, w_grad):
+        """Backward of the factorised first layer: scatter dY to the source points, then two small GEMMs.
+        ``w_grad``: None (return dW) or the [co, 3+D] gradient tensor to accumulate into (returns None)."""
         lib, st = _lib.load(), _lib.stream()
         g_xyz, g_new, g_idx, g_first = ctx.geom
         B, N, D = feats.shape
         S, K = g_idx.shape[1], g_idx.shape[2]
         dev = feats.device
         ldc, ldd = _r4(co), _r4(D)
-        G = torch.zeros(B * N, ldc, device=dev, dtype=torch.float32)
-        dWx = torch.zeros(co, 3, device=dev, dtype=torch.float32)
-        _check(lib.pn2_group_affine_bwd(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new), _p(g_idx),
-                                        B, N, S, K, co, _p(G), ldc, _p(dWx), st), "pn2_group_affine_bwd")
-        ident = torch.zeros(4 * ldc, device=dev, dtype=torch.float32)      # dY := 1*G + 0*(y-0) + 0
+        zb = torch.zeros(B * N * ldc + 4 * ldc, device=dev, dtype=torch.float32)
+        G = zb[:B * N * ldc].view(B * N, ldc)
+        ident = zb[B * N * ldc:]                      # dY := 1*G + 0*(y-0) + 0
         ident[:co] = 1.0
+        dW = torch.zeros(co, 3 + D, device=dev, dtype=torch.float32) if w_grad is None else w_grad
+        ldw = 3 + D
+        x_col, f_col = (0, 3) if g_first else (D, 0)
+        _check(lib.pn2_group_affine_bwd(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new), _p(g_idx),
+                                        B, N, S, K, co, _p(G), ldc, dW.data_ptr() + 4 * x_col, ldw, st),
+               "pn2_group_affine_bwd")
         feat = feats.reshape(B * N, D)
         if ldd != D:
             feat = torch.nn.functional.pad(feat, (0, ldd - D)).contiguous()
-        dWf = torch.zeros(co, D, device=dev, dtype=torch.float32)
-        _check(lib.pn2_conv1x1_wgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), _p(feat), ldd, None, _p(dWf), D,
-                                     None, B * N, co, D, st), "pn2_conv1x1_wgrad")
-        dW = torch.cat([dWx, dWf], 1) if g_first else torch.cat([dWf, dWx], 1)
+        _check(lib.pn2_conv1x1_wgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), _p(feat), ldd, None,
+                                     dW.data_ptr() + 4 * f_col, ldw, None, B * N, co, D, st), "pn2_conv1x1_wgrad")
         d_feats = None
         if need_dfeat:
             w2 = w.detach().reshape(co, 3 + D)
@@ -430,7 +474,7 @@ class _SharedMLP(torch.autograd.Function):
             _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), _p(wt), ldc, None, 0, None,
                                          _p(dF), ldd, None, B * N, co, D, st), "pn2_conv1x1_dgrad")
             d_feats = (dF[:, :D] if ldd != D else dF).reshape(B, N, D)
-        return d_feats, dW.view_as(w)
+        return d_feats, (dW.view_as(w) if w_grad is None else None)
 
 
 def _flat_params(convs, bns):
