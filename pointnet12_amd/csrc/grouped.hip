@@ -108,15 +108,31 @@ __global__ __launch_bounds__(256) void group_affine_bwd_kernel(const float *__re
         float acc[3] = {0.f, 0.f, 0.f};
         if (live && c < C) {
             const float c0 = coef[c], q1 = coef[ldc + c], q0 = coef[2 * ldc + c], mu = coef[3 * ldc + c];
-            for (int64_t p = (int64_t)blockIdx.x * RPB + r; p < P; p += (int64_t)gridDim.x * RPB) {
-                const int64_t g = p / K, b = g / S;
-                const int64_t j = idx[p];
-                const float *q = xyz + (b * N + j) * 3, *ctr = new_xyz + g * 3;
-                const float dy = __builtin_fmaf(c0, dZ[p * ldz + c], __builtin_fmaf(q1, Y[p * ldy + c] - mu, q0));
-                atomicAdd(G + (b * N + j) * ldg + c, dy);
-                acc[0] = __builtin_fmaf(dy, q[0] - ctr[0], acc[0]);
-                acc[1] = __builtin_fmaf(dy, q[1] - ctr[1], acc[1]);
-                acc[2] = __builtin_fmaf(dy, q[2] - ctr[2], acc[2]);
+            // four independent rows per trip: the idx -> xyz -> atomic chains of a lane overlap instead of queueing
+            const int64_t stride = (int64_t)gridDim.x * RPB;
+            for (int64_t p0 = (int64_t)blockIdx.x * RPB + r; p0 < P; p0 += 4 * stride) {
+                int64_t j[4], g[4];
+                float dzv[4], yv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t p = p0 + u * stride;
+                    const bool v = p < P;
+                    g[u] = v ? p / K : 0;
+                    j[u] = v ? idx[p] : 0;
+                    dzv[u] = v ? dZ[p * ldz + c] : 0.f;
+                    yv[u] = v ? Y[p * ldy + c] : mu;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (p0 + u * stride >= P) break;
+                    const int64_t b = g[u] / S;
+                    const float *q = xyz + (b * N + j[u]) * 3, *ctr = new_xyz + g[u] * 3;
+                    const float dy = __builtin_fmaf(c0, dzv[u], __builtin_fmaf(q1, yv[u] - mu, q0));
+                    atomicAdd(G + (b * N + j[u]) * ldg + c, dy);
+                    acc[0] = __builtin_fmaf(dy, q[0] - ctr[0], acc[0]);
+                    acc[1] = __builtin_fmaf(dy, q[1] - ctr[1], acc[1]);
+                    acc[2] = __builtin_fmaf(dy, q[2] - ctr[2], acc[2]);
+                }
             }
         }
         red[t * 3] = acc[0]; red[t * 3 + 1] = acc[1]; red[t * 3 + 2] = acc[2];
@@ -146,7 +162,7 @@ int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float
     const int64_t P = (int64_t)B * S * K;
     const int rpb = 256 / ((C + 3) >> 2);
     int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 8);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;    // 2*C same-address fp64 atomics per workgroup at the end
     hipLaunchKernelGGL(group_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), Zf, ldz, xyz, new_xyz, idx,
                        Wx, N, S, K, C, P, Y, ldy, stats);
     return pn2_launch_status();
@@ -161,7 +177,7 @@ int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, cons
     const int64_t P = (int64_t)B * S * K;
     const int rpb = C < 256 ? 256 / C : 1;
     int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 16);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 768) blocks = 768;      // every workgroup ends with 3*C same-address atomics on dWx: keep that queue short
     hipLaunchKernelGGL(group_affine_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), dZ, ldz, Y, ldy, coef,
                        (C + 3) & ~3, xyz, new_xyz, idx, N, S, K, C, P, G, ldg, dWx, ldwx);
     return pn2_launch_status();
