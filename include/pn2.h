@@ -29,6 +29,12 @@ extern "C" {
 
 #define PN2_ABI_VERSION 1
 
+/* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
+ * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
+ * same-address atomic queues stay short; pn2_bn_finalize / pn2_bn_bwd_coef sum the copies.  The caller
+ * allocates and zeroes PN2_STAT_REPLICAS * 2 * C doubles. */
+#define PN2_STAT_REPLICAS 8
+
 #define PN2_OK 0
 #define PN2_EINVAL (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define PN2_ELAUNCH (-2)    /* hipLaunch / hipMemsetAsync failed */
@@ -133,7 +139,7 @@ int pn2_copy_cols(const float *src, int lds, int scol0, float *dst, int ldd, int
 /* Y[P,N] = act(X)[P,K] * W[N,K]^T + bias.  X has row pitch ldx (>= K, multiple of 4, pad
  * columns zero), W row pitch ldw (>= K, multiple of 4, pad columns zero), Y pitch ldy
  * (multiple of 4).  in_affine: NULL (X is used as is) or the affine block (4*ldx floats) of
- * the layer that produced X.  stats: NULL or double[2*N] (caller zeroes) receiving
+ * the layer that produced X.  stats: NULL or a replicated double[2*N] block (see PN2_STAT_REPLICAS; caller zeroes) receiving
  * sum(y) and sum(y*y) per output channel over the P rows (training-mode BN statistics). */
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias,
                     float *Y, int ldy, int64_t P, int K, int N, double *stats, pn2_stream_t stream);

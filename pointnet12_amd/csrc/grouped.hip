@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256) void group_affine_fwd_kernel(const float *__re
             a0 += red[(rr * CG + g4) * 8 + e];
             a1 += red[(rr * CG + g4) * 8 + 4 + e];
         }
-        atomicAdd(stats + ch, a0);
-        atomicAdd(stats + C + ch, a1);
+        double *rep = stats + (size_t)(blockIdx.x % PN2_STAT_REPLICAS) * 2 * C;
+        atomicAdd(rep + ch, a0);
+        atomicAdd(rep + C + ch, a1);
     }
 }
 

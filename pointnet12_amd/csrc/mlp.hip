@@ -208,8 +208,9 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
         s1.z = __builtin_fmaf(y.z, y.z, s1.z); s1.w = __builtin_fmaf(y.w, y.w, s1.w);
     }
     __device__ __forceinline__ void flush(int n, int N, double a0, double a1) const {
-        atomicAdd(stats + n, a0);
-        atomicAdd(stats + N + n, a1);
+        double *rep = stats + (size_t)(blockIdx.x % PN2_STAT_REPLICAS) * 2 * N;    // spread the same-address queue
+        atomicAdd(rep + n, a0);
+        atomicAdd(rep + N + n, a1);
     }
 };
 
@@ -237,8 +238,9 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
         s1.w = __builtin_fmaf(dz.w, (y.w - c[0].w) * c[3].w, s1.w);
     }
     __device__ __forceinline__ void flush(int n, int N, double a0, double a1) const {
-        atomicAdd(red + n, a0);
-        atomicAdd(red + N + n, a1);
+        double *rep = red + (size_t)(blockIdx.x % PN2_STAT_REPLICAS) * 2 * N;
+        atomicAdd(rep + n, a0);
+        atomicAdd(rep + N + n, a1);
     }
 };
 
@@ -646,8 +648,10 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, double inv_
     if (c >= C) return;
     double mean, var;
     if (training) {
-        mean = stats[c] * inv_p;
-        var = stats[C + c] * inv_p - mean * mean;
+        double s0 = 0.0, s1 = 0.0;
+        for (int r = 0; r < PN2_STAT_REPLICAS; ++r) { s0 += stats[r * 2 * C + c]; s1 += stats[r * 2 * C + C + c]; }
+        mean = s0 * inv_p;
+        var = s1 * inv_p - mean * mean;
         if (var < 0.0) var = 0.0;
         if (rmean) rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
         if (rvar) rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * var * unbias);
@@ -714,8 +718,9 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
     if (gl == 0 && c < C) {
         double a0 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
         double a1 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
-        atomicAdd(red + c, a0);
-        atomicAdd(red + C + c, a1);
+        double *rep = red + (size_t)(blockIdx.y % PN2_STAT_REPLICAS) * 2 * C;
+        atomicAdd(rep + c, a0);
+        atomicAdd(rep + C + c, a1);
     }
 }
 
@@ -745,8 +750,9 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
     if (gl == 0 && c < C) {
         double a0 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
         double a1 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
-        atomicAdd(red + c, a0);
-        atomicAdd(red + C + c, a1);
+        double *rep = red + (size_t)(blockIdx.y % PN2_STAT_REPLICAS) * 2 * C;
+        atomicAdd(rep + c, a0);
+        atomicAdd(rep + C + c, a1);
     }
 }
 
@@ -758,7 +764,8 @@ __global__ void bn_bwd_coef_kernel(const double *__restrict__ red, double inv_p,
     if (c >= C) return;
     Affine a(aff, ld);
     double c0 = (double)gamma[c] * (double)a.invstd[c];
-    double r0 = red[c], r1 = red[C + c];
+    double r0 = 0.0, r1 = 0.0;
+    for (int r = 0; r < PN2_STAT_REPLICAS; ++r) { r0 += red[r * 2 * C + c]; r1 += red[r * 2 * C + C + c]; }
     coef[c] = (float)c0;
     coef[ld + c] = use_batch ? (float)(-c0 * (double)a.invstd[c] * r1 * inv_p) : 0.f;
     coef[2 * ld + c] = use_batch ? (float)(-c0 * r0 * inv_p) : 0.f;

@@ -235,6 +235,7 @@ class _InterpCat(torch.autograd.Function):
 # --------------------------------------------------------------------------------------- shared MLP
 
 _DIRECT_GRADS = False
+_REPL = 8                         # PN2_STAT_REPLICAS of include/pn2.h
 _MALL_CHUNK_BYTES = 1 << 62       # row-chunked dgrad+wgrad pairing is OFF: measured 10.9 -> 13.1 ms/step at 96 MiB chunks
                                   # (per-launch fixed costs beat the Infinity-Cache hits); kept as a tuning knob
 
@@ -286,7 +287,7 @@ class _SharedMLP(torch.autograd.Function):
             gS, gK = g_idx.shape[1], g_idx.shape[2]
             P = gB * gS * gK
         chans = [c_in] + [flat[7 * l].shape[0] for l in range(L)]
-        stats = torch.zeros(2 * sum(chans[1:]), device=dev, dtype=torch.float64) if training else None
+        stats = torch.zeros(_REPL * 2 * sum(chans[1:]), device=dev, dtype=torch.float64) if training else None
         Ys, affs, Wps = [], [], []
         aff_all = torch.zeros(4 * sum(_r4(c) for c in chans[1:]), device=dev, dtype=torch.float32)
         aff_off = 0
@@ -295,7 +296,7 @@ class _SharedMLP(torch.autograd.Function):
             w, b, gamma, beta, rmean, rvar, nbt = flat[7 * l:7 * l + 7]
             co, ci = chans[l + 1], chans[l]
             y = _empty_rows(P, co, dev)
-            st_l = stats[off:off + 2 * co] if training else None
+            st_l = stats[off:off + _REPL * 2 * co] if training else None
             if l == 0 and geom is not None:
                 w2 = w.detach().reshape(co, ci)
                 wx = (w2[:, :3] if g_first else w2[:, gD:]).contiguous()
@@ -328,7 +329,7 @@ class _SharedMLP(torch.autograd.Function):
             affs.append(aff)
             Wps.append(wp)
             x, ldx, x_aff = y, y.shape[1], aff
-            off += 2 * co
+            off += _REPL * 2 * co
         cl = chans[-1]
         K = pool if pool else 1
         G = P // K
@@ -363,8 +364,8 @@ class _SharedMLP(torch.autograd.Function):
             g[:, :cl] = grad_out
             grad_out = g
         grad_out = grad_out.contiguous()
-        red = torch.zeros(2 * sum(chans[1:]), device=dev, dtype=torch.float64)
-        offs = np.cumsum([0] + [2 * c for c in chans[1:]])
+        red = torch.zeros(_REPL * 2 * sum(chans[1:]), device=dev, dtype=torch.float64)
+        offs = np.cumsum([0] + [_REPL * 2 * c for c in chans[1:]])
         K = pool if pool else 1
         G = P // K
         dZ = None

@@ -73,7 +73,7 @@ def main():
             W = torch.zeros(N, r4(K), device=dev)
             W[:, :K] = rnd(N, K)
             bias, Y = rnd(N), torch.empty(P, r4(N), device=dev)
-            stats = torch.zeros(2 * N, device=dev, dtype=torch.float64)
+            stats = torch.zeros(8 * 2 * N, device=dev, dtype=torch.float64)
             aff = affine(K) if K > 12 else None
 
             def fn():
@@ -102,7 +102,7 @@ def main():
                 dy_bytes = 2 * P * Cl
             if which == "dgrad":
                 dX = torch.empty(P, r4(Cp), device=dev)
-                red = torch.zeros(2 * Cp, device=dev, dtype=torch.float64)
+                red = torch.zeros(8 * 2 * Cp, device=dev, dtype=torch.float64)
 
                 def fn():
                     rc = lib.pn2_conv1x1_dgrad(*dz, p(Y), r4(Cl), p(coef), p(Wt), r4(Cl), p(Yp), r4(Cp), p(affp), p(dX), r4(Cp),
