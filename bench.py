@@ -265,6 +265,17 @@ def main():
         else:
             roofline = {"kernel": top, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+        # HBM traffic of that kernel family from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes), per launch.
+        fam = {"pn2_conv1x1_wgrad": "gemm_tn_kernel", "pn2_conv1x1_fwd": "gemm_nt_kernel<fwd>",
+               "pn2_conv1x1_dgrad": "gemm_nt_kernel<dgrad>"}.get(top)
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)
+        if fam and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))["families"].get(fam)
+            if pmc:
+                roofline["traffic"] = round(pmc["hbm_bytes_per_step"] / pmc["launches_per_step"])
+                roofline["traffic_note"] = "bytes per launch, PMC (profiles/%s); algorithmic bytes per launch %d" % (
+                    os.path.basename(pmc_path), round(v[3] / v[1]))
         roofline["avg_launch_us"] = round(v[0] / v[1] * 1e3, 2)
         roofline["launches"] = v[1] // prof_steps
         roofline["device_ms_all_kernels_per_step"] = round(sum(x[0] for x in agg.values()) / prof_steps, 3)

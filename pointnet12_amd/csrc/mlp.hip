@@ -603,7 +603,8 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
 template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad>
 int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
     unsigned tm = (unsigned)pn2_cdiv(M, BM), tn = (unsigned)pn2_cdiv(N, BN);
-    int64_t want = (int64_t)pn2_num_cus() * MINB / ((int64_t)tm * tn);   // MINB resident workgroups per CU
+    static const int splitdiv = pn2_env_int("PN2_TN_SPLITDIV", 1);
+    int64_t want = (int64_t)pn2_num_cus() * MINB / ((int64_t)tm * tn) / splitdiv;   // MINB resident workgroups per CU
     if (want < 1) want = 1;
     int64_t max_split = pn2_cdiv(P, 8 * WG_BP);
     int64_t split = want < max_split ? want : max_split;
