@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-launch table of the instrumented pass on stderr")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="compute each batch's FPS/ball-query/3-NN inside its own step instead of one step ahead")
     args = ap.parse_args()
 
     import numpy as np
@@ -198,7 +200,10 @@ def main():
     if not args.no_graph:
         from pointnet12_amd.graph import GraphedStep
         torch.manual_seed(4321)
-        graphed = GraphedStep(compute, dev)         # one hipGraph launch per step (capture failures raise)
+        geometry = None
+        if args.workload != "sa" and not args.no_prefetch:
+            geometry = lambda: net.features(pts)    # geometry-only pass (recording tape) over the next batch
+        graphed = GraphedStep(compute, dev, geometry_fn=geometry)   # one hipGraph launch per step (failures raise)
     else:
         graphed = compute
 
@@ -292,6 +297,8 @@ def main():
             "config": {"workload": WORKLOADS[args.workload], "clouds_per_gpu": batch, "points_per_cloud": n_points,
                        "channels": 9, "global_batch": batch * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
+                       "geometry": "in-step" if (args.no_graph or args.no_prefetch or args.workload == "sa")
+                       else "next batch's FPS/ball-query/3-NN prefetched on a side stream inside the same graph",
                        "grad_bucket_bytes": bucket.nbytes},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

@@ -121,8 +121,58 @@ def draw_fps_start(B, N, device):
     return torch.randint(0, N, (B,), dtype=torch.long).to(device, non_blocking=True)
 
 
+class GeometryTape:
+    """Recorded results of the index-producing primitives (FPS, ball query, 3-NN) of one forward pass.
+
+    Everything those primitives compute depends only on the xyz coordinates, never on features or weights, so the
+    whole geometry of a batch can be produced ahead of time (pointnet12_amd.graph prefetches the NEXT batch's
+    geometry on a side stream while the current batch's MLPs run).  ``record`` mode: the modules run their
+    geometry, append the results here and skip all feature work (they return uninitialised placeholders of the
+    right shape).  ``replay`` mode: the primitives hand back the recorded tensors in the same call order."""
+
+    def __init__(self):
+        self.items = []
+        self.pos = 0
+        self.mode = "record"
+
+    def rewind(self, mode):
+        self.pos = 0
+        self.mode = mode
+
+
+_tape = None
+
+
+def set_geometry_tape(tape):
+    global _tape
+    _tape = tape
+
+
+def _recording():
+    return _tape is not None and _tape.mode == "record"
+
+
+def _taped(compute):
+    if _tape is None:
+        return compute()
+    if _tape.mode == "record":
+        v = compute()
+        _tape.items.append(v)
+        return v
+    v = _tape.items[_tape.pos]
+    _tape.pos += 1
+    return v
+
+
+def _placeholder(B, C, S, device):
+    """Channel-first view of uninitialised channel-last storage (what a module returns in record mode)."""
+    return torch.empty(B, S, C, device=device, dtype=torch.float32).permute(0, 2, 1)
+
+
 def farthest_point_sample(xyz, npoint, start=None):
     """xyz [B,N,3] -> int64 [B,npoint]; pointnet_util.py:63-84.  ``start`` overrides the random draw."""
+    if _tape is not None and _tape.mode == "replay":
+        return _taped(None)
     xyz = _gpu_f32(xyz, "xyz")
     B, N, C = xyz.shape
     if C != 3:
@@ -135,11 +185,13 @@ def farthest_point_sample(xyz, npoint, start=None):
     nbytes = lib.pn2_fps_workspace_bytes(B, N)
     work = torch.empty(nbytes, device=xyz.device, dtype=torch.uint8) if nbytes else None
     _check(lib.pn2_fps(_p(xyz), B, N, _p(start), npoint, _p(out), _p(work), _lib.stream()), "pn2_fps")
-    return out
+    return _taped(lambda: out)
 
 
 def query_ball_point(radius, nsample, xyz, new_xyz):
     """-> int64 [B,S,nsample]; pointnet_util.py:87-107 (first nsample in-radius indices, padded with the first)."""
+    if _tape is not None and _tape.mode == "replay":
+        return _taped(None)
     xyz, new_xyz = _gpu_f32(xyz, "xyz"), _gpu_f32(new_xyz, "new_xyz")
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
@@ -149,13 +201,15 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     r2 = float(np.float32(radius ** 2))
     _check(_lib.load().pn2_ball_query(_p(xyz), _p(new_xyz), B, N, S, r2, nsample, _p(out), _lib.stream()),
            "pn2_ball_query")
-    return out
+    return _taped(lambda: out)
 
 
 def three_nn(xyz1, xyz2):
     """3 nearest of xyz2 [B,S,3] for every point of xyz1 [B,N,3] -> (idx int64, raw dist, weights), each [B,N,3].
 
     pointnet_util.py:295-300; ties go to the lower index (the reference's sort leaves tie order undefined)."""
+    if _tape is not None and _tape.mode == "replay":
+        return _taped(None)
     xyz1, xyz2 = _gpu_f32(xyz1, "xyz1"), _gpu_f32(xyz2, "xyz2")
     B, N, _ = xyz1.shape
     S = xyz2.shape[1]
@@ -166,7 +220,7 @@ def three_nn(xyz1, xyz2):
     w = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
     _check(_lib.load().pn2_three_nn(_p(xyz1), _p(xyz2), B, N, S, _p(idx), _p(dist), _p(w), _lib.stream()),
            "pn2_three_nn")
-    return idx, dist, w
+    return _taped(lambda: (idx, dist, w))
 
 
 class _Group(torch.autograd.Function):
@@ -599,7 +653,7 @@ class PointNetSetAbstraction(nn.Module):
         B, N, _ = xyz.shape
         if self.group_all:
             new_xyz = torch.zeros(B, 1, 3, device=xyz.device)
-            rows = _Group.apply(xyz, pts, None, None, 1, N, True)
+            rows = None if _recording() else _Group.apply(xyz, pts, None, None, 1, N, True)
             S, K = 1, N
         else:
             S, K = self.npoint, self.nsample
@@ -610,6 +664,8 @@ class PointNetSetAbstraction(nn.Module):
         c_in = 3 + (0 if pts is None else pts.shape[2])
         if c_in != self.in_channel:
             raise RuntimeError("expected %d input channels (3 + features), got %d" % (self.in_channel, c_in))
+        if _recording():
+            return new_xyz.permute(0, 2, 1), _placeholder(B, self.mlp_convs[-1].out_channels, S, xyz.device)
         if rows is None:
             out = grouped_mlp(xyz, pts, new_xyz, idx, True, self.mlp_convs, self.mlp_bns, self.training)
         else:
@@ -650,8 +706,12 @@ class PointNetSetAbstractionMsg(nn.Module):
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             idx = query_ball_point(radius, K, xyz, new_xyz)
+            if _recording():
+                continue
             outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
                                     self.training))                           # features first (:247)
+        if _recording():
+            return new_xyz.permute(0, 2, 1), _placeholder(B, sum(c[-1].out_channels for c in self.conv_blocks), S, xyz.device)
         out = torch.cat(outs, dim=1)                                          # [B*S, sum C]
         return new_xyz.permute(0, 2, 1), out.view(B, S, -1).permute(0, 2, 1)
 
@@ -678,6 +738,10 @@ class PointNetFeaturePropagation(nn.Module):
         p1 = None if points1 is None else _channel_last(points1, "points1")
         B, N, _ = x1.shape
         S = x2.shape[1]
+        if _recording():
+            if S != 1:
+                three_nn(x1, x2)
+            return _placeholder(B, self.mlp_convs[-1].out_channels, N, x1.device)
         if S == 1:                                      # pointnet_util.py:292-293: broadcast the single feature row
             interp = p2.expand(B, N, p2.shape[2])
             rows = interp if p1 is None else torch.cat([p1, interp], dim=-1)

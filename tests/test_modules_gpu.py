@@ -239,3 +239,40 @@ def test_direct_grad_accumulation_matches_autograd(dev):
     assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())       # atomics order + flip noise of the tiny batch
     # exactness check on a flip-free quantity: per-tensor L2 norms
     assert abs(float(a.norm()) - float(b.norm())) <= 5e-3 * float(a.norm())
+
+
+def test_prefetched_geometry_graph_matches_eager(dev):
+    """Graph with the next batch's geometry on a side stream: same loss sequence as plain eager steps (same draws)."""
+    from pointnet12_amd import parallel
+    from pointnet12_amd.graph import GraphedStep
+    g = golden("g6_nets.npz")
+    pts = torch.from_numpy(g["points"]).to(dev)
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    seqs = []
+    for mode in ("eager", "prefetch"):
+        torch.manual_seed(int(g["init_seed"]))
+        net = M.PointNet2SemSegMsg(13, 6)
+        net.drop1.p = 0.0
+        net.to(dev).train()
+        bucket = parallel.FlatGradBucket(net)
+
+        def compute():
+            bucket.zero()
+            lp = net(pts)
+            loss = F.nll_loss(lp.reshape(-1, 13), labels.reshape(-1))
+            loss.backward()
+            return loss
+        torch.manual_seed(31)
+        if mode == "eager":
+            for _ in range(2):
+                compute()
+            step = compute
+        else:
+            step = GraphedStep(compute, dev, warmup=2, geometry_fn=lambda: net.features(pts))
+        losses = []
+        for _ in range(4):
+            losses.append(float(step()))
+        seqs.append((losses, bucket.flat.clone()))
+    (la, ga), (lb, gb) = seqs
+    assert np.allclose(la, lb, rtol=0, atol=2e-5), (la, lb)
+    assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
