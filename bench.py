@@ -71,13 +71,13 @@ def algorithmic_work(name, a):
     return 0.0, 0.0
 
 
-def build_net(workload, dev):
+def build_net(workload, dev, npoint_scale=1):
     import torch
     from pointnet12_amd import pointnet2 as M
     from pointnet12_amd import pointnet_util as U
     torch.manual_seed(0)
     if workload == "msg":
-        net = M.PointNet2SemSegMsg(13, 6)
+        net = M.PointNet2SemSegMsg(13, 6, npoint_scale=npoint_scale)
     elif workload == "ssg":
         net = M.PointNet2SemSeg(13, 6)
     else:
@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="msg")
     ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (default 16; 8 for --workload sa)")
+    ap.add_argument("--points", type=int, default=4096, help="points per cloud (cfg5 of BASELINE.json: 65536)")
+    ap.add_argument("--npoint-scale", type=int, default=1, help="MSG only: multiply sa1/sa2 npoint (cfg5: 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-launch table of the instrumented pass on stderr")
@@ -187,13 +189,13 @@ def main():
     _lib.load()                              # no HIP library -> raise, never fall back
 
     batch = args.batch or (8 if args.workload == "sa" else 16)
-    n_points = 4096
+    n_points = args.points
     lo, _ = parallel.shard_range(batch * world, rank, world)
     pts_np, lab_np = syn.kitti_batch(lo, batch, n_points)
     pts = torch.from_numpy(pts_np).to(dev)
     labels = torch.from_numpy(lab_np).to(dev)
 
-    net = build_net(args.workload, dev)
+    net = build_net(args.workload, dev, args.npoint_scale)
     parallel.broadcast_module(net)
     bucket = parallel.FlatGradBucket(net, direct=True)
     compute = make_step(args.workload, net, pts, labels, bucket)     # zero grads + forward + loss + backward
@@ -286,7 +288,7 @@ def main():
         roofline["device_ms_all_kernels_per_step"] = round(sum(x[0] for x in agg.values()) / prof_steps, 3)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and n_points == 4096:
         cpu = cpu_baseline(args.workload, batch)
 
     if rank == 0:
