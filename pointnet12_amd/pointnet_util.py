@@ -16,6 +16,9 @@ Layout notes
   * inside a module the grouped tensor is position-major ``[P, C]`` (P = B*S*K rows); the
     reference's ``[B, C, K, S]`` permute (pointnet_util.py:194) never happens.
 """
+import contextlib
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -100,6 +103,17 @@ def index_points(points, idx, _checked=True):
     if idx.dtype != torch.int64:
         idx = idx.long()
     return _GatherRows.apply(points, idx, _checked)
+
+
+MSG_SCALE_STREAMS = os.environ.get("PN2_MSG_STREAMS", "1") == "1"     # measured: 10.36 -> 9.90 ms/step (MSG-SemSeg)
+_scale_stream_pool = {}
+
+
+def _scale_streams(device, n):
+    pool = _scale_stream_pool.setdefault(str(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool
 
 
 _fps_start_feed = None
@@ -703,13 +717,33 @@ class PointNetSetAbstractionMsg(nn.Module):
         new_xyz = index_points(xyz, farthest_point_sample(xyz, S, fps_start), _checked=False)
         c_in = 3 + (0 if pts is None else pts.shape[2])
         outs = []
+        # The scales are independent until the final concatenation: with MSG_SCALE_STREAMS on, each one is issued
+        # on its own HIP stream (autograd replays the backward on the same streams), so under graph capture they
+        # become parallel branches and one scale's small kernels / GEMM tails fill under another's GEMMs.
+        branch = MSG_SCALE_STREAMS and not _recording() and len(self.radius_list) > 1
+        if branch:
+            main = torch.cuda.current_stream(xyz.device)
+            streams = _scale_streams(xyz.device, len(self.radius_list))
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
-            idx = query_ball_point(radius, K, xyz, new_xyz)
-            if _recording():
-                continue
-            outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
-                                    self.training))                           # features first (:247)
+            if branch:
+                streams[i].wait_stream(main)
+                for t in (xyz, pts, new_xyz):              # allocated on the main stream, read on the branch
+                    if t is not None:
+                        t.record_stream(streams[i])
+                ctx_mgr = torch.cuda.stream(streams[i])
+            else:
+                ctx_mgr = contextlib.nullcontext()
+            with ctx_mgr:
+                idx = query_ball_point(radius, K, xyz, new_xyz)
+                if _recording():
+                    continue
+                outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
+                                        self.training))                       # features first (:247)
+        if branch:
+            for st, o in zip(streams, outs):
+                main.wait_stream(st)
+                o.record_stream(main)                      # produced on the branch, concatenated on the main stream
         if _recording():
             return new_xyz.permute(0, 2, 1), _placeholder(B, sum(c[-1].out_channels for c in self.conv_blocks), S, xyz.device)
         out = torch.cat(outs, dim=1)                                          # [B*S, sum C]
