@@ -276,3 +276,33 @@ def test_prefetched_geometry_graph_matches_eager(dev):
     (la, ga), (lb, gb) = seqs
     assert np.allclose(la, lb, rtol=0, atol=2e-5), (la, lb)
     assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
+
+
+def test_cfg2_full_size_set_abstraction_vs_oracle(dev):
+    """BASELINE.json configs[1] at its real size: PointNetSetAbstraction(1024, 0.1, 32, 9, [32,32,64]), B=8 x 4096 KITTI-shaped
+    clouds, forward + backward, against the oracle module on the host CPU (about 2 s there)."""
+    from oracle import torch_ref as T
+    from pointnet12_amd import synthetic as syn
+    pts = torch.from_numpy(syn.kitti_batch(700, 8, 4096)[0])
+    xyz, feat = pts[:, :3].contiguous(), pts[:, 3:].contiguous()
+    torch.manual_seed(2)
+    orc = T.RefSetAbstraction(1024, 0.1, 32, 9, [32, 32, 64], False)
+    mod = U.PointNetSetAbstraction(1024, 0.1, 32, 9, [32, 32, 64], False)
+    mod.load_state_dict(orc.state_dict())
+    mod.to(dev).train()
+    orc.train()
+    f_ref, f_gpu = feat.clone().requires_grad_(True), feat.clone().to(dev).requires_grad_(True)
+    torch.manual_seed(3)
+    nx_ref, a = orc(xyz, f_ref)
+    torch.manual_seed(3)
+    nx, b = mod(xyz.to(dev), f_gpu)
+    assert torch.equal(nx_ref, nx.cpu())                            # same FPS picks -> identical centroids
+    assert float((a.detach() - b.detach().cpu()).abs().max()) <= FWD_TOL
+    gw = torch.randn(a.shape, generator=torch.Generator().manual_seed(4))
+    (a * gw).sum().backward()
+    (b * gw.to(dev)).sum().backward()
+    assert relmax(f_gpu.grad.cpu().numpy(), f_ref.grad.numpy()) <= GRAD_TOL
+    for (n, p), (_, q) in zip(orc.named_parameters(), mod.named_parameters()):
+        if "conv" in n and n.endswith("bias"):
+            continue
+        assert relmax(q.grad.cpu().numpy(), p.grad.numpy()) <= GRAD_TOL, n
