@@ -39,6 +39,7 @@ __device__ __forceinline__ int4 ld4i(const int32_t *p) { return *reinterpret_cas
 // Rows of one loader thread are m + i*stride, i < IT, all at the same 4 columns k..k+3.
 
 const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};
+__device__ float4 pn2_zero_page[4];          // always-zero source for predicated-off operand requests
 
 // The per-channel constants of a loader's 4 columns are (re)loaded by params() at finish time -- they hit L1/L2,
 // and keeping them out of the in-flight register set is what lets the kernels run at 3-4 workgroups per CU
@@ -54,7 +55,7 @@ struct LoadPlain {          // X as stored
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
-            r.x[i] = (kvalid && mi < rows) ? ld4(X + mi * ldx + k) : kZero4;
+            r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : reinterpret_cast<const float *>(pn2_zero_page));
         }
     }
     __device__ __forceinline__ Params params(int, bool) const { return Params(); }
@@ -70,13 +71,16 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
     template <int IT>
     __device__ __forceinline__ void issue(Raw<IT> &r, int64_t m, int stride, int k, int64_t rows, bool kvalid) const {
         Affine a(aff, ldx);
-        r.mu = kvalid ? ld4(a.mean + k) : kZero4;      // pad / invalid columns: scale = beta = 0 -> operand 0
-        r.sc = kvalid ? ld4(a.scale + k) : kZero4;
-        r.be = kvalid ? ld4(a.beta + k) : kZero4;
+        // every request is always issued (invalid ones read the zero page): straight-line code lets the compiler
+        // count the outstanding requests instead of draining them
+        const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+        r.mu = ld4(kvalid ? a.mean + k : zp);          // pad / invalid columns: scale = beta = 0 -> operand 0
+        r.sc = ld4(kvalid ? a.scale + k : zp);
+        r.be = ld4(kvalid ? a.beta + k : zp);
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
-            r.x[i] = (kvalid && mi < rows) ? ld4(X + mi * ldx + k) : kZero4;
+            r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : zp);
         }
     }
     __device__ __forceinline__ Params params(int, bool) const { return Params(); }
@@ -96,10 +100,11 @@ struct DyParams { float4 c0, q1, q0, mu; };
 
 __device__ __forceinline__ DyParams dy_params(const float *coef, int ldc, int k, bool kvalid) {
     DyParams q;
-    q.c0 = kvalid ? ld4(coef + k) : kZero4;
-    q.q1 = kvalid ? ld4(coef + ldc + k) : kZero4;
-    q.q0 = kvalid ? ld4(coef + 2 * ldc + k) : kZero4;
-    q.mu = kvalid ? ld4(coef + 3 * ldc + k) : kZero4;
+    const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+    q.c0 = ld4(kvalid ? coef + k : zp);
+    q.q1 = ld4(kvalid ? coef + ldc + k : zp);
+    q.q0 = ld4(kvalid ? coef + 2 * ldc + k : zp);
+    q.mu = ld4(kvalid ? coef + 3 * ldc + k : zp);
     return q;
 }
 
@@ -124,8 +129,9 @@ struct LoadDyDense {
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
             const bool v = kvalid && mi < rows;
-            r.dz[i] = v ? ld4(dZ + mi * ldz + k) : kZero4;
-            r.y[i] = v ? ld4(Y + mi * ldy + k) : kZero4;
+            const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+            r.dz[i] = ld4(v ? dZ + mi * ldz + k : zp);
+            r.y[i] = ld4(v ? Y + mi * ldy + k : zp);
         }
     }
     __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid); }
@@ -151,9 +157,10 @@ struct LoadDyPooled {
             const bool v = kvalid && mi < rows;
             const unsigned g = (unsigned)mi / (unsigned)Kp;         // P < 2^31 (checked by the host wrapper)
             r.kk[i] = (int)((unsigned)mi - g * (unsigned)Kp);
-            r.go[i] = v ? ld4(dZp + (int64_t)g * ldo + k) : kZero4;
-            r.a[i] = v ? ld4i(arg + (int64_t)g * ldo + k) : make_int4(-1, -1, -1, -1);
-            r.y[i] = v ? ld4(Y + mi * ldy + k) : kZero4;
+            const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+            r.go[i] = ld4(v ? dZp + (int64_t)g * ldo + k : zp);           // invalid: dZp = 0 -> dz = 0 whatever arg says
+            r.a[i] = ld4i(v ? arg + (int64_t)g * ldo + k : reinterpret_cast<const int32_t *>(pn2_zero_page));
+            r.y[i] = ld4(v ? Y + mi * ldy + k : zp);
         }
     }
     __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid); }
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int n = n0 + lrow + i * RPL;
-            qb[i] = (n < N && kvalid) ? ld4(Bw + (int64_t)n * ldb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qb[i] = ld4((n < N && kvalid) ? Bw + (int64_t)n * ldb + k : reinterpret_cast<const float *>(pn2_zero_page));
         }
     };
 
@@ -497,6 +504,8 @@ int dispatch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N,
     // 128x128x32 at two per CU (+10..17 %, tools/bench_kernels.py).  Loaders with a large in-flight register set
     // (two or three tensors per operand row) get a 168-VGPR budget (3 per CU) instead of 128 (4 per CU): no spills.
     if (cfg == 3) return launch_nt<64, 128, 16, 2, 2, 3, 2>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (cfg == 5) return launch_nt<64, 128, 16, 2, 2, 3, 3>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (cfg == 6) return launch_nt<64, 128, 16, 2, 2, 2, 4>(aload, Bw, ldb, P, K4, N, epi, s);
     if (cfg == 4) return launch_nt<64, 128, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     if (ALoad::kRegs >= 8 || cfg == 2) return launch_nt<64, 128, 16, 2, 2, 3, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     return launch_nt<64, 128, 16, 2, 2, 4, 1>(aload, Bw, ldb, P, K4, N, epi, s);
@@ -589,7 +598,11 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#ifdef PN2_X_NOWATOMIC
+                if (m < M && n < N && acc[i][j][r] == 123456.f) dW[(int64_t)m * lddw + n] = 1.f;
+#else
                 if (m < M && n < N) atomicAdd(dW + (int64_t)m * lddw + n, acc[i][j][r]);
+#endif
             }
         }
     if (dbias != nullptr && blockIdx.y == 0) {
