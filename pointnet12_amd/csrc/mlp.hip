@@ -605,11 +605,22 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
 #endif
             }
         }
-    if (dbias != nullptr && blockIdx.y == 0) {
-        if (m0 + acq < M) atomicAdd(dbias + m0 + acq, bsum.x);
-        if (m0 + acq + 1 < M) atomicAdd(dbias + m0 + acq + 1, bsum.y);
-        if (m0 + acq + 2 < M) atomicAdd(dbias + m0 + acq + 2, bsum.z);
-        if (m0 + acq + 3 < M) atomicAdd(dbias + m0 + acq + 3, bsum.w);
+    if (dbias != nullptr && blockIdx.y == 0) {      // combine the AR row-threads of each column group in LDS: one atomic per channel
+        __syncthreads();
+        float *sh = As[0];
+        *reinterpret_cast<float4 *>(&sh[t * 4]) = bsum;
+        __syncthreads();
+        if (arow == 0) {
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < AR; ++r) {
+                const float4 v = *reinterpret_cast<const float4 *>(&sh[(r * (BM / 4) + t) * 4]);
+                tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+            }
+            if (m0 + acq < M) atomicAdd(dbias + m0 + acq, tot.x);
+            if (m0 + acq + 1 < M) atomicAdd(dbias + m0 + acq + 1, tot.y);
+            if (m0 + acq + 2 < M) atomicAdd(dbias + m0 + acq + 2, tot.z);
+            if (m0 + acq + 3 < M) atomicAdd(dbias + m0 + acq + 3, tot.w);
+        }
     }
 }
 

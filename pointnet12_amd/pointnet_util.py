@@ -355,9 +355,12 @@ class _SharedMLP(torch.autograd.Function):
             gS, gK = g_idx.shape[1], g_idx.shape[2]
             P = gB * gS * gK
         chans = [c_in] + [flat[7 * l].shape[0] for l in range(L)]
-        stats = torch.zeros(_REPL * 2 * sum(chans[1:]), device=dev, dtype=torch.float64) if training else None
+        n_stats = _REPL * 2 * sum(chans[1:]) if training else 0
+        n_aff = 4 * sum(_r4(c) for c in chans[1:])
+        zero_bytes = torch.zeros(8 * n_stats + 4 * n_aff, device=dev, dtype=torch.uint8)     # one memset for both
+        stats = zero_bytes[:8 * n_stats].view(torch.float64) if training else None
         Ys, affs, Wps = [], [], []
-        aff_all = torch.zeros(4 * sum(_r4(c) for c in chans[1:]), device=dev, dtype=torch.float32)
+        aff_all = zero_bytes[8 * n_stats:].view(torch.float32)
         aff_off = 0
         x, ldx, x_aff, off = rows, rows.shape[-1], None, 0
         for l in range(L):
@@ -432,7 +435,11 @@ class _SharedMLP(torch.autograd.Function):
             g[:, :cl] = grad_out
             grad_out = g
         grad_out = grad_out.contiguous()
-        red = torch.zeros(_REPL * 2 * sum(chans[1:]), device=dev, dtype=torch.float64)
+        n_red = _REPL * 2 * sum(chans[1:])
+        direct = _direct_ok([ctx.params[7 * l + j] for l in range(L) for j in (0, 2, 3)])
+        sizes = [4 * _r4(chans[l + 1]) + (0 if direct else chans[l + 1] * chans[l] + chans[l + 1]) for l in range(L)]
+        zero_bytes = torch.zeros(8 * n_red + 4 * sum(sizes), device=dev, dtype=torch.uint8)   # one memset per backward
+        red = zero_bytes[:8 * n_red].view(torch.float64)
         offs = np.cumsum([0] + [_REPL * 2 * c for c in chans[1:]])
         K = pool if pool else 1
         G = P // K
@@ -450,10 +457,8 @@ class _SharedMLP(torch.autograd.Function):
         grads = [None] * (7 * L)
         d_rows = None
         flat = ctx.params
-        direct = _direct_ok([flat[7 * l + j] for l in range(L) for j in (0, 2, 3)])
-        # one zeroed scratch buffer per call: BN-backward coefficient blocks (+ the gradient tensors in autograd mode)
-        sizes = [4 * _r4(chans[l + 1]) + (0 if direct else chans[l + 1] * chans[l] + chans[l + 1]) for l in range(L)]
-        zbuf = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        # zeroed scratch: BN-backward coefficient blocks (+ the gradient tensors in autograd mode)
+        zbuf = zero_bytes[8 * n_red:].view(torch.float32)
         zoff = np.cumsum([0] + sizes)
         for l in range(L - 1, -1, -1):
             co, ci = chans[l + 1], chans[l]
@@ -566,6 +571,67 @@ class _SharedMLP(torch.autograd.Function):
                                          _p(dF), ldd, None, B * N, co, D, st), "pn2_conv1x1_dgrad")
             d_feats = (dF[:, :D] if ldd != D else dF).reshape(B, N, D)
         return d_feats, (dW.view_as(w) if w_grad is None else None)
+
+
+class _Conv1x1(torch.autograd.Function):
+    """Plain per-point linear layer on position-major rows (no BatchNorm): y = x W^T + b.
+
+    The 128 -> num_classes classifier of the segmentation heads (reference model/pointnet2.py:174); a skinny GEMM
+    (N = 13) that the vendor library runs at 0.11 ms -- the same fp32-MFMA NT/TN cores do it in ~15 us.
+    Backward reuses pn2_conv1x1_dgrad / pn2_conv1x1_wgrad with identity BN coefficients."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias):
+        lib, st = _lib.load(), _lib.stream()
+        P, ldx = rows.shape
+        co = weight.shape[0]
+        ci = weight.numel() // co
+        w = weight.detach().reshape(co, ci)
+        if ldx != ci:
+            w = torch.nn.functional.pad(w, (0, ldx - ci))
+        w = w.contiguous()
+        y = _empty_rows(P, co, rows.device)
+        _check(lib.pn2_conv1x1_fwd(_p(rows), ldx, None, _p(w), ldx, _p(bias), _p(y), y.shape[1], P, ci, co, None, st),
+               "pn2_conv1x1_fwd")
+        ctx.save_for_backward(rows, weight)
+        ctx.dims = (P, ci, co, ldx, y.shape[1])
+        return y[:, :co] if y.shape[1] != co else y
+
+    @staticmethod
+    def backward(ctx, grad):
+        lib, st = _lib.load(), _lib.stream()
+        rows, weight = ctx.saved_tensors
+        P, ci, co, ldx, ldy = ctx.dims
+        dev = rows.device
+        if ldy != co:
+            g = torch.zeros(P, ldy, device=dev, dtype=torch.float32)
+            g[:, :co] = grad
+        else:
+            g = grad.contiguous()
+        zb = torch.zeros(4 * ldy + co * ci + co, device=dev, dtype=torch.float32)
+        ident = zb[:4 * ldy]
+        ident[:co] = 1.0                                   # dY := 1*g + 0*(y - 0) + 0
+        dW = zb[4 * ldy:4 * ldy + co * ci].view(co, ci)
+        db = zb[4 * ldy + co * ci:]
+        _check(lib.pn2_conv1x1_wgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(rows), ldx, None, _p(dW), ci,
+                                     _p(db), P, co, ci, st), "pn2_conv1x1_wgrad")
+        d_rows = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().reshape(co, ci).t()
+            if ldy != co:
+                wt = torch.nn.functional.pad(wt, (0, ldy - co))
+            wt = wt.contiguous()
+            d_rows = torch.zeros(P, ldx, device=dev, dtype=torch.float32) if ldx != ci else \
+                torch.empty(P, ldx, device=dev, dtype=torch.float32)
+            _check(lib.pn2_conv1x1_dgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(wt), ldy, None, 0, None,
+                                         _p(d_rows), ldx, None, P, co, ci, st), "pn2_conv1x1_dgrad")
+        return d_rows, dW.view_as(weight), db
+
+
+def conv1x1(rows, conv):
+    """rows [P, round4(C_in)] -> [P, C_out] through ``conv`` (an nn.Conv1d/Conv2d with kernel size 1), HIP kernels."""
+    rows = _gpu_f32(rows, "rows")
+    return _Conv1x1.apply(rows, conv.weight, conv.bias)
 
 
 def _flat_params(convs, bns):
