@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
     constexpr int LDP = BK + 4;                      // LDS row pitch: 16 consecutive rows cover all 64 banks once
     constexpr int TPR = BK / 4;                      // loader threads per row segment
     constexpr int RPL = NTHREADS / TPR;              // rows per loader pass
-    constexpr int A_IT = BM / RPL, B_IT = BN / RPL;
+    constexpr int A_IT = BM / RPL, B_IT = (BN + RPL - 1) / RPL;   // BN = 96: the last B pass is half live
     constexpr int CG = BN / 4;                       // float4 column groups of the output tile
     constexpr int RPP = NTHREADS / CG;               // rows per epilogue pass
     constexpr int LDC = BN + 4;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int n = n0 + lrow + i * RPL;
-            qb[i] = ld4((n < N && kvalid) ? Bw + (int64_t)n * ldb + k : reinterpret_cast<const float *>(pn2_zero_page));
+            qb[i] = ld4((n < N && kvalid && lrow + i * RPL < BN) ? Bw + (int64_t)n * ldb + k : reinterpret_cast<const float *>(pn2_zero_page));
         }
     };
 
@@ -386,7 +386,8 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
                 *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) =
                     aload.template finish<A_IT>(ra[d], i, kv && (m0 + lrow + i * RPL < P), ap);
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) *reinterpret_cast<float4 *>(&Bb[(lrow + i * RPL) * LDP + lkq]) = rb[d][i];
+            for (int i = 0; i < B_IT; ++i)
+                if (BN % RPL == 0 || lrow + i * RPL < BN) *reinterpret_cast<float4 *>(&Bb[(lrow + i * RPL) * LDP + lkq]) = rb[d][i];
             fetch(ra[d], rb[d], ptile, pks);
             if (++pks == nk) { pks = 0; ptile += gridDim.x; }
             STAMP(0)
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
             STAMP(4)
             __syncthreads();
             STAMP(5)
-            if (en < ((N + 3) & ~3)) {
+            if (en < ((N + 3) & ~3) && erow < RPP) {        // (NTHREADS % CG) threads have no row when BN = 96
                 float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
 #pragma unroll 4
                 for (int r = erow; r < BM; r += RPP) {
@@ -499,6 +500,11 @@ int dispatch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N,
     static const int cfg = pn2_env_int("PN2_NT_CFG", 0);     // tuning hook (tools/bench_kernels.py)
     if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+    // 65..96 output channels (64->96, 128->96 in MSG sa1): an exact 96-wide tile instead of 25 % padding MFMAs
+    if (N <= 96 && cfg != 9) {
+        if (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);   // no spills
+        return launch_nt<128, 96, 16, 4, 1, 3, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+    }
     if (cfg == 1) return launch_nt<128, 128, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
     // 64x128 tiles, 16-deep k-steps: more, smaller workgroups per CU hide the operand stream's latency better than
     // 128x128x32 at two per CU (+10..17 %, tools/bench_kernels.py).  Loaders with a large in-flight register set
