@@ -238,11 +238,19 @@ def main():
     roofline = None
     kernels = None
     if rank == 0 and not args.no_roofline:
-        # instrumented pass: HIP events around every C-ABI launch, on the stream the kernels run on
+        # instrumented pass: HIP events around every C-ABI launch, on the stream the kernel runs on.  The launches
+        # are issued one after the other here (no parallel MSG scale streams), so a launch's duration
+        # is its own and not that of whatever shared the chip with it in the timed, overlapped step above.
+        from pointnet12_amd import pointnet_util as _pu
         prof_steps = 3
+        _saved_streams = _pu.MSG_SCALE_STREAMS
+        _pu.MSG_SCALE_STREAMS = False
         with _lib.call_profile() as calls:           # eager launches: every C-ABI call bracketed by HIP events
-            for _ in range(prof_steps):
-                compute()
+            try:
+                for _ in range(prof_steps):
+                    compute()
+            finally:
+                _pu.MSG_SCALE_STREAMS = _saved_streams
             torch.cuda.synchronize()
             agg = {}
             ncall = len(calls) // prof_steps

@@ -152,7 +152,8 @@ int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, c
                     int64_t *num_batches_tracked, float *affine, pn2_stream_t stream);
 
 /* out[g,c] = max_k relu(bn(Y[g*K+k, c])), arg[g,c] = first k attaining it (K = 1: plain
- * BN+ReLU, arg may be NULL).  Y pitch ldy, out pitch ldo. */
+ * BN+ReLU, arg may be NULL).  Y pitch ldy, out / arg pitch ldo: both multiples of 4 and >= round4(C)
+ * (rows are moved as float4; the pad columns of out / arg are written too, from the zero pad of `affine`). */
 int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int K, int C, float *out, int ldo,
                     int32_t *arg, pn2_stream_t stream);
 

@@ -63,7 +63,7 @@ _profile = None          # None, or a list receiving (name, args, start_event, e
 
 class _Timed:
     """Proxy handed out while a call profile is active: brackets every launch with HIP events recorded on
-    the stream the kernel is launched on (torch's current stream, passed as the last argument)."""
+    the stream the kernel is launched on (the handle passed as the last argument of every launch entry point)."""
 
     def __getattr__(self, name):
         fn = getattr(_raw, name)
@@ -73,9 +73,11 @@ class _Timed:
         def timed(*args):
             import torch
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+            h = args[-1]
+            s = torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream()
+            a.record(s)
             rc = fn(*args)
-            b.record()
+            b.record(s)
             _profile.append((name, args, a, b))
             return rc
         return timed

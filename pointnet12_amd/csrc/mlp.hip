@@ -698,24 +698,66 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, double inv_
 }
 
 // out[g,c] = max_k relu(bn(Y[g*K+k,c])); arg = first k attaining it.
+// One wave per group.  A lane owns one float4 column group; LPR (a power of two) lanes cover a row, so one
+// wave-wide load instruction fetches 64/LPR consecutive rows of 16 B per lane (1 KiB per instruction, whole
+// 64 B segments per row).  Each lane keeps the running (max, first k) of its rows -- it visits k in ascending
+// order, so a strict `>` keeps the first -- and the 64/LPR row-lanes of a column are folded with xor-shuffles
+// (greater value, or equal value and smaller k).  K == 1 (FeaturePropagation outputs: BN + ReLU only) maps
+// the row-lanes to consecutive groups instead.
+template <bool kPooled>
 __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restrict__ Y, int ldy,
                                                           const float *__restrict__ aff, int lda, int64_t G, int K,
-                                                          int C, float *__restrict__ out, int ldo,
+                                                          int lpr_log2, float *__restrict__ out, int ldo,
                                                           int32_t *__restrict__ arg) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int64_t g = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (c >= C || g >= G) return;
+    const int lane = threadIdx.x & 63;
+    const int LPR = 1 << lpr_log2, RPW = 64 >> lpr_log2;
+    const int cq = (blockIdx.x * LPR + (lane & (LPR - 1))) * 4;      // first of this lane's four channels
+    const int rsub = lane >> lpr_log2;
+    const int64_t w = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);  // wave index
+    const bool colv = cq < lda;
     Affine a(aff, lda);
-    const float mu = a.mean[c], sc = a.scale[c], be = a.beta[c];
-    const float *y = Y + g * K * ldy + c;
-    float best = -INFINITY;
-    int bk = 0;
-    for (int k = 0; k < K; ++k) {
-        float v = fmaxf(bn_act(y[(int64_t)k * ldy], mu, sc, be), 0.f);
-        if (v > best) { best = v; bk = k; }
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
+    if (colv) { mu = ld4(a.mean + cq); sc = ld4(a.scale + cq); be = ld4(a.beta + cq); }
+    if (!kPooled) {                               // K == 1: RPW groups per wave, no reduction
+        const int64_t g = w * RPW + rsub;
+        if (!colv || g >= G) return;
+        const float4 y = ld4(Y + g * ldy + cq);
+        float4 o;
+        o.x = fmaxf(bn_act(y.x, mu.x, sc.x, be.x), 0.f);
+        o.y = fmaxf(bn_act(y.y, mu.y, sc.y, be.y), 0.f);
+        o.z = fmaxf(bn_act(y.z, mu.z, sc.z, be.z), 0.f);
+        o.w = fmaxf(bn_act(y.w, mu.w, sc.w, be.w), 0.f);
+        *reinterpret_cast<float4 *>(out + g * ldo + cq) = o;
+        if (arg) *reinterpret_cast<int4 *>(arg + g * ldo + cq) = make_int4(0, 0, 0, 0);
+        return;
     }
-    out[g * ldo + c] = best;
-    if (arg) arg[g * ldo + c] = bk;
+    if (w >= G) return;                           // wave-uniform
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bk[4] = {0, 0, 0, 0};
+    if (colv) {
+        const float *y = Y + w * K * ldy + cq;
+#pragma unroll 4
+        for (int k = rsub; k < K; k += RPW) {
+            const float4 v = ld4(y + (int64_t)k * ldy);
+            const float o[4] = {fmaxf(bn_act(v.x, mu.x, sc.x, be.x), 0.f), fmaxf(bn_act(v.y, mu.y, sc.y, be.y), 0.f),
+                                fmaxf(bn_act(v.z, mu.z, sc.z, be.z), 0.f), fmaxf(bn_act(v.w, mu.w, sc.w, be.w), 0.f)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (o[e] > best[e]) { best[e] = o[e]; bk[e] = k; }
+        }
+    }
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ov = __shfl_xor(best[e], off, 64);
+            const int ok = __shfl_xor(bk[e], off, 64);
+            if (ov > best[e] || (ov == best[e] && ok < bk[e])) { best[e] = ov; bk[e] = ok; }
+        }
+    }
+    if (colv && rsub == 0) {
+        *reinterpret_cast<float4 *>(out + w * ldo + cq) = make_float4(best[0], best[1], best[2], best[3]);
+        if (arg) *reinterpret_cast<int4 *>(arg + w * ldo + cq) = make_int4(bk[0], bk[1], bk[2], bk[3]);
+    }
 }
 
 // red[c] += sum_g dZ, red[C+c] += sum_g dZ*yhat at the pooled positions.
@@ -843,24 +885,28 @@ int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, c
 
 int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int K, int C, float *out, int ldo,
                     int32_t *arg, pn2_stream_t stream) {
-    PN2_CHECK_ARG(Y && affine && out && G > 0 && K > 0 && C > 0 && ldy >= C && ldo >= C);
-    int64_t gy = pn2_cdiv(G, 4);
-    PN2_CHECK_ARG(gy <= 0x7fffffff);
-    // grid.y is limited to 65535: fold the group index into x-major order when needed
-    if (gy > 65535) {
-        // split into slabs of 65535*4 groups
-        int64_t done = 0;
-        while (done < G) {
-            int64_t take = G - done < 65535LL * 4 ? G - done : 65535LL * 4;
-            hipLaunchKernelGGL(bn_relu_max_kernel, dim3((unsigned)pn2_cdiv(C, 64), (unsigned)pn2_cdiv(take, 4)), dim3(256), 0,
-                               pn2_s(stream), Y + done * K * ldy, ldy, affine, (C + 3) & ~3, take, K, C, out + done * ldo, ldo,
-                               arg ? arg + done * ldo : nullptr);
-            done += take;
-        }
-        return pn2_launch_status();
+    PN2_CHECK_ARG(Y && affine && out && G > 0 && K > 0 && C > 0);
+    const int ld = (C + 3) & ~3;
+    PN2_CHECK_ARG(ldy % 4 == 0 && ldo % 4 == 0 && ldy >= ld && ldo >= ld);      // float4 rows; pad columns are written (0)
+    const int cg = ld / 4;
+    int lpr_log2 = 0;
+    while ((1 << lpr_log2) < cg && lpr_log2 < 6) ++lpr_log2;
+    const int rpw = 64 >> lpr_log2;
+    const unsigned gx = (unsigned)pn2_cdiv(cg, 1 << lpr_log2);
+    const int64_t waves = K == 1 ? pn2_cdiv(G, rpw) : G;
+    // grid.y is limited to 65535 blocks of four waves: issue slabs
+    const int64_t slab = 65535LL * 4;
+    for (int64_t done = 0; done < waves; done += slab) {
+        const int64_t take = waves - done < slab ? waves - done : slab;
+        const int64_t g0 = K == 1 ? done * rpw : done;
+        const dim3 grid(gx, (unsigned)pn2_cdiv(take, 4));
+        if (K == 1)
+            hipLaunchKernelGGL(bn_relu_max_kernel<false>, grid, dim3(256), 0, pn2_s(stream), Y + g0 * ldy, ldy, affine, ld,
+                               G - g0, K, lpr_log2, out + g0 * ldo, ldo, arg ? arg + g0 * ldo : nullptr);
+        else
+            hipLaunchKernelGGL(bn_relu_max_kernel<true>, grid, dim3(256), 0, pn2_s(stream), Y + g0 * K * ldy, ldy, affine, ld,
+                               G - g0, K, lpr_log2, out + g0 * ldo, ldo, arg ? arg + g0 * ldo : nullptr);
     }
-    hipLaunchKernelGGL(bn_relu_max_kernel, dim3((unsigned)pn2_cdiv(C, 64), (unsigned)gy), dim3(256), 0, pn2_s(stream), Y, ldy,
-                       affine, (C + 3) & ~3, G, K, C, out, ldo, arg);
     return pn2_launch_status();
 }
 
