@@ -86,7 +86,7 @@ def build_net(workload, dev, npoint_scale=1):
 
 
 def make_step(workload, net, pts, labels, bucket):
-    import torch.nn.functional as F
+    from pointnet12_amd.loss import nll_loss      # F.nll_loss (semseg.py:143) on the HIP library
 
     def step():
         bucket.zero()
@@ -95,7 +95,7 @@ def make_step(workload, net, pts, labels, bucket):
             loss = feat.sum()
         else:
             lp = net(pts)
-            loss = F.nll_loss(lp.reshape(-1, lp.shape[-1]), labels.reshape(-1))
+            loss = nll_loss(lp.reshape(-1, lp.shape[-1]), labels.reshape(-1))
         loss.backward()
         return loss
     return step

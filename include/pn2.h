@@ -192,6 +192,23 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       pn2_stream_t stream);
 
+/* ---- the loss either side of the path ---------------------------------------
+ * Replaces F.nll_loss(pred, target) of semseg.py:143 (weight == NULL) and the class-weighted form of
+ * pcdseg.py:179, reduction "mean":
+ *     loss = - sum_r w[t_r] * logp[r, t_r] / sum_r w[t_r]     over rows with t_r != ignore_index.
+ * logp [R, ld >= C] log-probabilities, target int64[R].  A target outside [0, C) that is not ignore_index
+ * turns the loss NaN (ATen raises a device assert).  workspace: pn2_nll_loss_workspace_bytes(R) bytes,
+ * zeroed ONCE by the caller (the kernel leaves it reusable); do not share it between concurrent launches.
+ * Outputs: *loss and *denom (= sum of the weights, kept for the backward).  The partial sums are fp64 and
+ * combined in a fixed order: the result does not depend on scheduling. */
+int64_t pn2_nll_loss_workspace_bytes(int64_t R);
+int pn2_nll_loss_fwd(const float *logp, int ld, const int64_t *target, const float *weight, int64_t R, int C,
+                     int64_t ignore_index, void *workspace, float *loss, float *denom, pn2_stream_t stream);
+/* dlogp[r, c] = -(*grad_loss) * w[t_r] / (*denom) at c == t_r (and t_r != ignore_index), 0 elsewhere;
+ * every element of dlogp [R, ld] is written. */
+int pn2_nll_loss_bwd(const int64_t *target, const float *weight, int64_t R, int C, int64_t ignore_index,
+                     const float *grad_loss, const float *denom, float *dlogp, int ld, pn2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

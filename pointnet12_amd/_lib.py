@@ -41,6 +41,9 @@ SIGNATURES = {
                                _i64, _i, _i, _vp]),
     "pn2_conv1x1_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
                                _i64, _i, _i, _vp]),
+    "pn2_nll_loss_workspace_bytes": (_i64, [_i64]),
+    "pn2_nll_loss_fwd": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp]),
+    "pn2_nll_loss_bwd": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp]),
 }
 
 
@@ -67,7 +70,8 @@ class _Timed:
 
     def __getattr__(self, name):
         fn = getattr(_raw, name)
-        if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes"):
+        if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes",
+                                                   "pn2_nll_loss_workspace_bytes"):
             return fn
 
         def timed(*args):

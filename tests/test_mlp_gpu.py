@@ -109,3 +109,37 @@ def test_eval_mode_with_grad(dev):
     gb = torch.autograd.grad((ref * gw).sum(), [x] + list(convs.parameters()))
     for a, b in zip(ga, gb):
         assert float((a - b).abs().max()) <= 3e-5 * max(float(b.abs().max()), 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C,weighted,ignored", [(65536, 13, False, False), (1000, 19, True, True), (7, 5, False, True),
+                                                  (300001, 50, True, False)])
+def test_nll_loss_matches_aten(dev, R, C, weighted, ignored):
+    """pn2_nll_loss_fwd/bwd against F.nll_loss (reference semseg.py:143, pcdseg.py:179) in fp64 on the CPU."""
+    from pointnet12_amd.loss import nll_loss
+    g = torch.Generator().manual_seed(R + C)
+    lp = torch.log_softmax(torch.randn(R, C, generator=g) * 3, dim=-1)
+    tgt = torch.randint(0, C, (R,), generator=g)
+    if ignored:
+        tgt[::3] = -100
+    w = (torch.rand(C, generator=g) + 0.5) if weighted else None
+    ref_in = lp.double().requires_grad_(True)
+    ref = F.nll_loss(ref_in, tgt, weight=None if w is None else w.double())
+    ref.backward()
+    mine_in = lp.to(dev).requires_grad_(True)
+    mine = nll_loss(mine_in, tgt.to(dev), weight=None if w is None else w.to(dev))
+    (mine * 1.0).backward()
+    assert abs(float(mine) - float(ref)) <= 2e-6 * abs(float(ref))          # fp32 products, fp64 sums
+    dref = ref_in.grad.float().numpy()
+    assert np.abs(mine_in.grad.cpu().numpy() - dref).max() <= 1e-6 * np.abs(dref).max()
+    # twice in a row on one stream: the ticket in the workspace resets itself
+    again = nll_loss(lp.to(dev), tgt.to(dev), weight=None if w is None else w.to(dev))
+    assert float(again) == float(mine)
+
+
+@pytest.mark.gpu
+def test_nll_loss_all_ignored_is_nan(dev):
+    from pointnet12_amd.loss import nll_loss
+    lp = torch.log_softmax(torch.randn(64, 4), dim=-1).to(dev)
+    assert np.isnan(float(nll_loss(lp, torch.full((64,), -100))))
+    assert np.isnan(float(F.nll_loss(lp.cpu(), torch.full((64,), -100))))
