@@ -105,32 +105,52 @@ class GraphedStep:
         finally:
             U.set_geometry_tape(None)
         torch.cuda.synchronize(device)
-        self.cur = cur
-        self.feed = FpsStartFeed(device)
-        self.graph = torch.cuda.CUDAGraph()
-        nxt = U.GeometryTape()
-        geo_stream = torch.cuda.Stream(device=device)
-        U.set_fps_start_feed(self.feed)
-        try:
-            with torch.cuda.graph(self.graph):
-                main = torch.cuda.current_stream(device)
-                geo_stream.wait_stream(main)
-                with torch.cuda.stream(geo_stream):            # branch 2: next batch's geometry
-                    U.set_geometry_tape(nxt)
-                    with torch.no_grad():
-                        geometry_fn()
-                cur.rewind("replay")                           # branch 1: this batch on the recorded geometry
-                U.set_geometry_tape(cur)
-                self.loss = fn()
+        # Two graphs, replayed alternately, double-buffer the geometry: graph A runs the step on tape T0 while its
+        # side branch records the next batch's geometry into T1; graph B runs on T1 and records into T0's tensors.
+        # (A single graph has to copy the prefetched tape over the replayed one at the very end of the step --
+        # 13 small copies that sit on the critical tail of the main stream, ~0.1 ms.)
+        self.graphs, self.feeds, self.losses = [], [], []
+        self.parity = 0
+        tapes = [cur, None]
+        pool = None
+        for which in (0, 1):
+            feed = FpsStartFeed(device)
+            graph = torch.cuda.CUDAGraph()
+            read = tapes[which]
+            write = U.GeometryTape() if which == 0 else U.GeometryTape(into=tapes[0].items)
+            geo_stream = torch.cuda.Stream(device=device)
+            U.set_fps_start_feed(feed)
+            try:
+                with torch.cuda.graph(graph, pool=pool):
+                    main = torch.cuda.current_stream(device)
+                    geo_stream.wait_stream(main)
+                    with torch.cuda.stream(geo_stream):            # branch 2: next batch's geometry
+                        U.set_geometry_tape(write)
+                        with torch.no_grad():
+                            geometry_fn()
+                    read.rewind("replay")                          # branch 1: this batch on the recorded geometry
+                    U.set_geometry_tape(read)
+                    loss = fn()
+                    U.set_geometry_tape(None)
+                    main.wait_stream(geo_stream)
+            finally:
                 U.set_geometry_tape(None)
-                main.wait_stream(geo_stream)
-                for dst, src in zip(_flatten(cur.items), _flatten(nxt.items)):
-                    dst.copy_(src)                             # hand the prefetched geometry to the next replay
-        finally:
-            U.set_geometry_tape(None)
-            U.set_fps_start_feed(None)
+                U.set_fps_start_feed(None)
+            if which == 0:
+                tapes[1] = write
+                pool = graph.pool()
+            self.graphs.append(graph)
+            self.feeds.append(feed)
+            self.losses.append(loss)
+        self.graph, self.feed, self.loss = self.graphs[0], self.feeds[0], self.losses[0]
 
     def __call__(self):
+        if getattr(self, "graphs", None):
+            i = self.parity
+            self.parity ^= 1
+            self.feeds[i].stage()
+            self.graphs[i].replay()
+            return self.losses[i]
         self.feed.stage()
         self.graph.replay()
         return self.loss

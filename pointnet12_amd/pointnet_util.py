@@ -144,10 +144,11 @@ class GeometryTape:
     geometry, append the results here and skip all feature work (they return uninitialised placeholders of the
     right shape).  ``replay`` mode: the primitives hand back the recorded tensors in the same call order."""
 
-    def __init__(self):
+    def __init__(self, into=None):
         self.items = []
         self.pos = 0
         self.mode = "record"
+        self.into = into           # record mode: existing items (same call order / shapes) to overwrite instead
 
     def rewind(self, mode):
         self.pos = 0
@@ -171,6 +172,11 @@ def _taped(compute):
         return compute()
     if _tape.mode == "record":
         v = compute()
+        if _tape.into is not None:            # land the result in the tensors another graph replays from
+            dst = _tape.into[len(_tape.items)]
+            for d, x in zip(dst if isinstance(dst, tuple) else (dst,), v if isinstance(v, tuple) else (v,)):
+                d.copy_(x)
+            v = dst
         _tape.items.append(v)
         return v
     v = _tape.items[_tape.pos]
