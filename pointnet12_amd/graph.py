@@ -81,10 +81,12 @@ class GraphedStep:
         self.feed = FpsStartFeed(device)
         self.graph = torch.cuda.CUDAGraph()
         U.set_fps_start_feed(self.feed)
+        U.set_capture_scope(object())
         try:
             with torch.cuda.graph(self.graph):
                 self.loss = fn()
         finally:
+            U.set_capture_scope(None)
             U.set_fps_start_feed(None)
 
     def _init_prefetch(self, fn, geometry_fn, device, warmup):
@@ -120,6 +122,7 @@ class GraphedStep:
             write = U.GeometryTape() if which == 0 else U.GeometryTape(into=tapes[0].items)
             geo_stream = torch.cuda.Stream(device=device)
             U.set_fps_start_feed(feed)
+            U.set_capture_scope(object())
             try:
                 with torch.cuda.graph(graph, pool=pool):
                     main = torch.cuda.current_stream(device)
@@ -134,6 +137,7 @@ class GraphedStep:
                     U.set_geometry_tape(None)
                     main.wait_stream(geo_stream)
             finally:
+                U.set_capture_scope(None)
                 U.set_geometry_tape(None)
                 U.set_fps_start_feed(None)
             if which == 0:

@@ -58,6 +58,60 @@ def _empty_rows(rows, cols, device):
     return torch.zeros(rows, ld, device=device, dtype=torch.float32)
 
 
+# Small zero-initialised scratch (BN statistics, reduction buffers, coefficient blocks, weight-gradient tiles) is
+# carved from per-stream chunks that are cleared by ONE memset each, instead of one fill kernel per buffer: a step of
+# MSG-SemSeg issued ~50 such fills, every one a ~5 us hop on the dependency chain of a stream (the fixed cost of a
+# step is ~2 ms, measured by sweeping the batch size, and is made of exactly these hops).  A piece is handed out
+# once; the chunk's storage is released when the last view dies.  Under stream capture the arena is only used
+# inside a capture scope announced by pointnet12_amd.graph (a chunk allocated in one capture must not leak into
+# another graph or into eager code: its memset is part of that graph only).
+_ZERO_CHUNK_BYTES = 4 << 20
+_zero_arenas = {}
+_capture_scope = None
+
+
+def set_capture_scope(token):
+    """graph.GraphedStep brackets every stream capture with set_capture_scope(object()) / set_capture_scope(None)."""
+    global _capture_scope
+    _capture_scope = token
+    for k in [k for k in _zero_arenas if k[2] is not None]:
+        del _zero_arenas[k]
+
+
+def _zeros_small(nbytes, device):
+    """uint8[nbytes], zero, 256-byte aligned."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    if nbytes > _ZERO_CHUNK_BYTES // 4 or (capturing and _capture_scope is None):
+        return torch.zeros(nbytes, device=device, dtype=torch.uint8)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, _capture_scope if capturing else None)
+    a = _zero_arenas.get(key)
+    if a is None or a[1] + nbytes > _ZERO_CHUNK_BYTES:
+        a = _zero_arenas[key] = [torch.zeros(_ZERO_CHUNK_BYTES, device=device, dtype=torch.uint8), 0]
+    off = a[1]
+    a[1] = off + ((nbytes + 255) & ~255)
+    return a[0][off:off + nbytes]
+
+
+_ident_cache = {}
+
+
+def _ident_coef(co, device):
+    """BN-backward coefficient block of the identity, dY := 1*dZ + 0*(y - 0) + 0 (float[4*round4(co)]); constant,
+    created once per (device, co) outside any capture."""
+    key = (device.index, co)
+    t = _ident_cache.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            t = torch.zeros(4 * _r4(co), device=device, dtype=torch.float32)
+            t[:co] = 1.0
+            return t                                   # private to this capture; not cached
+        t = torch.zeros(4 * _r4(co), device=device, dtype=torch.float32)
+        t[:co] = 1.0
+        torch.cuda.current_stream(device).synchronize()    # once per (device, co): later readers may be on any stream
+        _ident_cache[key] = t
+    return t
+
+
 # --------------------------------------------------------------------------------------- primitives
 
 def square_distance(src, dst):
@@ -363,7 +417,7 @@ class _SharedMLP(torch.autograd.Function):
         chans = [c_in] + [flat[7 * l].shape[0] for l in range(L)]
         n_stats = _REPL * 2 * sum(chans[1:]) if training else 0
         n_aff = 4 * sum(_r4(c) for c in chans[1:])
-        zero_bytes = torch.zeros(8 * n_stats + 4 * n_aff, device=dev, dtype=torch.uint8)     # one memset for both
+        zero_bytes = _zeros_small(8 * n_stats + 4 * n_aff, dev)
         stats = zero_bytes[:8 * n_stats].view(torch.float64) if training else None
         Ys, affs, Wps = [], [], []
         aff_all = zero_bytes[8 * n_stats:].view(torch.float32)
@@ -444,7 +498,7 @@ class _SharedMLP(torch.autograd.Function):
         n_red = _REPL * 2 * sum(chans[1:])
         direct = _direct_ok([ctx.params[7 * l + j] for l in range(L) for j in (0, 2, 3)])
         sizes = [4 * _r4(chans[l + 1]) + (0 if direct else chans[l + 1] * chans[l] + chans[l + 1]) for l in range(L)]
-        zero_bytes = torch.zeros(8 * n_red + 4 * sum(sizes), device=dev, dtype=torch.uint8)   # one memset per backward
+        zero_bytes = _zeros_small(8 * n_red + 4 * sum(sizes), dev)
         red = zero_bytes[:8 * n_red].view(torch.float64)
         offs = np.cumsum([0] + [_REPL * 2 * c for c in chans[1:]])
         K = pool if pool else 1
@@ -550,11 +604,9 @@ class _SharedMLP(torch.autograd.Function):
         S, K = g_idx.shape[1], g_idx.shape[2]
         dev = feats.device
         ldc, ldd = _r4(co), _r4(D)
-        zb = torch.zeros(B * N * ldc + 4 * ldc, device=dev, dtype=torch.float32)
-        G = zb[:B * N * ldc].view(B * N, ldc)
-        ident = zb[B * N * ldc:]                      # dY := 1*G + 0*(y-0) + 0
-        ident[:co] = 1.0
-        dW = torch.zeros(co, 3 + D, device=dev, dtype=torch.float32) if w_grad is None else w_grad
+        G = torch.zeros(B * N, ldc, device=dev, dtype=torch.float32)
+        ident = _ident_coef(co, dev)                  # dY := 1*G + 0*(y-0) + 0
+        dW = _zeros_small(4 * co * (3 + D), dev).view(torch.float32).view(co, 3 + D) if w_grad is None else w_grad
         ldw = 3 + D
         x_col, f_col = (0, 3) if g_first else (D, 0)
         _check(lib.pn2_group_affine_bwd(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new), _p(g_idx),
@@ -614,11 +666,10 @@ class _Conv1x1(torch.autograd.Function):
             g[:, :co] = grad
         else:
             g = grad.contiguous()
-        zb = torch.zeros(4 * ldy + co * ci + co, device=dev, dtype=torch.float32)
-        ident = zb[:4 * ldy]
-        ident[:co] = 1.0                                   # dY := 1*g + 0*(y - 0) + 0
-        dW = zb[4 * ldy:4 * ldy + co * ci].view(co, ci)
-        db = zb[4 * ldy + co * ci:]
+        zb = _zeros_small(4 * (co * ci + co), dev).view(torch.float32)
+        ident = _ident_coef(co, dev)                       # dY := 1*g + 0*(y - 0) + 0
+        dW = zb[:co * ci].view(co, ci)
+        db = zb[co * ci:]
         _check(lib.pn2_conv1x1_wgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(rows), ldx, None, _p(dW), ci,
                                      _p(db), P, co, ci, st), "pn2_conv1x1_wgrad")
         d_rows = None
