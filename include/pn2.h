@@ -113,9 +113,10 @@ int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, cons
 
 /* Inverse-distance interpolation, model/pointnet_util.py:301: out[b,n,col0+c] =
  * ((p2[i0,c]*w0 + p2[i1,c]*w1) + p2[i2,c]*w2).  points2 [B,S,D]; out rows of pitch ld
- * (so the result lands directly inside the concatenated FP input, :305). */
+ * (so the result lands directly inside the concatenated FP input, :305).  zero_tail != 0: the columns
+ * col0+D .. ld-1 of every row are cleared as well (the pad lanes of a float4-pitched row; nobody pre-clears it). */
 int pn2_three_interp(const float *points2, const int64_t *idx, const float *weight, int B, int N, int S, int D,
-                     float *out, int ld, int col0, pn2_stream_t stream);
+                     float *out, int ld, int col0, int zero_tail, pn2_stream_t stream);
 /* backward: grad_points2 [B,S,D] += w_k * grad_out[b,n,col0+c] (caller zeroes). */
 int pn2_three_interp_bwd(const float *grad_out, int ld, int col0, const int64_t *idx, const float *weight, int B,
                          int N, int S, int D, float *grad_points2, pn2_stream_t stream);
@@ -162,7 +163,8 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
  * red is double[2*C], caller zeroes. */
 int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
                         const float *affine, int64_t G, int K, int C, float *dZp, double *red, pn2_stream_t stream);
-/* Backward, dense (FP) last layer: dZ = dOut * (out > 0) written to dZ [P, ldz]; same reductions. */
+/* Backward, dense (FP) last layer: dZ = dOut * (out > 0) written to dZ [P, ldz] (its pad columns
+ * C .. round4(C)-1 are written as zeros); same reductions. */
 int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,
                         int64_t P, int C, float *dZ, int ldz, double *red, pn2_stream_t stream);
 

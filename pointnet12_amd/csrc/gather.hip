@@ -85,11 +85,14 @@ __global__ __launch_bounds__(TPB) void group_bwd_kernel(const float *__restrict_
 __global__ __launch_bounds__(TPB) void three_interp_kernel(const float *__restrict__ points2,
                                                            const int64_t *__restrict__ idx,
                                                            const float *__restrict__ w, int N, int S, int D,
-                                                           int64_t total, float *__restrict__ out, int ld, int col0) {
+                                                           int64_t total, float *__restrict__ out, int ld, int col0,
+                                                           int zero_tail) {
     int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (e >= total) return;
     int c = (int)(e % D);
     int64_t r = e / D;            // b*N + n
+    if (zero_tail && c == D - 1)
+        for (int t = col0 + D; t < ld; ++t) out[r * ld + t] = 0.f;
     int64_t b = r / N;
     const int64_t *i3 = idx + r * 3;
     const float *w3 = w + r * 3;
@@ -174,11 +177,11 @@ int pn2_group_bwd(const float *grad_rows, const int64_t *idx, int B, int N, int 
 }
 
 int pn2_three_interp(const float *points2, const int64_t *idx, const float *weight, int B, int N, int S, int D,
-                     float *out, int ld, int col0, pn2_stream_t stream) {
+                     float *out, int ld, int col0, int zero_tail, pn2_stream_t stream) {
     PN2_CHECK_ARG(points2 && idx && weight && out && B > 0 && N > 0 && S > 0 && D > 0 && col0 >= 0 && ld >= col0 + D);
     int64_t total = (int64_t)B * N * D;
     hipLaunchKernelGGL(three_interp_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), points2, idx, weight, N,
-                       S, D, total, out, ld, col0);
+                       S, D, total, out, ld, col0, zero_tail);
     return pn2_launch_status();
 }
 

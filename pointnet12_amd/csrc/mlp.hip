@@ -807,6 +807,9 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
     const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s0 = 0.0, s1 = 0.0;
+    if (c >= C && c < lda) {                          // pad columns of dZ are written too (zero): nobody pre-clears it
+        for (int64_t p = (int64_t)blockIdx.y * 4 + gl; p < P; p += (int64_t)gridDim.y * 4) dZ[p * ldz + c] = 0.f;
+    }
     if (c < C) {
         Affine a(aff, lda);
         const float mu = a.mean[c], is = a.invstd[c];

@@ -51,11 +51,10 @@ def _gpu_f32(t, name):
 
 
 def _empty_rows(rows, cols, device):
-    """[rows, round4(cols)] float32; pad columns (if any) are zero."""
-    ld = _r4(cols)
-    if ld == cols:
-        return torch.empty(rows, ld, device=device, dtype=torch.float32)
-    return torch.zeros(rows, ld, device=device, dtype=torch.float32)
+    """Uninitialised [rows, round4(cols)] float32.  Every kernel that fills such a matrix writes the pad columns
+    too (as zeros: GEMM epilogues, group, three_interp with zero_tail, bn_relu_max, relu_bwd_reduce), so no
+    separate clearing pass is spent on it."""
+    return torch.empty(rows, _r4(cols), device=device, dtype=torch.float32)
 
 
 # Small zero-initialised scratch (BN statistics, reduction buffers, coefficient blocks, weight-gradient tiles) is
@@ -338,7 +337,7 @@ class _InterpCat(torch.autograd.Function):
         lib, st = _lib.load(), _lib.stream()
         if D1:
             _check(lib.pn2_copy_cols(_p(points1), D1, 0, _p(rows), ld, 0, B * N, D1, st), "pn2_copy_cols")
-        _check(lib.pn2_three_interp(_p(points2), _p(idx), _p(w), B, N, S, D2, _p(rows), ld, D1, st), "pn2_three_interp")
+        _check(lib.pn2_three_interp(_p(points2), _p(idx), _p(w), B, N, S, D2, _p(rows), ld, D1, 1, st), "pn2_three_interp")
         ctx.save_for_backward(idx, w)
         ctx.dims = (B, N, S, D1, D2, ld)
         return rows
@@ -559,8 +558,7 @@ class _SharedMLP(torch.autograd.Function):
                 if l > 0:
                     dx = _empty_rows(P, ci, dev)
                 else:
-                    dx = d_rows = torch.zeros(P, ldx, device=dev, dtype=torch.float32) if ldx != ci else \
-                        torch.empty(P, ldx, device=dev, dtype=torch.float32)
+                    dx = d_rows = torch.empty(P, ldx, device=dev, dtype=torch.float32)   # pad lanes written (0) by the GEMM
             # dgrad and wgrad of one layer read the same dZ / Y rows.  Run them back to back on row chunks small
             # enough to stay in the 256 MiB Infinity Cache, so the second kernel's operand stream is served on-die
             # instead of from HBM (both only accumulate: fp64 reductions / fp32 weight gradients).
@@ -678,8 +676,7 @@ class _Conv1x1(torch.autograd.Function):
             if ldy != co:
                 wt = torch.nn.functional.pad(wt, (0, ldy - co))
             wt = wt.contiguous()
-            d_rows = torch.zeros(P, ldx, device=dev, dtype=torch.float32) if ldx != ci else \
-                torch.empty(P, ldx, device=dev, dtype=torch.float32)
+            d_rows = torch.empty(P, ldx, device=dev, dtype=torch.float32)     # pad lanes written (0) by the GEMM
             _check(lib.pn2_conv1x1_dgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(wt), ldy, None, 0, None,
                                          _p(d_rows), ldx, None, P, co, ci, st), "pn2_conv1x1_dgrad")
         return d_rows, dW.view_as(weight), db
