@@ -99,10 +99,11 @@ int pn2_group_bwd(const float *grad_rows, const int64_t *idx, int B, int N, int 
  * model/pointnet_util.py:127-131,:197 / :243-247,:254, for that layer only):
  *   Y[p, c] = Zf[b, idx[p], c] + sum_a Wx[c, a] * (xyz[b, idx[p], a] - new_xyz[b, s, a]),  p = (b, s, k)
  * with Zf [B*N, ldz] = W_f f + bias precomputed per SOURCE point (one small pn2_conv1x1_fwd) and
- * Wx [C, 3] the xyz columns of the layer's weight.  stats as in pn2_conv1x1_fwd (double[2*C], may be NULL). */
+ * Wx [C, 3] (row pitch ldwx >= 3) the xyz columns of the layer's weight -- it may point into the full
+ * [C, 3+D] weight.  stats as in pn2_conv1x1_fwd (double[2*C], may be NULL). */
 int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float *new_xyz, const int64_t *idx,
-                         const float *Wx, int B, int N, int S, int K, int C, float *Y, int ldy, double *stats,
-                         pn2_stream_t stream);
+                         const float *Wx, int ldwx, int B, int N, int S, int K, int C, float *Y, int ldy,
+                         double *stats, pn2_stream_t stream);
 /* backward: dY = c0*dZ + q1*(y-mean) + q0 (coef from pn2_bn_bwd_coef) is scattered to the source points,
  * G[b*N + idx[p], :] += dY[p, :] (G [B*N, ldg], caller zeroes), and dWx[c, a] += dY[p, c] * (xyz - centre)[a]
  * (dWx [C, 3] with row pitch ldwx >= 3 -- it may point at the xyz columns of the full weight gradient --
@@ -137,9 +138,12 @@ int pn2_copy_cols(const float *src, int lds, int scol0, float *dst, int ldd, int
  * and relu((y-mean)*scale+beta) is applied on the fly wherever a pre-BN tensor is consumed.
  */
 
-/* Y[P,N] = act(X)[P,K] * W[N,K]^T + bias.  X has row pitch ldx (>= K, multiple of 4, pad
- * columns zero), W row pitch ldw (>= K, multiple of 4, pad columns zero), Y pitch ldy
- * (multiple of 4).  in_affine: NULL (X is used as is) or the affine block (4*ldx floats) of
+/* Y[P,N] = act(X)[P,K] * W[N,K]^T + bias.  X has row pitch ldx (>= round4(K), multiple of 4, pad
+ * columns zero).  W is the Conv weight [N = C_out, K = C_in] as nn.Conv1d/2d stores it, row pitch
+ * ldw >= K floats: no padding or alignment is required (16-byte aligned rows with K % 4 == 0 are read as
+ * float4, anything else -- a C_in of 9 or 137, or the feature columns sliced out of a [C_out, 3+D]
+ * weight -- with guarded scalar loads).  Y pitch ldy (multiple of 4, >= round4(N); pad lanes are
+ * written as zeros).  in_affine: NULL (X is used as is) or the affine block (4*ldx floats) of
  * the layer that produced X.  stats: NULL or a replicated double[2*N] block (see PN2_STAT_REPLICAS; caller zeroes) receiving
  * sum(y) and sum(y*y) per output channel over the P rows (training-mode BN statistics). */
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias,
@@ -175,14 +179,16 @@ int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const floa
 int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, const float *affine,
                     int use_batch_stats, float *coef, float *dgamma, float *dbeta, int accumulate, pn2_stream_t stream);
 
-/* dgrad: dXact[P,N] = dY[P,K] * Wt[N,K]^T with dY formed on the fly from (dZ or the pooled
- * pair dOut/arg, Y, coef); K = C_l, N = C_{l-1}; Wt = W^T padded to pitch ldw.
+/* dgrad: dXact[P,N] = dY[P,K] * W[K,N] with dY formed on the fly from (dZ or the pooled
+ * pair dOut/arg, Y, coef); K = C_l, N = C_{l-1}.  W is the SAME Conv weight [C_l, C_{l-1}] the forward
+ * read (row pitch ldw >= N, no padding / alignment requirement): the kernel reads it "down the columns",
+ * no transposed copy exists.  dXout pitch ldxo (multiple of 4, >= round4(N); pad lanes written as zeros).
  *   dZ != NULL: dense dZ [P, ldz];  dZ == NULL: pooled form (dZp [G,ldo] from pn2_pool_bwd_reduce, arg, Kpool).
  * Epilogue, prev_Y != NULL: dZprev = dXact * (bn_relu(prev_Y) > 0) -> dXout, and
  *   prev_red (double[2*N], caller zeroes) += sum dZprev, sum dZprev*yhat_prev;
  * prev_Y == NULL (first layer): dXout = dXact. */
 int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg,
-                      int Kpool, const float *Y, int ldy, const float *coef, const float *Wt, int ldw,
+                      int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
                       double *prev_red, int64_t P, int K, int N, pn2_stream_t stream);
 

@@ -19,8 +19,8 @@ __global__ __launch_bounds__(256) void group_affine_fwd_kernel(const float *__re
                                                                const float *__restrict__ xyz,
                                                                const float *__restrict__ new_xyz,
                                                                const int64_t *__restrict__ idx,
-                                                               const float *__restrict__ Wx, int N, int S, int K,
-                                                               int C, int64_t P, float *__restrict__ Y, int ldy,
+                                                               const float *__restrict__ Wx, int ldwx, int N, int S,
+                                                               int K, int C, int64_t P, float *__restrict__ Y, int ldy,
                                                                double *__restrict__ stats) {
     __shared__ double red[256 * 8];
     const int CG = (C + 3) >> 2;                  // float4 column groups per row
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void group_affine_fwd_kernel(const float *__re
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) wx[e][a] = (live && c + e < C) ? Wx[(c + e) * 3 + a] : 0.f;
+        for (int a = 0; a < 3; ++a) wx[e][a] = (live && c + e < C) ? Wx[(c + e) * ldwx + a] : 0.f;
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int since = 0;
@@ -156,16 +156,17 @@ __global__ __launch_bounds__(256) void group_affine_bwd_kernel(const float *__re
 extern "C" {
 
 int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float *new_xyz, const int64_t *idx,
-                         const float *Wx, int B, int N, int S, int K, int C, float *Y, int ldy, double *stats,
+                         const float *Wx, int ldwx, int B, int N, int S, int K, int C, float *Y, int ldy, double *stats,
                          pn2_stream_t stream) {
-    PN2_CHECK_ARG(Zf && xyz && new_xyz && idx && Wx && Y && B > 0 && N > 0 && S > 0 && K > 0 && C > 0 && C <= 1024);
+    PN2_CHECK_ARG(Zf && xyz && new_xyz && idx && Wx && Y && B > 0 && N > 0 && S > 0 && K > 0 && C > 0 && C <= 1024 &&
+                  ldwx >= 3);
     PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldz >= ((C + 3) & ~3) && ldy >= ((C + 3) & ~3));
     const int64_t P = (int64_t)B * S * K;
     const int rpb = 256 / ((C + 3) >> 2);
     int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 8);
     if (blocks > 1024) blocks = 1024;    // 2*C same-address fp64 atomics per workgroup at the end
     hipLaunchKernelGGL(group_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), Zf, ldz, xyz, new_xyz, idx,
-                       Wx, N, S, K, C, P, Y, ldy, stats);
+                       Wx, ldwx, N, S, K, C, P, Y, ldy, stats);
     return pn2_launch_status();
 }
 

@@ -3,7 +3,7 @@
 //     loss = - sum_r w[t_r] * logp[r, t_r] / sum_r w[t_r]      over rows with t_r != ignore_index
 // ATen's own kernel for this reduction is a single workgroup (66 us forward + 37 us backward at 65 536 rows
 // on MI355X, fully exposed between the forward and the backward pass); here every CU takes a slice, the
-// per-workgroup partials are fp64 and the last workgroup to finish (ticket) adds them in index order, so
+// per-workgroup partials are fp64 and the last workgroup to finish (ticket) adds them in a fixed order, so
 // the result does not depend on the order the workgroups ran in.
 #include "pn2_common.h"
 
@@ -44,14 +44,27 @@ __global__ __launch_bounds__(kThreads) void nll_fwd_kernel(const float *__restri
     __syncthreads();
     if (!last) return;
     __threadfence();
-    if (threadIdx.x == 0) {                                // <= 1024 partials, added in index order
-        double n = 0.0, d = 0.0;
-        for (unsigned i = 0; i < gridDim.x; ++i) {
-            n += __builtin_nontemporal_load(ws + i);
-            d += __builtin_nontemporal_load(ws + gridDim.x + i);
+    // <= 1024 partials: thread t adds partials t, t + 256, ... in index order, then a fixed-shape tree over the 256
+    // threads -- the summation order is a function of gridDim only, never of which workgroup finished when.
+    __shared__ double tree[2][kThreads];
+    double n = 0.0, d = 0.0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += kThreads) {
+        n += __builtin_nontemporal_load(ws + i);
+        d += __builtin_nontemporal_load(ws + gridDim.x + i);
+    }
+    tree[0][threadIdx.x] = n;
+    tree[1][threadIdx.x] = d;
+    __syncthreads();
+    for (int w = kThreads / 2; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            tree[0][threadIdx.x] += tree[0][threadIdx.x + w];
+            tree[1][threadIdx.x] += tree[1][threadIdx.x + w];
         }
-        *loss = (float)(n / d);                            // 0/0 = NaN when every row is ignored, as ATen
-        *denom = (float)d;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *loss = (float)(tree[0][0] / tree[1][0]);          // 0/0 = NaN when every row is ignored, as ATen
+        *denom = (float)tree[1][0];
         *ticket = 0;                                       // the workspace is reusable without another memset
     }
 }

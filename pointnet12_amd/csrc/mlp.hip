@@ -251,7 +251,7 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
     }
 };
 
-struct EpiStore {           // first layer: dX0 = acc (pad lanes are exact zeros: the W^T pad rows are zero)
+struct EpiStore {           // first layer: dX0 = acc (pad lanes are exact zeros: weight columns n >= N are never fetched)
     float *dX; int ldx;
     static constexpr bool kHasStats = false;
     __device__ __forceinline__ bool want_stats() const { return false; }
@@ -295,33 +295,52 @@ __device__ unsigned long long pn2_stamp_buf[8 * 2048];
 #define STAMP_FLUSH
 #endif
 
-template <int BM, int BN, int BK>
+// The weight operand of the NT core.  Rows of pitch `ld` floats; K = contraction length.
+//   BNN == false (forward):  p[n * ld + k], n < N rows, k contiguous   (a Conv weight [C_out, C_in] as it is stored)
+//   BNN == true  (dgrad):    p[k * ld + n], k < K rows, n contiguous   (the same Conv weight read "down the columns":
+//                            dX = dY * W needs W[k = c_out][n = c_in], so no transposed copy is ever made)
+// vec != 0: rows are 16-byte aligned (pointer and pitch) and whole float4 reads stay inside a row; otherwise
+// the tile is fetched with guarded scalar loads (weights sliced out of a wider matrix, C_in not a multiple of 4).
+struct BMat { const float *p; int ld; int K; int vec; };
+
+inline BMat make_bmat(const float *p, int ld, int K, int contiguous_len) {
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (contiguous_len & 3) == 0;
+    return BMat{p, ld, K, vec ? 1 : 0};
+}
+
+template <int BM, int BN, int BK, bool BNN = false>
 struct NtLds {
-    static constexpr int kOperands = 2 * (BM + BN) * (BK + 4);       // floats, double buffered
+    static constexpr int kB = BNN ? BK * (BN + 8) : BN * (BK + 4);
+    static constexpr int kOperands = 2 * (BM * (BK + 4) + kB);       // floats, double buffered
     static constexpr int kStage = BM * (BN + 4);                      // floats, aliases the operands
     static constexpr int kReduce = NTHREADS * 8 * 2;                  // floats (256 x 8 doubles)
     static constexpr int kFloats = kOperands > kStage ? (kOperands > kReduce ? kOperands : kReduce)
                                                       : (kStage > kReduce ? kStage : kReduce);
 };
 
-template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, class ALoad, class Epi>
-__global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, const float *__restrict__ Bw, int ldb,
-                                                              int64_t P, int K4, int N, Epi epi) {
+template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi>
+__global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi) {
     static_assert(WR * WC == 4, "four waves");
     constexpr int WTM = BM / WR, WTN = BN / WC;      // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;      // MFMA tiles per wave
     constexpr int LDP = BK + 4;                      // LDS row pitch: 16 consecutive rows cover all 64 banks once
     constexpr int TPR = BK / 4;                      // loader threads per row segment
     constexpr int RPL = NTHREADS / TPR;              // rows per loader pass
-    constexpr int A_IT = BM / RPL, B_IT = (BN + RPL - 1) / RPL;   // BN = 96: the last B pass is half live
+    constexpr int A_IT = BM / RPL;
+    constexpr int TPRB = BNN ? BN / 4 : TPR;         // B tile in LDS: [BN][BK] (k contiguous) or, BNN, [BK][BN] (n contiguous)
+    constexpr int RPLB = NTHREADS / TPRB;            // B rows per loader pass (BN = 96, BNN: 10, sixteen threads idle)
+    constexpr int BROWS = BNN ? BK : BN;
+    constexpr int B_IT = (BROWS + RPLB - 1) / RPLB;  // the last pass may be partly live
+    constexpr int LDBS = BNN ? BN + 8 : LDP;         // LDS pitch of a B row (BNN: lanes 32..63 read 4 rows further down,
+                                                     // 4 * (BN + 8) = 32 mod 64 banks -> the two half-waves never collide)
     constexpr int CG = BN / 4;                       // float4 column groups of the output tile
     constexpr int RPP = NTHREADS / CG;               // rows per epilogue pass
     constexpr int LDC = BN + 4;
     static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 loader threads");
 
-    __shared__ __attribute__((aligned(16))) float lds[NtLds<BM, BN, BK>::kFloats];
+    __shared__ __attribute__((aligned(16))) float lds[NtLds<BM, BN, BK, BNN>::kFloats];
     float *As = lds;                                  // [2][BM*LDP]
-    float *Bs = lds + 2 * BM * LDP;                   // [2][BN*LDP]
+    float *Bs = lds + 2 * BM * LDP;                   // [2][BROWS*LDBS]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -330,6 +349,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
     const int64_t tiles_m = (P + BM - 1) / BM;
     const int nk = (K4 + BK - 1) / BK;
     const int lrow = t / TPR, lkq = (t % TPR) * 4;    // loader coordinates
+    const int brow = t / TPRB, bcq = (t % TPRB) * 4;  // B loader coordinates (row of the LDS layout, first of 4 columns)
     const int ecg = t % CG, erow = t / CG;            // epilogue coordinates
     const int en = n0 + ecg * 4;
 
@@ -348,10 +368,23 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
         const int k = ks * BK + lkq;
         const bool kvalid = k < K4 && tile < tiles_m;
         aload.template issue<A_IT>(qa, tile * BM + lrow, RPL, k, P, kvalid);
+        const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + lrow + i * RPL;
-            qb[i] = ld4((n < N && kvalid && lrow + i * RPL < BN) ? Bw + (int64_t)n * ldb + k : reinterpret_cast<const float *>(pn2_zero_page));
+            const int r = brow + i * RPLB;
+            // (row, col) = global coordinates of the first of this thread's four elements; `lim` bounds the run
+            const int row = BNN ? ks * BK + r : n0 + r, col = BNN ? n0 + bcq : ks * BK + bcq;
+            const int rlim = BNN ? bm.K : N, lim = BNN ? N : bm.K;
+            const bool ok = brow < RPLB && r < BROWS && tile < tiles_m && row < rlim;
+            const float *src = bm.p + (int64_t)row * bm.ld + col;
+            if (VEC) {
+                qb[i] = ld4((ok && col < lim) ? src : zp);
+            } else {
+                qb[i].x = *((ok && col < lim) ? src : zp);
+                qb[i].y = *((ok && col + 1 < lim) ? src + 1 : zp);
+                qb[i].z = *((ok && col + 2 < lim) ? src + 2 : zp);
+                qb[i].w = *((ok && col + 3 < lim) ? src + 3 : zp);
+            }
         }
     };
 
@@ -378,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
-            float *Ab = As + buf * (BM * LDP), *Bb = Bs + buf * (BN * LDP);
+            float *Ab = As + buf * (BM * LDP), *Bb = Bs + buf * (BROWS * LDBS);
             const bool kv = ks * BK + lkq < K4;
             const typename ALoad::Params ap = aload.params(ks * BK + lkq, kv);
 #pragma unroll
@@ -387,7 +420,8 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
                     aload.template finish<A_IT>(ra[d], i, kv && (m0 + lrow + i * RPL < P), ap);
 #pragma unroll
             for (int i = 0; i < B_IT; ++i)
-                if (BN % RPL == 0 || lrow + i * RPL < BN) *reinterpret_cast<float4 *>(&Bb[(lrow + i * RPL) * LDP + lkq]) = rb[d][i];
+                if ((NTHREADS % TPRB == 0 && BROWS % RPLB == 0) || (brow < RPLB && brow + i * RPLB < BROWS))
+                    *reinterpret_cast<float4 *>(&Bb[(brow + i * RPLB) * LDBS + bcq]) = rb[d][i];
             fetch(ra[d], rb[d], ptile, pks);
             if (++pks == nk) { pks = 0; ptile += gridDim.x; }
             STAMP(0)
@@ -400,8 +434,14 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, co
                 for (int i = 0; i < TM; ++i)
                     a[i] = *reinterpret_cast<const float4 *>(&Ab[(wr * WTM + i * 32 + l31) * LDP + kb * 8 + lh * 4]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    b[j] = *reinterpret_cast<const float4 *>(&Bb[(wc * WTN + j * 32 + l31) * LDP + kb * 8 + lh * 4]);
+                for (int j = 0; j < TN; ++j) {
+                    if (BNN) {                        // four k-rows of the [BK][BN] image, lanes on consecutive n
+                        const float *bp = &Bb[(kb * 8 + lh * 4) * LDBS + wc * WTN + j * 32 + l31];
+                        b[j] = make_float4(bp[0], bp[LDBS], bp[2 * LDBS], bp[3 * LDBS]);
+                    } else {
+                        b[j] = *reinterpret_cast<const float4 *>(&Bb[(wc * WTN + j * 32 + l31) * LDP + kb * 8 + lh * 4]);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -478,15 +518,15 @@ inline int pn2_num_cus() {
     return cus;
 }
 
-template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, class ALoad, class Epi>
-int launch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
+template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi>
+int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     int64_t tiles_m = pn2_cdiv(P, BM);
     unsigned tiles_n = (unsigned)pn2_cdiv(N, BN);
     int64_t cap = (int64_t)pn2_num_cus() * MINB / tiles_n;  // MINB resident workgroups per CU in total
     if (cap < 1) cap = 1;
     unsigned gx = (unsigned)(tiles_m < cap ? tiles_m : cap);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS), 0, s, aload, Bw,
-                       ldb, P, K4, N, epi);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS), 0, s,
+                       aload, bm, P, K4, N, epi);
     return pn2_launch_status();
 }
 
@@ -495,26 +535,36 @@ inline int pn2_env_int(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <class ALoad, class Epi>
-int dispatch_nt(ALoad aload, const float *Bw, int ldb, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
+template <bool BNN, class ALoad, class Epi>
+int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     static const int cfg = pn2_env_int("PN2_NT_CFG", 0);     // tuning hook (tools/bench_kernels.py)
-    if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
-    if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     // 65..96 output channels (64->96, 128->96 in MSG sa1): an exact 96-wide tile instead of 25 % padding MFMAs
     if (N <= 96 && cfg != 9) {
-        if (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);   // no spills
-        return launch_nt<128, 96, 16, 4, 1, 3, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+        if (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);   // no spills
+        return launch_nt<128, 96, 16, 4, 1, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     }
-    if (cfg == 1) return launch_nt<128, 128, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (cfg == 1) return launch_nt<128, 128, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     // 64x128 tiles, 16-deep k-steps: more, smaller workgroups per CU hide the operand stream's latency better than
     // 128x128x32 at two per CU (+10..17 %, tools/bench_kernels.py).  Loaders with a large in-flight register set
     // (two or three tensors per operand row) get a 168-VGPR budget (3 per CU) instead of 128 (4 per CU): no spills.
-    if (cfg == 3) return launch_nt<64, 128, 16, 2, 2, 3, 2>(aload, Bw, ldb, P, K4, N, epi, s);
-    if (cfg == 5) return launch_nt<64, 128, 16, 2, 2, 3, 3>(aload, Bw, ldb, P, K4, N, epi, s);
-    if (cfg == 6) return launch_nt<64, 128, 16, 2, 2, 2, 4>(aload, Bw, ldb, P, K4, N, epi, s);
-    if (cfg == 4) return launch_nt<64, 128, 32, 2, 2, 2, 1>(aload, Bw, ldb, P, K4, N, epi, s);
-    if (ALoad::kRegs >= 8 || cfg == 2) return launch_nt<64, 128, 16, 2, 2, 3, 1>(aload, Bw, ldb, P, K4, N, epi, s);
-    return launch_nt<64, 128, 16, 2, 2, 4, 1>(aload, Bw, ldb, P, K4, N, epi, s);
+    if (cfg == 3) return launch_nt<64, 128, 16, 2, 2, 3, 2, BNN, true>(aload, bm, P, K4, N, epi, s);
+    if (cfg == 5) return launch_nt<64, 128, 16, 2, 2, 3, 3, BNN, true>(aload, bm, P, K4, N, epi, s);
+    if (cfg == 6) return launch_nt<64, 128, 16, 2, 2, 2, 4, BNN, true>(aload, bm, P, K4, N, epi, s);
+    if (cfg == 4) return launch_nt<64, 128, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    if (ALoad::kRegs >= 8 || cfg == 2) return launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    return launch_nt<64, 128, 16, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+}
+
+// Weights whose rows cannot be read as float4 (C_in = 9, 137, ...; column slices of a wider matrix) take guarded
+// scalar loads for the weight tile; three tile shapes cover them (these are the first layers: short K or short P).
+template <bool BNN, class ALoad, class Epi>
+int dispatch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
+    if (bm.vec) return dispatch_nt_vec<BNN>(aload, bm, P, K4, N, epi, s);
+    if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
+    if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
+    return launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
 }
 
 // ----------------------------------------------------------------------------- TN GEMM (wgrad)
@@ -866,11 +916,12 @@ extern "C" {
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
                     int ldy, int64_t P, int K, int N, double *stats, pn2_stream_t stream) {
     PN2_CHECK_ARG(X && W && bias && Y && P > 0 && K > 0 && N > 0);
-    PN2_CHECK_ARG(ldx % 4 == 0 && ldw % 4 == 0 && ldx >= round4(K) && ldw >= round4(K) && ldy >= N);
+    PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= round4(K) && ldw >= K && ldy % 4 == 0 && ldy >= round4(N));
     const int K4 = round4(K);
     EpiFwd epi{Y, ldy, bias, stats};
-    if (in_affine) return dispatch_nt(LoadBnRelu{X, ldx, in_affine}, W, ldw, P, K4, N, epi, pn2_s(stream));
-    return dispatch_nt(LoadPlain{X, ldx}, W, ldw, P, K4, N, epi, pn2_s(stream));
+    const BMat bm = make_bmat(W, ldw, K, K);
+    if (in_affine) return dispatch_nt<false>(LoadBnRelu{X, ldx, in_affine}, bm, P, K4, N, epi, pn2_s(stream));
+    return dispatch_nt<false>(LoadPlain{X, ldx}, bm, P, K4, N, epi, pn2_s(stream));
 }
 
 int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, const float *beta, float eps,
@@ -941,12 +992,13 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
     return pn2_launch_status();
 }
 
-int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *Wt, int ldw,
+int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
                       double *prev_red, int64_t P, int K, int N, pn2_stream_t stream) {
-    PN2_CHECK_ARG(Y && coef && Wt && dXout && P > 0 && K > 0 && N > 0);
+    PN2_CHECK_ARG(Y && coef && W && dXout && P > 0 && K > 0 && N > 0);
     PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
-    PN2_CHECK_ARG(ldw % 4 == 0 && ldw >= round4(K) && ldy % 4 == 0 && ldy >= round4(K) && ldxo >= N);
+    PN2_CHECK_ARG(ldw >= N && ldy % 4 == 0 && ldy >= round4(K) && ldxo % 4 == 0 && ldxo >= round4(N));
+    const BMat bm = make_bmat(W, ldw, K, N);
     PN2_CHECK_ARG(prev_Y == nullptr || prev_affine != nullptr);
     const int K4 = round4(K), ldc = round4(K);
     hipStream_t s = pn2_s(stream);
@@ -954,16 +1006,16 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
         PN2_CHECK_ARG(ldz % 4 == 0 && ldz >= K4);
         LoadDyDense ld{dZ, ldz, Y, ldy, coef, ldc};
         if (prev_Y)
-            return dispatch_nt(ld, Wt, ldw, P, K4, N,
-                               EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red}, s);
-        return dispatch_nt(ld, Wt, ldw, P, K4, N, EpiStore{dXout, ldxo}, s);
+            return dispatch_nt<true>(ld, bm, P, K4, N,
+                                     EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red}, s);
+        return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= K4);
     LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc};
     if (prev_Y)
-        return dispatch_nt(ld, Wt, ldw, P, K4, N, EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red},
-                           s);
-    return dispatch_nt(ld, Wt, ldw, P, K4, N, EpiStore{dXout, ldxo}, s);
+        return dispatch_nt<true>(ld, bm, P, K4, N,
+                                 EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red}, s);
+    return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
 }
 
 int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,

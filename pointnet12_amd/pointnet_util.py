@@ -91,6 +91,13 @@ def _zeros_small(nbytes, device):
     return a[0][off:off + nbytes]
 
 
+def _contig_weight(w):
+    """The [C_out, C_in(,1(,1))] Conv weight as the kernels read it: contiguous storage, row pitch C_in.  Parameters
+    always are; a copy is made only for exotic views."""
+    w = w.detach()
+    return w if w.is_contiguous() else w.contiguous()
+
+
 _ident_cache = {}
 
 
@@ -418,7 +425,7 @@ class _SharedMLP(torch.autograd.Function):
         n_aff = 4 * sum(_r4(c) for c in chans[1:])
         zero_bytes = _zeros_small(8 * n_stats + 4 * n_aff, dev)
         stats = zero_bytes[:8 * n_stats].view(torch.float64) if training else None
-        Ys, affs, Wps = [], [], []
+        Ys, affs = [], []
         aff_all = zero_bytes[8 * n_stats:].view(torch.float32)
         aff_off = 0
         x, ldx, x_aff, off = rows, rows.shape[-1], None, 0
@@ -428,28 +435,21 @@ class _SharedMLP(torch.autograd.Function):
             y = _empty_rows(P, co, dev)
             st_l = stats[off:off + _REPL * 2 * co] if training else None
             if l == 0 and geom is not None:
-                w2 = w.detach().reshape(co, ci)
-                wx = (w2[:, :3] if g_first else w2[:, gD:]).contiguous()
-                wf = w2[:, 3:] if g_first else w2[:, :gD]
+                # the kernels read the xyz / feature columns straight out of the [co, 3+D] weight (pitch ci): no copies
+                w_ptr = _contig_weight(w).data_ptr()
+                wx_ptr, wf_ptr = (w_ptr, w_ptr + 12) if g_first else (w_ptr + 4 * gD, w_ptr)
                 ldd = _r4(gD)
                 feat = rows.reshape(gB * gN, gD)
                 if ldd != gD:
                     feat = torch.nn.functional.pad(feat, (0, ldd - gD))
-                    wf = torch.nn.functional.pad(wf, (0, ldd - gD))
-                wf = wf.contiguous()
                 zf = _empty_rows(gB * gN, co, dev)
-                _check(lib.pn2_conv1x1_fwd(_p(feat), ldd, None, _p(wf), ldd, _p(b), _p(zf), zf.shape[1], gB * gN, gD, co,
+                _check(lib.pn2_conv1x1_fwd(_p(feat), ldd, None, wf_ptr, ci, _p(b), _p(zf), zf.shape[1], gB * gN, gD, co,
                                            None, st), "pn2_conv1x1_fwd")
-                _check(lib.pn2_group_affine_fwd(_p(zf), zf.shape[1], _p(g_xyz), _p(g_new), _p(g_idx), _p(wx), gB, gN, gS, gK,
-                                                co, _p(y), y.shape[1], _p(st_l), st), "pn2_group_affine_fwd")
-                wp = wf
+                _check(lib.pn2_group_affine_fwd(_p(zf), zf.shape[1], _p(g_xyz), _p(g_new), _p(g_idx), wx_ptr, ci, gB, gN, gS,
+                                                gK, co, _p(y), y.shape[1], _p(st_l), st), "pn2_group_affine_fwd")
             else:
-                wp = w.detach().reshape(co, ci)
-                if ldx != ci:
-                    wp = torch.nn.functional.pad(wp, (0, ldx - ci))
-                wp = wp.contiguous()
-                _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(wp), ldx, _p(b), _p(y), y.shape[1], P, ci, co,
-                                           _p(st_l), st), "pn2_conv1x1_fwd")
+                _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(_contig_weight(w)), ci, _p(b), _p(y), y.shape[1], P, ci,
+                                           co, _p(st_l), st), "pn2_conv1x1_fwd")
             aff = aff_all[aff_off:aff_off + 4 * _r4(co)]
             aff_off += 4 * _r4(co)
             eps, mom = bn_cfg[l]
@@ -457,7 +457,6 @@ class _SharedMLP(torch.autograd.Function):
                                        _p(rmean), _p(rvar), _p(nbt), _p(aff), st), "pn2_bn_finalize")
             Ys.append(y)
             affs.append(aff)
-            Wps.append(wp)
             x, ldx, x_aff = y, y.shape[1], aff
             off += _REPL * 2 * co
         cl = chans[-1]
@@ -549,12 +548,9 @@ class _SharedMLP(torch.autograd.Function):
             if not training and direct:
                 raise NotImplementedError("direct gradient accumulation with eval-mode BatchNorm: use autograd mode")
             need_dx = l > 0 or ctx.needs_input_grad[0]
-            wt = dx = None
+            dx = None
             if need_dx:
-                wt = Ws[l].detach().reshape(co, ci).t()
-                if ldy != co:
-                    wt = torch.nn.functional.pad(wt, (0, ldy - co))
-                wt = wt.contiguous()
+                w_l = _p(_contig_weight(Ws[l]))             # [co, ci] as stored: the dgrad kernel reads it down the columns
                 if l > 0:
                     dx = _empty_rows(P, ci, dev)
                 else:
@@ -578,11 +574,11 @@ class _SharedMLP(torch.autograd.Function):
                 if need_dx:
                     c_dx = dx.data_ptr() + 4 * r0 * dx.shape[1]
                     if l > 0:
-                        _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), _p(wt), ldy, c_x, ldx, _p(x_aff), c_dx,
+                        _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, ci, c_x, ldx, _p(x_aff), c_dx,
                                                      dx.shape[1], _p(red[offs[l - 1]:offs[l]]), rn, co, ci, st),
                                "pn2_conv1x1_dgrad")
                     else:
-                        _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), _p(wt), ldy, None, 0, None, c_dx,
+                        _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, ci, None, 0, None, c_dx,
                                                      ldx, None, rn, co, ci, st), "pn2_conv1x1_dgrad")
                 _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
                                              None if training else _p(dbias), rn, co, ci, st), "pn2_conv1x1_wgrad")
@@ -617,13 +613,9 @@ class _SharedMLP(torch.autograd.Function):
                                      dW.data_ptr() + 4 * f_col, ldw, None, B * N, co, D, st), "pn2_conv1x1_wgrad")
         d_feats = None
         if need_dfeat:
-            w2 = w.detach().reshape(co, 3 + D)
-            wt = (w2[:, 3:] if g_first else w2[:, :D]).t()
-            if ldc != co:
-                wt = torch.nn.functional.pad(wt, (0, ldc - co))
-            wt = wt.contiguous()
+            wf_ptr = _contig_weight(w).data_ptr() + (12 if g_first else 0)      # feature columns of the [co, 3+D] weight
             dF = _empty_rows(B * N, D, dev)
-            _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), _p(wt), ldc, None, 0, None,
+            _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), wf_ptr, 3 + D, None, 0, None,
                                          _p(dF), ldd, None, B * N, co, D, st), "pn2_conv1x1_dgrad")
             d_feats = (dF[:, :D] if ldd != D else dF).reshape(B, N, D)
         return d_feats, (dW.view_as(w) if w_grad is None else None)
@@ -642,13 +634,9 @@ class _Conv1x1(torch.autograd.Function):
         P, ldx = rows.shape
         co = weight.shape[0]
         ci = weight.numel() // co
-        w = weight.detach().reshape(co, ci)
-        if ldx != ci:
-            w = torch.nn.functional.pad(w, (0, ldx - ci))
-        w = w.contiguous()
         y = _empty_rows(P, co, rows.device)
-        _check(lib.pn2_conv1x1_fwd(_p(rows), ldx, None, _p(w), ldx, _p(bias), _p(y), y.shape[1], P, ci, co, None, st),
-               "pn2_conv1x1_fwd")
+        _check(lib.pn2_conv1x1_fwd(_p(rows), ldx, None, _p(_contig_weight(weight)), ci, _p(bias), _p(y), y.shape[1], P, ci, co,
+                                   None, st), "pn2_conv1x1_fwd")
         ctx.save_for_backward(rows, weight)
         ctx.dims = (P, ci, co, ldx, y.shape[1])
         return y[:, :co] if y.shape[1] != co else y
@@ -672,12 +660,9 @@ class _Conv1x1(torch.autograd.Function):
                                      _p(db), P, co, ci, st), "pn2_conv1x1_wgrad")
         d_rows = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().reshape(co, ci).t()
-            if ldy != co:
-                wt = torch.nn.functional.pad(wt, (0, ldy - co))
-            wt = wt.contiguous()
             d_rows = torch.empty(P, ldx, device=dev, dtype=torch.float32)     # pad lanes written (0) by the GEMM
-            _check(lib.pn2_conv1x1_dgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(wt), ldy, None, 0, None,
+            _check(lib.pn2_conv1x1_dgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(_contig_weight(weight)), ci,
+                                         None, 0, None,
                                          _p(d_rows), ldx, None, P, co, ci, st), "pn2_conv1x1_dgrad")
         return d_rows, dW.view_as(weight), db
 

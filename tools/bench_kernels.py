@@ -70,14 +70,13 @@ def main():
         for P, K, N in FWD:
             X = torch.zeros(P, r4(K), device=dev)
             X[:, :K] = rnd(P, K)
-            W = torch.zeros(N, r4(K), device=dev)
-            W[:, :K] = rnd(N, K)
+            W = rnd(N, K)
             bias, Y = rnd(N), torch.empty(P, r4(N), device=dev)
             stats = torch.zeros(8 * 2 * N, device=dev, dtype=torch.float64)
             aff = affine(K) if K > 12 else None
 
             def fn():
-                rc = lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), r4(K), p(bias), p(Y), r4(N), P, K, N, p(stats), st)
+                rc = lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), st)
                 assert rc == 0
             report("fwd", (P, K, N), timeit(fn, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
             del X, Y
@@ -88,8 +87,7 @@ def main():
         for P, Cl, Cp, Kp in BWD:
             Y, Yp = rnd(P, r4(Cl)), rnd(P, r4(Cp))
             coef, affp = affine(Cl), affine(Cp)
-            Wt = torch.zeros(Cp, r4(Cl), device=dev)
-            Wt[:, :Cl] = rnd(Cp, Cl)
+            Wt = rnd(Cl, Cp)                    # the Conv weight [C_l, C_{l-1}] as stored; dgrad reads it down the columns
             if Kp:
                 G = P // Kp
                 dOut, out = rnd(G, r4(Cl)), rnd(G, r4(Cl))
@@ -105,7 +103,7 @@ def main():
                 red = torch.zeros(8 * 2 * Cp, device=dev, dtype=torch.float64)
 
                 def fn():
-                    rc = lib.pn2_conv1x1_dgrad(*dz, p(Y), r4(Cl), p(coef), p(Wt), r4(Cl), p(Yp), r4(Cp), p(affp), p(dX), r4(Cp),
+                    rc = lib.pn2_conv1x1_dgrad(*dz, p(Y), r4(Cl), p(coef), p(Wt), Cp, p(Yp), r4(Cp), p(affp), p(dX), r4(Cp),
                                                p(red), P, Cl, Cp, st)
                     assert rc == 0
                 report("dgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
