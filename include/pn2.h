@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 1
+#define PN2_ABI_VERSION 2
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -41,6 +41,30 @@ extern "C" {
 #define PN2_EUNSUPPORTED (-3)
 
 typedef void *pn2_stream_t;
+
+/* Fused BatchNorm "tails" (optional; pass NULL for none).  A kernel that finishes a per-channel reduction can do
+ * the small per-channel step that depends on it before it ends, instead of leaving it to a launch of its own
+ * (pn2_bn_finalize / pn2_bn_bwd_coef: ~5 us hops on the dependency chain, 50 per training step): every
+ * workgroup takes a ticket once its sums are visible device-wide and the one that draws the last ticket does the
+ * work.  *ticket must be 0 on entry (the kernel leaves it 0), and must not be shared by concurrent launches.
+ * The arithmetic is the same code path as the stand-alone entry points. */
+typedef struct pn2_bn_finalize_tail {       /* training-mode pn2_bn_finalize of the channels this launch produces */
+    unsigned *ticket;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *running_mean, *running_var;      /* may be NULL */
+    int64_t *num_batches_tracked;           /* may be NULL */
+    float *affine;                          /* out: float[4 * round4(C)] */
+} pn2_bn_finalize_tail;
+
+typedef struct pn2_bn_coef_tail {           /* pn2_bn_bwd_coef of the layer whose reductions this launch completes */
+    unsigned *ticket;
+    const float *gamma, *affine;
+    int use_batch_stats;
+    float *coef;                            /* out: float[4 * round4(C)] */
+    float *dgamma, *dbeta;                  /* may be NULL */
+    int accumulate;
+} pn2_bn_coef_tail;
 
 int pn2_version(void);
 const char *pn2_error_string(int code);
@@ -103,7 +127,7 @@ int pn2_group_bwd(const float *grad_rows, const int64_t *idx, int B, int N, int 
  * [C, 3+D] weight.  stats as in pn2_conv1x1_fwd (double[2*C], may be NULL). */
 int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float *new_xyz, const int64_t *idx,
                          const float *Wx, int ldwx, int B, int N, int S, int K, int C, float *Y, int ldy,
-                         double *stats, pn2_stream_t stream);
+                         double *stats, const pn2_bn_finalize_tail *fin, pn2_stream_t stream);
 /* backward: dY = c0*dZ + q1*(y-mean) + q0 (coef from pn2_bn_bwd_coef) is scattered to the source points,
  * G[b*N + idx[p], :] += dY[p, :] (G [B*N, ldg], caller zeroes), and dWx[c, a] += dY[p, c] * (xyz - centre)[a]
  * (dWx [C, 3] with row pitch ldwx >= 3 -- it may point at the xyz columns of the full weight gradient --
@@ -147,7 +171,8 @@ int pn2_copy_cols(const float *src, int lds, int scol0, float *dst, int ldd, int
  * the layer that produced X.  stats: NULL or a replicated double[2*N] block (see PN2_STAT_REPLICAS; caller zeroes) receiving
  * sum(y) and sum(y*y) per output channel over the P rows (training-mode BN statistics). */
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias,
-                    float *Y, int ldy, int64_t P, int K, int N, double *stats, pn2_stream_t stream);
+                    float *Y, int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin,
+                    pn2_stream_t stream);
 
 /* BatchNorm statistics -> affine block.  training != 0: mean/var (biased) from stats/P,
  * running_mean/var (may be NULL) updated with `momentum` and the unbiased variance,
@@ -166,11 +191,13 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
  * red[0..C) = sum dZ, red[C..2C) = sum dZ*yhat with dZ[g*K+k,c] = (k == arg[g,c]) ? dZp[g,c] : 0.
  * red is double[2*C], caller zeroes. */
 int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
-                        const float *affine, int64_t G, int K, int C, float *dZp, double *red, pn2_stream_t stream);
+                        const float *affine, int64_t G, int K, int C, float *dZp, double *red,
+                        const pn2_bn_coef_tail *tail, pn2_stream_t stream);
 /* Backward, dense (FP) last layer: dZ = dOut * (out > 0) written to dZ [P, ldz] (its pad columns
  * C .. round4(C)-1 are written as zeros); same reductions. */
 int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,
-                        int64_t P, int C, float *dZ, int ldz, double *red, pn2_stream_t stream);
+                        int64_t P, int C, float *dZ, int ldz, double *red, const pn2_bn_coef_tail *tail,
+                        pn2_stream_t stream);
 
 /* Per-channel BN-backward coefficients from the reductions: coef float[4*C] =
  * [c0 = gamma*invstd, q1 = -c0*invstd*red1/P, q0 = -c0*red0/P, mean]; dgamma = red1, dbeta = red0.
@@ -186,11 +213,13 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
  *   dZ != NULL: dense dZ [P, ldz];  dZ == NULL: pooled form (dZp [G,ldo] from pn2_pool_bwd_reduce, arg, Kpool).
  * Epilogue, prev_Y != NULL: dZprev = dXact * (bn_relu(prev_Y) > 0) -> dXout, and
  *   prev_red (double[2*N], caller zeroes) += sum dZprev, sum dZprev*yhat_prev;
- * prev_Y == NULL (first layer): dXout = dXact. */
+ * prev_Y == NULL (first layer): dXout = dXact.
+ * prev_tail (optional, needs prev_Y): the coefficients / dgamma / dbeta of layer l-1 from the finished prev_red. */
 int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg,
                       int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
-                      double *prev_red, int64_t P, int K, int N, pn2_stream_t stream);
+                      double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail,
+                      pn2_stream_t stream);
 
 /* wgrad: dW[M,N] (pitch lddw, caller zeroes) += sum_p dY[p,m] * Xact[p,n]; M = C_l, N = C_{l-1}.
  * dY formed as in dgrad; Xact = bn_relu(prev_Y) when prev_affine != NULL, else X as is.

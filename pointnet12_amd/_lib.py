@@ -26,25 +26,40 @@ SIGNATURES = {
     "pn2_gather_rows_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_group": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pn2_group_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "pn2_group_affine_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "pn2_group_affine_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_group_affine_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "pn2_three_interp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "pn2_three_interp_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_copy_cols": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
-    "pn2_conv1x1_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
+    "pn2_conv1x1_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "pn2_bn_finalize": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "pn2_bn_relu_max": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
-    "pn2_pool_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
-    "pn2_relu_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp]),
+    "pn2_pool_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "pn2_relu_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_bn_bwd_coef": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pn2_conv1x1_dgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp,
-                               _i64, _i, _i, _vp]),
+                               _i64, _i, _i, _vp, _vp]),
     "pn2_conv1x1_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
                                _i64, _i, _i, _vp]),
     "pn2_nll_loss_workspace_bytes": (_i64, [_i64]),
     "pn2_nll_loss_fwd": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp]),
     "pn2_nll_loss_bwd": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp]),
 }
+
+
+ABI_VERSION = 2
+
+
+class BnFinalizeTail(ctypes.Structure):
+    """pn2_bn_finalize_tail of include/pn2.h."""
+    _fields_ = [("ticket", _vp), ("gamma", _vp), ("beta", _vp), ("eps", _f), ("momentum", _f), ("running_mean", _vp),
+                ("running_var", _vp), ("num_batches_tracked", _vp), ("affine", _vp)]
+
+
+class BnCoefTail(ctypes.Structure):
+    """pn2_bn_coef_tail of include/pn2.h."""
+    _fields_ = [("ticket", _vp), ("gamma", _vp), ("affine", _vp), ("use_batch_stats", _i), ("coef", _vp), ("dgamma", _vp),
+                ("dbeta", _vp), ("accumulate", _i)]
 
 
 class Pn2Error(RuntimeError):
@@ -118,8 +133,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pn2_version() != 1:
-        raise Pn2Error("libpn2_hip.so ABI version %d, expected 1" % lib.pn2_version())
+    if lib.pn2_version() != ABI_VERSION:
+        raise Pn2Error("libpn2_hip.so ABI version %d, expected %d -- rebuild it" % (lib.pn2_version(), ABI_VERSION))
     _lib = _raw = lib
     return lib
 

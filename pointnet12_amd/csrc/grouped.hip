@@ -10,6 +10,7 @@
 // Replaces, for the first layer only: index_points + cat (pointnet_util.py:127-131, :243-247) and
 // nn.Conv2d (pointnet_util.py:197, :254), and their autograd.
 #include "pn2_common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void group_affine_fwd_kernel(const float *__re
                                                                const int64_t *__restrict__ idx,
                                                                const float *__restrict__ Wx, int ldwx, int N, int S,
                                                                int K, int C, int64_t P, float *__restrict__ Y, int ldy,
-                                                               double *__restrict__ stats) {
+                                                               double *__restrict__ stats, FinTail fin) {
     __shared__ double red[256 * 8];
     const int CG = (C + 3) >> 2;                  // float4 column groups per row
     const int RPB = 256 / CG;                     // rows per pass
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void group_affine_fwd_kernel(const float *__re
         atomicAdd(rep + ch, a0);
         atomicAdd(rep + C + ch, a1);
     }
+    if (fin.ticket != nullptr && tail_is_last_block(fin.ticket, gridDim.x)) run_fin_tail(fin, stats, C, 256);
 }
 
 // Backward: dY = c0*dZ + q1*(y-mean) + q0 (BatchNorm backward folded into `coef`, see mlp.hip) is
@@ -157,7 +159,15 @@ extern "C" {
 
 int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float *new_xyz, const int64_t *idx,
                          const float *Wx, int ldwx, int B, int N, int S, int K, int C, float *Y, int ldy, double *stats,
-                         pn2_stream_t stream) {
+                         const pn2_bn_finalize_tail *fin, pn2_stream_t stream) {
+    PN2_CHECK_ARG(fin == nullptr || (stats && fin->ticket && fin->gamma && fin->beta && fin->affine));
+    FinTail ft{};
+    if (fin) {
+        const int64_t rows = (int64_t)B * S * K;
+        ft = FinTail{fin->ticket, fin->gamma, fin->beta, fin->eps, fin->momentum, fin->running_mean, fin->running_var,
+                     fin->num_batches_tracked, fin->affine, 1.0 / (double)rows,
+                     rows > 1 ? (double)rows / (double)(rows - 1) : 1.0};
+    }
     PN2_CHECK_ARG(Zf && xyz && new_xyz && idx && Wx && Y && B > 0 && N > 0 && S > 0 && K > 0 && C > 0 && C <= 1024 &&
                   ldwx >= 3);
     PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldz >= ((C + 3) & ~3) && ldy >= ((C + 3) & ~3));
@@ -166,7 +176,7 @@ int pn2_group_affine_fwd(const float *Zf, int ldz, const float *xyz, const float
     int64_t blocks = pn2_cdiv(P, (int64_t)rpb * 8);
     if (blocks > 1024) blocks = 1024;    // 2*C same-address fp64 atomics per workgroup at the end
     hipLaunchKernelGGL(group_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), Zf, ldz, xyz, new_xyz, idx,
-                       Wx, ldwx, N, S, K, C, P, Y, ldy, stats);
+                       Wx, ldwx, N, S, K, C, P, Y, ldy, stats, ft);
     return pn2_launch_status();
 }
 

@@ -6,6 +6,7 @@
 // Activations are position-major: row p = one grouped position, channels contiguous.
 // Replaces model/pointnet_util.py:194-199, :251-256, :309-312 and their autograd.
 #include "pn2_common.h"
+#include "bn_tail.h"
 #include <stdlib.h>
 
 namespace {
@@ -20,10 +21,6 @@ __device__ __forceinline__ float bn_act(float y, float mean, float scale, float 
     return __builtin_fmaf(y - mean, scale, beta);
 }
 
-struct Affine {   // views into a float[4*ld] affine block (see pn2.h)
-    const float *mean, *scale, *beta, *invstd;
-    __device__ __host__ Affine(const float *base, int ld) : mean(base), scale(base + ld), beta(base + 2 * ld), invstd(base + 3 * ld) {}
-};
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ int4 ld4i(const int32_t *p) { return *reinterpret_cast<const int4 *>(p); }
@@ -193,9 +190,11 @@ __device__ __forceinline__ float4 ld4_guard(const float *p, int n, int N) {
     return r;
 }
 
-struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y) -> stats
-    float *Y; int ldy; const float *bias; double *stats;
+struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y) -> stats (-> affine block, fused tail)
+    float *Y; int ldy; const float *bias; double *stats; FinTail fin;
     static constexpr bool kHasStats = true;
+    __device__ __forceinline__ unsigned *ticket() const { return fin.ticket; }
+    __device__ __forceinline__ void tail(int N) const { run_fin_tail(fin, stats, N, NTHREADS); }
     __device__ __forceinline__ bool want_stats() const { return stats != nullptr; }
     __device__ __forceinline__ void prep(int n, int N, float4 (&c)[4]) const { c[0] = ld4_guard(bias, n, N); }
     __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], float4 &s0,
@@ -222,8 +221,10 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
 };
 
 struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev), sum(dZprev*yhat_prev) -> red
-    float *dX; int ldx; const float *prevY; int ldp; const float *aff; int lda; double *red;
+    float *dX; int ldx; const float *prevY; int ldp; const float *aff; int lda; double *red; CoefTail ct;
     static constexpr bool kHasStats = true;
+    __device__ __forceinline__ unsigned *ticket() const { return ct.ticket; }
+    __device__ __forceinline__ void tail(int N) const { run_coef_tail(ct, red, N, NTHREADS); }
     __device__ __forceinline__ bool want_stats() const { return red != nullptr; }
     __device__ __forceinline__ void prep(int n, int N, float4 (&c)[4]) const {
         Affine a(aff, lda);     // affine blocks are padded to a multiple of 4 with zeros
@@ -254,6 +255,8 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
 struct EpiStore {           // first layer: dX0 = acc (pad lanes are exact zeros: weight columns n >= N are never fetched)
     float *dX; int ldx;
     static constexpr bool kHasStats = false;
+    __device__ __forceinline__ unsigned *ticket() const { return nullptr; }
+    __device__ __forceinline__ void tail(int) const {}
     __device__ __forceinline__ bool want_stats() const { return false; }
     __device__ __forceinline__ void prep(int, int, float4 (&)[4]) const {}
     __device__ __forceinline__ void apply(int64_t m, int n, int, float4 acc, const float4 (&)[4], float4 &,
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             }
             if (n0 + t < N) epi.flush(n0 + t, N, a0, a1);
         }
+        if (epi.ticket() != nullptr && tail_is_last_block(epi.ticket(), gridDim.x * gridDim.y)) epi.tail(N);
     }
 }
 
@@ -727,21 +731,14 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, double inv_
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && training && nbt) *nbt += 1;
     if (c >= C) return;
-    double mean, var;
     if (training) {
         double s0 = 0.0, s1 = 0.0;
         for (int r = 0; r < PN2_STAT_REPLICAS; ++r) { s0 += stats[r * 2 * C + c]; s1 += stats[r * 2 * C + C + c]; }
-        mean = s0 * inv_p;
-        var = s1 * inv_p - mean * mean;
-        if (var < 0.0) var = 0.0;
-        if (rmean) rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
-        if (rvar) rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * var * unbias);
-    } else {
-        mean = (double)rmean[c];
-        var = (double)rvar[c];
+        bn_finalize_channel(s0, s1, c, ld, inv_p, unbias, gamma, beta, eps, momentum, rmean, rvar, affine);
+        return;
     }
-    double invstd = 1.0 / sqrt(var + (double)eps);
-    affine[c] = (float)mean;
+    const double invstd = 1.0 / sqrt((double)rvar[c] + (double)eps);
+    affine[c] = rmean[c];
     affine[ld + c] = (float)((double)gamma[c] * invstd);
     affine[2 * ld + c] = beta[c];
     affine[3 * ld + c] = (float)invstd;
@@ -816,7 +813,8 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
                                                               const int32_t *__restrict__ arg,
                                                               const float *__restrict__ Y, int ldy,
                                                               const float *__restrict__ aff, int lda, int64_t G, int K,
-                                                              int C, float *__restrict__ dZp, double *__restrict__ red) {
+                                                              int C, float *__restrict__ dZp, double *__restrict__ red,
+                                                              CoefTail ct) {
     __shared__ double sh[2][4][64];
     const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -845,6 +843,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
         atomicAdd(rep + c, a0);
         atomicAdd(rep + C + c, a1);
     }
+    if (ct.ticket != nullptr && tail_is_last_block(ct.ticket, gridDim.x * gridDim.y)) run_coef_tail(ct, red, C, 256);
 }
 
 // Dense last layer (FP): dZ = dOut * (out > 0), same two reductions.
@@ -852,7 +851,8 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
                                                               const float *__restrict__ out,
                                                               const float *__restrict__ Y, int ldy,
                                                               const float *__restrict__ aff, int lda, int64_t P, int C,
-                                                              float *__restrict__ dZ, int ldz, double *__restrict__ red) {
+                                                              float *__restrict__ dZ, int ldz, double *__restrict__ red,
+                                                              CoefTail ct) {
     __shared__ double sh[2][4][64];
     const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -880,6 +880,7 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
         atomicAdd(rep + c, a0);
         atomicAdd(rep + C + c, a1);
     }
+    if (ct.ticket != nullptr && tail_is_last_block(ct.ticket, gridDim.x * gridDim.y)) run_coef_tail(ct, red, C, 256);
 }
 
 __global__ void bn_bwd_coef_kernel(const double *__restrict__ red, double inv_p, int C, int ld,
@@ -888,16 +889,9 @@ __global__ void bn_bwd_coef_kernel(const double *__restrict__ red, double inv_p,
                                    int accumulate) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    Affine a(aff, ld);
-    double c0 = (double)gamma[c] * (double)a.invstd[c];
     double r0 = 0.0, r1 = 0.0;
     for (int r = 0; r < PN2_STAT_REPLICAS; ++r) { r0 += red[r * 2 * C + c]; r1 += red[r * 2 * C + C + c]; }
-    coef[c] = (float)c0;
-    coef[ld + c] = use_batch ? (float)(-c0 * (double)a.invstd[c] * r1 * inv_p) : 0.f;
-    coef[2 * ld + c] = use_batch ? (float)(-c0 * r0 * inv_p) : 0.f;
-    coef[3 * ld + c] = a.mean[c];
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)r1 : (float)r1;     // one writer per channel
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)r0 : (float)r0;
+    bn_coef_channel(r0, r1, c, ld, inv_p, gamma, aff, use_batch, coef, dgamma, dbeta, accumulate);
 }
 
 inline int round4(int x) { return (x + 3) & ~3; }
@@ -911,14 +905,47 @@ extern "C" int pn2_debug_stamps(unsigned long long *host_out, int n) {
 }
 #endif
 
+namespace {
+
+FinTail make_fin_tail(const pn2_bn_finalize_tail *t, int64_t P) {
+    FinTail f{};
+    if (t == nullptr) return f;
+    f.ticket = t->ticket;
+    f.gamma = t->gamma; f.beta = t->beta; f.eps = t->eps; f.momentum = t->momentum;
+    f.rmean = t->running_mean; f.rvar = t->running_var; f.nbt = t->num_batches_tracked; f.affine = t->affine;
+    f.inv_p = 1.0 / (double)P;
+    f.unbias = P > 1 ? (double)P / (double)(P - 1) : 1.0;
+    return f;
+}
+
+CoefTail make_coef_tail(const pn2_bn_coef_tail *t, int64_t P) {
+    CoefTail c{};
+    if (t == nullptr) return c;
+    c.ticket = t->ticket;
+    c.gamma = t->gamma; c.aff = t->affine; c.use_batch = t->use_batch_stats;
+    c.coef = t->coef; c.dgamma = t->dgamma; c.dbeta = t->dbeta; c.accumulate = t->accumulate;
+    c.inv_p = 1.0 / (double)P;
+    return c;
+}
+
+bool fin_tail_ok(const pn2_bn_finalize_tail *t, const double *stats) {
+    return t == nullptr || (stats && t->ticket && t->gamma && t->beta && t->affine);
+}
+
+bool coef_tail_ok(const pn2_bn_coef_tail *t, const double *red) {
+    return t == nullptr || (red && t->ticket && t->gamma && t->affine && t->coef);
+}
+
+}  // namespace
+
 extern "C" {
 
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
-                    int ldy, int64_t P, int K, int N, double *stats, pn2_stream_t stream) {
-    PN2_CHECK_ARG(X && W && bias && Y && P > 0 && K > 0 && N > 0);
+                    int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin, pn2_stream_t stream) {
+    PN2_CHECK_ARG(X && W && bias && Y && P > 0 && K > 0 && N > 0 && fin_tail_ok(fin, stats));
     PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= round4(K) && ldw >= K && ldy % 4 == 0 && ldy >= round4(N));
     const int K4 = round4(K);
-    EpiFwd epi{Y, ldy, bias, stats};
+    EpiFwd epi{Y, ldy, bias, stats, make_fin_tail(fin, P)};
     const BMat bm = make_bmat(W, ldw, K, K);
     if (in_affine) return dispatch_nt<false>(LoadBnRelu{X, ldx, in_affine}, bm, P, K4, N, epi, pn2_s(stream));
     return dispatch_nt<false>(LoadPlain{X, ldx}, bm, P, K4, N, epi, pn2_s(stream));
@@ -965,22 +992,24 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
 }
 
 int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
-                        const float *affine, int64_t G, int K, int C, float *dZp, double *red, pn2_stream_t stream) {
-    PN2_CHECK_ARG(dOut && out && arg && Y && affine && dZp && red && G > 0 && K > 0 && C > 0 && ldo >= ((C + 3) & ~3));
+                        const float *affine, int64_t G, int K, int C, float *dZp, double *red, const pn2_bn_coef_tail *tail,
+                        pn2_stream_t stream) {
+    PN2_CHECK_ARG(dOut && out && arg && Y && affine && dZp && red && G > 0 && K > 0 && C > 0 && ldo >= ((C + 3) & ~3) &&
+                  coef_tail_ok(tail, red));
     int64_t gy = pn2_cdiv(G, 4 * 16);
     if (gy > 256) gy = 256;
     hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((unsigned)pn2_cdiv((C + 3) & ~3, 64), (unsigned)gy), dim3(256), 0, pn2_s(stream), dOut,
-                       ldo, out, arg, Y, ldy, affine, (C + 3) & ~3, G, K, C, dZp, red);
+                       ldo, out, arg, Y, ldy, affine, (C + 3) & ~3, G, K, C, dZp, red, make_coef_tail(tail, G * K));
     return pn2_launch_status();
 }
 
 int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,
-                        int64_t P, int C, float *dZ, int ldz, double *red, pn2_stream_t stream) {
-    PN2_CHECK_ARG(dOut && out && Y && affine && dZ && red && P > 0 && C > 0);
+                        int64_t P, int C, float *dZ, int ldz, double *red, const pn2_bn_coef_tail *tail, pn2_stream_t stream) {
+    PN2_CHECK_ARG(dOut && out && Y && affine && dZ && red && P > 0 && C > 0 && coef_tail_ok(tail, red));
     int64_t gy = pn2_cdiv(P, 4 * 16);
     if (gy > 512) gy = 512;
     hipLaunchKernelGGL(relu_bwd_reduce_kernel, dim3((unsigned)pn2_cdiv(C, 64), (unsigned)gy), dim3(256), 0, pn2_s(stream), dOut,
-                       ldo, out, Y, ldy, affine, (C + 3) & ~3, P, C, dZ, ldz, red);
+                       ldo, out, Y, ldy, affine, (C + 3) & ~3, P, C, dZ, ldz, red, make_coef_tail(tail, P));
     return pn2_launch_status();
 }
 
@@ -994,8 +1023,10 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
 
 int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
-                      double *prev_red, int64_t P, int K, int N, pn2_stream_t stream) {
-    PN2_CHECK_ARG(Y && coef && W && dXout && P > 0 && K > 0 && N > 0);
+                      double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail, pn2_stream_t stream) {
+    PN2_CHECK_ARG(Y && coef && W && dXout && P > 0 && K > 0 && N > 0 && coef_tail_ok(prev_tail, prev_red) &&
+                  (prev_tail == nullptr || prev_Y != nullptr));
+    const CoefTail ct = make_coef_tail(prev_tail, P);
     PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
     PN2_CHECK_ARG(ldw >= N && ldy % 4 == 0 && ldy >= round4(K) && ldxo % 4 == 0 && ldxo >= round4(N));
     const BMat bm = make_bmat(W, ldw, K, N);
@@ -1007,14 +1038,14 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
         LoadDyDense ld{dZ, ldz, Y, ldy, coef, ldc};
         if (prev_Y)
             return dispatch_nt<true>(ld, bm, P, K4, N,
-                                     EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red}, s);
+                                     EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct}, s);
         return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= K4);
     LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc};
     if (prev_Y)
         return dispatch_nt<true>(ld, bm, P, K4, N,
-                                 EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red}, s);
+                                 EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct}, s);
     return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
 }
 

@@ -17,6 +17,7 @@ Layout notes
     reference's ``[B, C, K, S]`` permute (pointnet_util.py:194) never happens.
 """
 import contextlib
+import ctypes
 import os
 
 import numpy as np
@@ -369,6 +370,11 @@ class _InterpCat(torch.autograd.Function):
 # --------------------------------------------------------------------------------------- shared MLP
 
 _DIRECT_GRADS = False
+# Statistics -> affine block / backward coefficients inside the kernel that finishes the reduction (the "tails" of
+# include/pn2.h) instead of pn2_bn_finalize / pn2_bn_bwd_coef launches.  Measured on MI355X: no gain (MSG-SemSeg
+# B=16 9.257 vs 9.245 ms, B=1 2.29 vs 2.33 ms; SSG 3.833 vs 3.827 ms) -- the last workgroup's ticket + device-scope
+# reads cost the same ~5 us as the dependent launch they replace -- so the stand-alone launches stay the default.
+FUSED_BN_TAILS = os.environ.get("PN2_FUSED_BN_TAILS", "0") == "1"
 _REPL = 8                         # PN2_STAT_REPLICAS of include/pn2.h
 _MALL_CHUNK_BYTES = 1 << 62       # row-chunked dgrad+wgrad pairing is OFF: measured 10.9 -> 13.1 ms/step at 96 MiB chunks
                                   # (per-launch fixed costs beat the Infinity-Cache hits); kept as a tuning knob
@@ -423,10 +429,11 @@ class _SharedMLP(torch.autograd.Function):
         chans = [c_in] + [flat[7 * l].shape[0] for l in range(L)]
         n_stats = _REPL * 2 * sum(chans[1:]) if training else 0
         n_aff = 4 * sum(_r4(c) for c in chans[1:])
-        zero_bytes = _zeros_small(8 * n_stats + 4 * n_aff, dev)
+        zero_bytes = _zeros_small(8 * n_stats + 4 * n_aff + 4 * L, dev)
         stats = zero_bytes[:8 * n_stats].view(torch.float64) if training else None
         Ys, affs = [], []
-        aff_all = zero_bytes[8 * n_stats:].view(torch.float32)
+        aff_all = zero_bytes[8 * n_stats:8 * n_stats + 4 * n_aff].view(torch.float32)
+        tickets = zero_bytes.data_ptr() + 8 * n_stats + 4 * n_aff      # one uint32 per fused BatchNorm tail
         aff_off = 0
         x, ldx, x_aff, off = rows, rows.shape[-1], None, 0
         for l in range(L):
@@ -434,6 +441,13 @@ class _SharedMLP(torch.autograd.Function):
             co, ci = chans[l + 1], chans[l]
             y = _empty_rows(P, co, dev)
             st_l = stats[off:off + _REPL * 2 * co] if training else None
+            aff = aff_all[aff_off:aff_off + 4 * _r4(co)]
+            aff_off += 4 * _r4(co)
+            eps, mom = bn_cfg[l]
+            fin = None
+            if training and FUSED_BN_TAILS:     # the producer of the statistics also turns them into the affine block
+                fin = ctypes.byref(_lib.BnFinalizeTail(tickets + 4 * l, _p(gamma), _p(beta), eps, mom, _p(rmean), _p(rvar),
+                                                       _p(nbt), _p(aff)))
             if l == 0 and geom is not None:
                 # the kernels read the xyz / feature columns straight out of the [co, 3+D] weight (pitch ci): no copies
                 w_ptr = _contig_weight(w).data_ptr()
@@ -444,17 +458,15 @@ class _SharedMLP(torch.autograd.Function):
                     feat = torch.nn.functional.pad(feat, (0, ldd - gD))
                 zf = _empty_rows(gB * gN, co, dev)
                 _check(lib.pn2_conv1x1_fwd(_p(feat), ldd, None, wf_ptr, ci, _p(b), _p(zf), zf.shape[1], gB * gN, gD, co,
-                                           None, st), "pn2_conv1x1_fwd")
+                                           None, None, st), "pn2_conv1x1_fwd")
                 _check(lib.pn2_group_affine_fwd(_p(zf), zf.shape[1], _p(g_xyz), _p(g_new), _p(g_idx), wx_ptr, ci, gB, gN, gS,
-                                                gK, co, _p(y), y.shape[1], _p(st_l), st), "pn2_group_affine_fwd")
+                                                gK, co, _p(y), y.shape[1], _p(st_l), fin, st), "pn2_group_affine_fwd")
             else:
                 _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(_contig_weight(w)), ci, _p(b), _p(y), y.shape[1], P, ci,
-                                           co, _p(st_l), st), "pn2_conv1x1_fwd")
-            aff = aff_all[aff_off:aff_off + 4 * _r4(co)]
-            aff_off += 4 * _r4(co)
-            eps, mom = bn_cfg[l]
-            _check(lib.pn2_bn_finalize(_p(st_l), P, co, _p(gamma), _p(beta), eps, mom, int(training),
-                                       _p(rmean), _p(rvar), _p(nbt), _p(aff), st), "pn2_bn_finalize")
+                                           co, _p(st_l), fin, st), "pn2_conv1x1_fwd")
+            if fin is None:
+                _check(lib.pn2_bn_finalize(_p(st_l), P, co, _p(gamma), _p(beta), eps, mom, int(training),
+                                           _p(rmean), _p(rvar), _p(nbt), _p(aff), st), "pn2_bn_finalize")
             Ys.append(y)
             affs.append(aff)
             x, ldx, x_aff = y, y.shape[1], aff
@@ -496,44 +508,59 @@ class _SharedMLP(torch.autograd.Function):
         n_red = _REPL * 2 * sum(chans[1:])
         direct = _direct_ok([ctx.params[7 * l + j] for l in range(L) for j in (0, 2, 3)])
         sizes = [4 * _r4(chans[l + 1]) + (0 if direct else chans[l + 1] * chans[l] + chans[l + 1]) for l in range(L)]
-        zero_bytes = _zeros_small(8 * n_red + 4 * sum(sizes), dev)
+        zero_bytes = _zeros_small(8 * n_red + 4 * sum(sizes) + 4 * L, dev)
         red = zero_bytes[:8 * n_red].view(torch.float64)
+        tickets = zero_bytes.data_ptr() + 8 * n_red + 4 * sum(sizes)   # one uint32 per fused BatchNorm tail
         offs = np.cumsum([0] + [_REPL * 2 * c for c in chans[1:]])
         K = pool if pool else 1
         G = P // K
+        flat = ctx.params
+        # zeroed scratch: BN-backward coefficient blocks (+ the gradient tensors in autograd mode)
+        zbuf = zero_bytes[8 * n_red:8 * n_red + 4 * sum(sizes)].view(torch.float32)
+        zoff = np.cumsum([0] + sizes)
+        outs = []                                    # per layer: coef, dgamma, dbeta, dW, dbias
+        for l in range(L):
+            co, ci = chans[l + 1], chans[l]
+            z0 = int(zoff[l])
+            coef = zbuf[z0:z0 + 4 * _r4(co)]
+            if direct:
+                outs.append((coef, flat[7 * l + 2].grad, flat[7 * l + 3].grad, flat[7 * l].grad, None))
+            else:
+                outs.append((coef, torch.empty(co, device=dev, dtype=torch.float32),
+                             torch.empty(co, device=dev, dtype=torch.float32),
+                             zbuf[z0 + 4 * _r4(co):z0 + 4 * _r4(co) + co * ci].view(co, ci),
+                             zbuf[z0 + 4 * _r4(co) + co * ci:z0 + 4 * _r4(co) + co * ci + co]))
+        coef_done = [False] * L
+
+        def coef_tail(l):
+            """The producer of layer l's reductions also turns them into coef_l / dgamma_l / dbeta_l (fused tail)."""
+            if not FUSED_BN_TAILS:
+                return None
+            coef_done[l] = True
+            return ctypes.byref(_lib.BnCoefTail(tickets + 4 * l, _p(gammas[l]), _p(affs[l]), int(training), _p(outs[l][0]),
+                                                _p(outs[l][1]), _p(outs[l][2]), int(direct)))
         dZ = None
         red_L = red[offs[L - 1]:offs[L]]
         dzp = None
         if pool:
             dzp = torch.empty_like(out)          # dOut masked by out > 0: the pooled form of dZ_L the GEMM loaders read
             _check(lib.pn2_pool_bwd_reduce(_p(grad_out), ldo, _p(out), _p(arg), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]),
-                                           G, K, cl, _p(dzp), _p(red_L), st), "pn2_pool_bwd_reduce")
+                                           G, K, cl, _p(dzp), _p(red_L), coef_tail(L - 1), st), "pn2_pool_bwd_reduce")
         else:
             dZ = _empty_rows(P, cl, dev)
             _check(lib.pn2_relu_bwd_reduce(_p(grad_out), ldo, _p(out), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), P, cl,
-                                           _p(dZ), dZ.shape[1], _p(red_L), st), "pn2_relu_bwd_reduce")
+                                           _p(dZ), dZ.shape[1], _p(red_L), coef_tail(L - 1), st), "pn2_relu_bwd_reduce")
         grads = [None] * (7 * L)
         d_rows = None
-        flat = ctx.params
-        # zeroed scratch: BN-backward coefficient blocks (+ the gradient tensors in autograd mode)
-        zbuf = zero_bytes[8 * n_red:].view(torch.float32)
-        zoff = np.cumsum([0] + sizes)
         for l in range(L - 1, -1, -1):
             co, ci = chans[l + 1], chans[l]
             y, aff = Ys[l], affs[l]
             ldy = y.shape[1]
-            z0 = int(zoff[l])
-            coef = zbuf[z0:z0 + 4 * _r4(co)]
-            w_p, g_p, b_p = flat[7 * l], flat[7 * l + 2], flat[7 * l + 3]
-            if direct:
-                dgamma, dbeta, dW, dbias = g_p.grad, b_p.grad, w_p.grad, None
-            else:
-                dgamma = torch.empty(co, device=dev, dtype=torch.float32)
-                dbeta = torch.empty(co, device=dev, dtype=torch.float32)
-                dW = zbuf[z0 + 4 * _r4(co):z0 + 4 * _r4(co) + co * ci].view(co, ci)
-                dbias = zbuf[z0 + 4 * _r4(co) + co * ci:z0 + 4 * _r4(co) + co * ci + co]
-            _check(lib.pn2_bn_bwd_coef(_p(red[offs[l]:offs[l + 1]]), P, co, _p(gammas[l]), _p(aff), int(training),
-                                       _p(coef), _p(dgamma), _p(dbeta), int(direct), st), "pn2_bn_bwd_coef")
+            coef, dgamma, dbeta, dW, dbias = outs[l]
+            w_p = flat[7 * l]
+            if not coef_done[l]:
+                _check(lib.pn2_bn_bwd_coef(_p(red[offs[l]:offs[l + 1]]), P, co, _p(gammas[l]), _p(aff), int(training),
+                                           _p(coef), _p(dgamma), _p(dbeta), int(direct), st), "pn2_bn_bwd_coef")
             if not direct:
                 grads[7 * l + 1], grads[7 * l + 2], grads[7 * l + 3] = dbias, dgamma, dbeta
             if l == 0 and ctx.geom is not None:
@@ -575,11 +602,11 @@ class _SharedMLP(torch.autograd.Function):
                     c_dx = dx.data_ptr() + 4 * r0 * dx.shape[1]
                     if l > 0:
                         _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, ci, c_x, ldx, _p(x_aff), c_dx,
-                                                     dx.shape[1], _p(red[offs[l - 1]:offs[l]]), rn, co, ci, st),
-                               "pn2_conv1x1_dgrad")
+                                                     dx.shape[1], _p(red[offs[l - 1]:offs[l]]), rn, co, ci,
+                                                     coef_tail(l - 1) if chunk == P else None, st), "pn2_conv1x1_dgrad")
                     else:
                         _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, ci, None, 0, None, c_dx,
-                                                     ldx, None, rn, co, ci, st), "pn2_conv1x1_dgrad")
+                                                     ldx, None, rn, co, ci, None, st), "pn2_conv1x1_dgrad")
                 _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
                                              None if training else _p(dbias), rn, co, ci, st), "pn2_conv1x1_wgrad")
             if not direct:
@@ -616,7 +643,7 @@ class _SharedMLP(torch.autograd.Function):
             wf_ptr = _contig_weight(w).data_ptr() + (12 if g_first else 0)      # feature columns of the [co, 3+D] weight
             dF = _empty_rows(B * N, D, dev)
             _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), wf_ptr, 3 + D, None, 0, None,
-                                         _p(dF), ldd, None, B * N, co, D, st), "pn2_conv1x1_dgrad")
+                                         _p(dF), ldd, None, B * N, co, D, None, st), "pn2_conv1x1_dgrad")
             d_feats = (dF[:, :D] if ldd != D else dF).reshape(B, N, D)
         return d_feats, (dW.view_as(w) if w_grad is None else None)
 
@@ -636,7 +663,7 @@ class _Conv1x1(torch.autograd.Function):
         ci = weight.numel() // co
         y = _empty_rows(P, co, rows.device)
         _check(lib.pn2_conv1x1_fwd(_p(rows), ldx, None, _p(_contig_weight(weight)), ci, _p(bias), _p(y), y.shape[1], P, ci, co,
-                                   None, st), "pn2_conv1x1_fwd")
+                                   None, None, st), "pn2_conv1x1_fwd")
         ctx.save_for_backward(rows, weight)
         ctx.dims = (P, ci, co, ldx, y.shape[1])
         return y[:, :co] if y.shape[1] != co else y
@@ -663,7 +690,7 @@ class _Conv1x1(torch.autograd.Function):
             d_rows = torch.empty(P, ldx, device=dev, dtype=torch.float32)     # pad lanes written (0) by the GEMM
             _check(lib.pn2_conv1x1_dgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(_contig_weight(weight)), ci,
                                          None, 0, None,
-                                         _p(d_rows), ldx, None, P, co, ci, st), "pn2_conv1x1_dgrad")
+                                         _p(d_rows), ldx, None, P, co, ci, None, st), "pn2_conv1x1_dgrad")
         return d_rows, dW.view_as(weight), db
 
 

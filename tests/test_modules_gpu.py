@@ -308,3 +308,45 @@ def test_cfg2_full_size_set_abstraction_vs_oracle(dev):
         if "conv" in n and n.endswith("bias"):
             continue
         assert relmax(q.grad.cpu().numpy(), p.grad.numpy()) <= GRAD_TOL, n
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_fused_bn_tails_match_standalone_launches(dev, direct, monkeypatch):
+    """pn2_bn_finalize_tail / pn2_bn_coef_tail (statistics -> affine block / coefficients inside the producer kernel)
+    against the stand-alone pn2_bn_finalize / pn2_bn_bwd_coef launches: same arithmetic, so the same network state
+    after two training steps (running statistics, num_batches_tracked) and the same gradients up to the
+    atomics-order noise of the reductions."""
+    from pointnet12_amd import parallel
+    g = golden("g6_nets.npz")
+    pts = torch.from_numpy(g["points"]).to(dev)
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    res = []
+    try:
+        for fused in (False, True):
+            monkeypatch.setattr(U, "FUSED_BN_TAILS", fused)
+            torch.manual_seed(int(g["init_seed"]))
+            net = M.PointNet2SemSegMsg(13, 6)
+            net.drop1.p = 0.0
+            net.to(dev).train()
+            bucket = parallel.FlatGradBucket(net, direct=direct)
+            losses = []
+            for _ in range(2):
+                bucket.zero()
+                torch.manual_seed(5)
+                lp = net(pts)
+                loss = F.nll_loss(lp.reshape(-1, 13), labels.reshape(-1))
+                loss.backward()
+                losses.append(float(loss))
+            bufs = {k: v.clone() for k, v in net.named_buffers()}
+            res.append((losses, bucket.flat.clone(), bufs))
+    finally:
+        U.set_direct_grad_accumulation(False)
+    (la, ga, ba), (lb, gb, bb) = res
+    assert np.allclose(la, lb, rtol=0, atol=2e-5), (la, lb)
+    assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
+    assert float((ga - gb).abs().max()) <= 2e-2 * float(ga.abs().max())
+    for k in ba:
+        if k.endswith("num_batches_tracked"):
+            assert int(ba[k]) == int(bb[k]) == 2, k
+        else:
+            assert float((ba[k] - bb[k]).abs().max()) <= 1e-5 * max(1.0, float(ba[k].abs().max())), k
