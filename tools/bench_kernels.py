@@ -19,7 +19,7 @@ from pointnet12_amd._lib import ptr as p
 FWD = [(1048576, 9, 64), (1048576, 64, 96), (1048576, 96, 128), (524288, 64, 64), (524288, 64, 128), (262144, 323, 128),
        (262144, 128, 196), (262144, 196, 256), (131072, 323, 128), (131072, 128, 256), (262144, 32, 64), (65536, 128, 128)]
 # backward shapes: (P, C_l, C_{l-1}, pooled K or 0)
-BWD = [(1048576, 128, 96, 128), (1048576, 96, 64, 0), (262144, 256, 196, 128), (262144, 196, 128, 0), (262144, 128, 323, 0),
+BWD = [(1048576, 64, 9, 0), (524288, 64, 9, 0), (262144, 32, 9, 0), (1048576, 128, 96, 128), (1048576, 96, 64, 0), (262144, 256, 196, 128), (262144, 196, 128, 0), (262144, 128, 323, 0),
        (524288, 128, 64, 64), (524288, 64, 64, 0), (131072, 256, 128, 64), (65536, 128, 128, 0)]
 
 
@@ -76,7 +76,7 @@ def main():
             aff = affine(K) if K > 12 else None
 
             def fn():
-                rc = lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), st)
+                rc = lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), None, st)
                 assert rc == 0
             report("fwd", (P, K, N), timeit(fn, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
             del X, Y
@@ -104,14 +104,15 @@ def main():
 
                 def fn():
                     rc = lib.pn2_conv1x1_dgrad(*dz, p(Y), r4(Cl), p(coef), p(Wt), Cp, p(Yp), r4(Cp), p(affp), p(dX), r4(Cp),
-                                               p(red), P, Cl, Cp, st)
+                                               p(red), P, Cl, Cp, None, st)
                     assert rc == 0
                 report("dgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
             else:
                 dW = torch.zeros(Cl, Cp, device=dev)
 
                 def fn():
-                    rc = lib.pn2_conv1x1_wgrad(*dz, p(Y), r4(Cl), p(coef), p(Yp), r4(Cp), p(affp), p(dW), Cp, None, P, Cl, Cp, st)
+                    rc = lib.pn2_conv1x1_wgrad(*dz, p(Y), r4(Cl), p(coef), p(Yp), r4(Cp), p(affp) if Cp >= 16 else None, p(dW), Cp,
+                                               None, P, Cl, Cp, st)
                     assert rc == 0
                 report("wgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + P * Cp))
 
