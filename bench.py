@@ -85,6 +85,10 @@ def build_net(workload, dev, npoint_scale=1):
     return net.to(dev).train()
 
 
+# SURVEY.md section 8(d), per input point: (ALG_BYTES, FLOP) of one forward + backward step at N = 4096 points per cloud
+STEP_MODEL = {"msg": (225604, 464.5e9 / 65536), "ssg": (55689, 92.8e9 / 65536), "sa": (20720, 5.28e9 / 32768)}
+
+
 def make_step(workload, net, pts, labels, bucket):
     from pointnet12_amd.loss import nll_loss      # F.nll_loss (semseg.py:143) on the HIP library
 
@@ -242,7 +246,7 @@ def main():
         # are issued one after the other here (no parallel MSG scale streams), so a launch's duration
         # is its own and not that of whatever shared the chip with it in the timed, overlapped step above.
         from pointnet12_amd import pointnet_util as _pu
-        prof_steps = 3
+        prof_steps = 5
         _saved_streams = _pu.MSG_SCALE_STREAMS
         _pu.MSG_SCALE_STREAMS = False
         with _lib.call_profile() as calls:           # eager launches: every C-ABI call bracketed by HIP events
@@ -254,8 +258,12 @@ def main():
             torch.cuda.synchronize()
             agg = {}
             ncall = len(calls) // prof_steps
+            # a launch's duration = the median over the prof_steps passes (every pass issues the same launches in the
+            # same order); eager issue leaves idle gaps in which the clocks wander, single samples are +-10 %
+            raw = [e0.elapsed_time(e1) for (_, _, e0, e1) in calls]
+            med = [float(np.median([raw[s_ * ncall + j] for s_ in range(prof_steps)])) for j in range(ncall)]
             for i, (name, a, e0, e1) in enumerate(calls):
-                ms = e0.elapsed_time(e1)
+                ms = med[i % ncall]
                 fl, by = algorithmic_work(name, a)
                 if args.detail and i >= len(calls) - ncall:
                     dims = [x for x in a if isinstance(x, int) and 0 < x < (1 << 31)][:8]
@@ -312,6 +320,16 @@ def main():
                        "grad_bucket_bytes": bucket.nbytes},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
+        # whole-step fractions on SURVEY.md section 8(d)'s byte / flop model (I/O + five passes over every pre-BN
+        # activation; 6 x forward MACs), per GPU: the headline the north star asks for next to the absolute number
+        model = STEP_MODEL.get(args.workload)
+        if model and n_points == 4096 and getattr(args, "npoint_scale", 1) in (1, None):
+            per_gpu = value / world
+            line["step_roofline"] = {
+                "alg_bytes_per_point": model[0], "flop_per_point": model[1],
+                "hbm_GBs": round(per_gpu * model[0] / 1e9, 1), "hbm_frac": round(per_gpu * model[0] / (HBM_PEAK_GBS * 1e9), 4),
+                "mfma_TFs": round(per_gpu * model[1] / 1e12, 2), "mfma_frac": round(per_gpu * model[1] / (F32_MFMA_PEAK_TF * 1e12), 4),
+                "model": "SURVEY.md 8(d): ALG_BYTES = I/O + 5 x pre-BN activations, FLOP = 6 x forward MACs"}
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(line))

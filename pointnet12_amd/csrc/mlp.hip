@@ -684,6 +684,110 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
     }
 }
 
+// Weight gradient of a FIRST layer, dW[M, N <= 16] += sum_p dY[p, m] * X[p, n] (X = the grouped input rows, 3+D = 9..12
+// columns).  Two flops per loaded byte: nothing for the matrix cores to do, the job is streaming dZ and Y once at
+// HBM speed.  A lane owns one output channel m (the dZ / Y rows are read as 256-byte segments), the X row of a
+// position is one broadcast request per row-slot, and each thread keeps its N accumulators in registers over four
+// independent rows per trip.  The 128x32-tile MFMA kernel runs these shapes at 1.1-3.2 TB/s (three quarters of
+// its loader threads idle on M = 32..64); this one is bounded by the memory system.
+template <int NQ>
+__global__ __launch_bounds__(256, 2) void wgrad_skinny_kernel(const float *__restrict__ dZ, int ldz,
+                                                              const float *__restrict__ Y, int ldy,
+                                                              const float *__restrict__ coef, int ldc,
+                                                              const float *__restrict__ X, int ldx, int64_t P, int M, int N,
+                                                              int cg_log2, float *__restrict__ dW, int lddw,
+                                                              float *__restrict__ dbias) {
+    constexpr int NA = NQ * 4;                                // accumulators per channel (+1 for the bias sum)
+    __shared__ float red[4 * 64 * 4 * (NA + 1)];              // [wave][column group (<= 64)][4 channels][NA + 1]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int CG = 1 << cg_log2, RS = 256 >> cg_log2;         // float4 column groups per row; rows per workgroup pass
+    const int cq = t & (CG - 1), slot = t >> cg_log2;
+    const int m = (blockIdx.y * CG + cq) * 4;                 // first of this lane's four output channels
+    const bool live = m < M;                                  // (pitches are multiples of 4: a live float4 is in-row)
+    const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+    const float4 c0 = ld4(live ? coef + m : zp), q1 = ld4(live ? coef + ldc + m : zp),
+                 q0 = ld4(live ? coef + 2 * ldc + m : zp), mu = ld4(live ? coef + 3 * ldc + m : zp);
+    const DyParams prm{c0, q1, q0, mu};
+    float acc[4][NA + 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e <= NA; ++e) acc[c][e] = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * RS;
+    for (int64_t p0 = (int64_t)blockIdx.x * RS + slot; p0 < P; p0 += 4 * stride) {
+        float4 dz[4], yv[4], x[4][NQ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                         // 4 independent rows: (2 + NQ) x 16 B per lane each
+            const int64_t p = p0 + u * stride;
+            const bool v = p < P && live;
+            dz[u] = ld4(v ? dZ + p * ldz + m : zp);
+            yv[u] = ld4(v ? Y + p * ldy + m : zp);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) x[u][q] = ld4(v ? X + p * ldx + q * 4 : zp);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool v = p0 + u * stride < P && live;
+            const float4 d4 = v ? dy_from(dz[u], yv[u], prm) : kZero4;
+            const float dy[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c][NA] += dy[c];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    acc[c][q * 4 + 0] = __builtin_fmaf(dy[c], x[u][q].x, acc[c][q * 4 + 0]);
+                    acc[c][q * 4 + 1] = __builtin_fmaf(dy[c], x[u][q].y, acc[c][q * 4 + 1]);
+                    acc[c][q * 4 + 2] = __builtin_fmaf(dy[c], x[u][q].z, acc[c][q * 4 + 2]);
+                    acc[c][q * 4 + 3] = __builtin_fmaf(dy[c], x[u][q].w, acc[c][q * 4 + 3]);
+                }
+            }
+        }
+    }
+    // fold the row slots: inside a wave with xor-shuffles (lanes cq, cq + CG, ...), across the four waves through LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e <= NA; ++e) {
+            float v = acc[c][e];
+            for (int off = CG; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            acc[c][e] = v;
+        }
+    const int lanes_cg = CG < 64 ? CG : 64;                   // distinct column groups inside one wave
+    if (lane < lanes_cg) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e <= NA; ++e) red[((wave * 64 + lane) * 4 + c) * (NA + 1) + e] = acc[c][e];
+    }
+    __syncthreads();
+    // CG <= 64: every wave holds all column groups -> add the 4 waves; CG > 64 cannot happen (M <= 256 per grid.y slab)
+    for (int i = t; i < lanes_cg * 4 * (NA + 1); i += 256) {
+        const int e = i % (NA + 1), c = (i / (NA + 1)) & 3, g = i / (4 * (NA + 1));
+        const int mm = (blockIdx.y * CG + g) * 4 + c;
+        if (mm >= M) continue;
+        float sum = 0.f;
+        for (int w = 0; w < 4; ++w) sum += red[((w * 64 + g) * 4 + c) * (NA + 1) + e];
+        if (e < N) atomicAdd(dW + (int64_t)mm * lddw + e, sum);
+        else if (e == NA && dbias != nullptr) atomicAdd(dbias + mm, sum);
+    }
+}
+
+template <int NQ>
+int launch_skinny(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, int ldc, const float *X, int ldx,
+                  int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
+    int cg_log2 = 3;                                          // 8 column groups = 32 channels at least
+    while ((4 << cg_log2) < M && cg_log2 < 6) ++cg_log2;      // up to 64 groups = 256 channels per grid.y slab
+    const int CG = 1 << cg_log2, RS = 256 >> cg_log2;
+    const unsigned gy = (unsigned)pn2_cdiv(M, 4 * CG);
+    int64_t gx = pn2_cdiv(P, (int64_t)RS * 16);
+    const int64_t cap = (int64_t)pn2_num_cus() * 2 / gy;      // two resident workgroups per CU; each ends with M*N atomics
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((wgrad_skinny_kernel<NQ>), dim3((unsigned)gx, gy), dim3(256), 0, s, dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N,
+                       cg_log2, dW, lddw, dbias);
+    return pn2_launch_status();
+}
+
 template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad>
 int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
     unsigned tm = (unsigned)pn2_cdiv(M, BM), tn = (unsigned)pn2_cdiv(N, BN);
@@ -1059,6 +1163,15 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     hipStream_t s = pn2_s(stream);
     if (dZ) {
         PN2_CHECK_ARG(ldz % 4 == 0 && ldz >= round4(M));
+        static const int skinny = pn2_env_int("PN2_WGRAD_SKINNY", 1);
+        if (skinny && x_affine == nullptr && N <= 16 && P >= 4096) {     // first layers: stream dZ / Y once, no MFMA
+            switch ((N + 3) / 4) {
+                case 1: return launch_skinny<1>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
+                case 2: return launch_skinny<2>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
+                case 3: return launch_skinny<3>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
+                default: return launch_skinny<4>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
+            }
+        }
         LoadDyDense dy{dZ, ldz, Y, ldy, coef, ldc};
         if (x_affine) return dispatch_tn(dy, LoadBnRelu{X, ldx, x_affine}, P, M, N, dW, lddw, dbias, s);
         return dispatch_tn(dy, LoadPlain{X, ldx}, P, M, N, dW, lddw, dbias, s);
