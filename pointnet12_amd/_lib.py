@@ -17,7 +17,7 @@ _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_floa
 SIGNATURES = {
     "pn2_version": (_i, []),
     "pn2_error_string": (ctypes.c_char_p, [_i]),
-    "pn2_fps_workspace_bytes": (_i64, [_i, _i]),
+    "pn2_fps_workspace_bytes": (_i64, [_i, _i, _i]),
     "pn2_fps": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "pn2_square_distance": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -7,6 +7,7 @@
 //                  d = ((-2*dot) + n(query)) + n(candidate)
 // so every fused step below is an explicit __builtin_fmaf and nothing else may contract.
 #include "pn2_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -142,6 +143,91 @@ __global__ __launch_bounds__(1024) void fps_large_kernel(const float *__restrict
     }
 }
 
+// N > 16384: ONE cloud spread over W workgroups (grid (W, B), 1024 threads, PPT = 8 or 16 points per thread in
+// registers, workgroup w owns the points [w * 1024 * PPT, (w + 1) * 1024 * PPT)).  An iteration is the single-
+// workgroup iteration plus one exchange: the thread that owns the workgroup's best point publishes
+// {key, x, y, z} into the slot (iteration, w) of a zero-initialised table, and wave 0 of every workgroup polls the W
+// slots of that iteration until all 4 W words are non-zero (the xyz words carry the iteration number in their
+// upper half, the key is never 0).  All accesses are relaxed agent-scope atomics, served at the device's point of
+// coherence -- no fences, no second pass over memory; the winner's coordinates travel with the key, so no
+// dependent load follows.  The single-workgroup fallback below re-reads the whole cloud and its distance array
+// from L2 every iteration: 13 us per iteration at N = 65 536 against ~3 us here.
+// All W * B workgroups must be resident at once (they spin on each other): the host caps W * B.
+struct FpsSlot { unsigned long long w[4]; };               // key, x | tag, y | tag, z | tag
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict__ xyz, int N,
+                                                        const int64_t *__restrict__ start, int npoint,
+                                                        int64_t *__restrict__ out, FpsSlot *__restrict__ table) {
+    __shared__ unsigned long long slots[2][16];
+    __shared__ float4 bcast[2];
+    const int W = gridDim.x, w = blockIdx.x, b = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *p = xyz + (size_t)b * N * 3;
+    const int base = w * 1024 * PPT;
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = base + t + i * 1024;
+        if (j < N) { px[i] = p[3 * j]; py[i] = p[3 * j + 1]; pz[i] = p[3 * j + 2]; md[i] = 1e10f; }
+        else { px[i] = py[i] = pz[i] = 0.f; md[i] = 0.f; }
+    }
+    int far = (int)start[b];
+    float cx = p[3 * far], cy = p[3 * far + 1], cz = p[3 * far + 2];
+    int64_t *o = out + (size_t)b * npoint;
+    FpsSlot *tab = table + (size_t)b * npoint * W;
+    for (int it = 0; it < npoint; ++it) {
+        if (w == 0 && t == 0) o[it] = far;
+        if (it == npoint - 1) break;                          // the last sample needs no successor
+        float bm = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+        int bj = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int j = base + t + i * 1024;
+            const float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            const float d = (xx + yy) + zz;
+            md[i] = d < md[i] ? d : md[i];
+            if (j < N && md[i] > bm) { bm = md[i]; bj = j; bx = px[i]; by = py[i]; bz = pz[i]; }
+        }
+        const unsigned long long mine = bm < 0.f ? 0ull
+                                                 : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
+        unsigned long long key = pn2_wave_max_u64_dpp(mine);
+        if (lane == 0) slots[it & 1][wave] = key;
+        __syncthreads();
+        key = pn2_row_max_u64(slots[it & 1][lane & 15]);     // 16 waves: every thread now holds the workgroup's best
+        FpsSlot *row = tab + (size_t)it * W;
+        if (mine == key && mine != 0ull) {                    // exactly one thread (indices are unique): publish
+            const unsigned long long tag = (unsigned long long)(unsigned)(it + 1) << 32;
+            __hip_atomic_exchange(&row[w].w[1], tag | __float_as_uint(bx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_exchange(&row[w].w[2], tag | __float_as_uint(by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_exchange(&row[w].w[3], tag | __float_as_uint(bz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_exchange(&row[w].w[0], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (wave == 0) {                                      // lanes 0 .. 4W-1 poll one word each
+            const bool act = lane < 4 * W;
+            const unsigned long long *src = &row[lane >> 2].w[lane & 3];
+            unsigned long long v = 1ull;
+            do {
+                if (act) v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while (__ballot(v == 0ull) != 0ull);
+            const unsigned long long best = pn2_wave_max_u64_dpp((act && (lane & 3) == 0) ? v : 0ull);
+            const unsigned long long hit = __ballot(act && (lane & 3) == 0 && v == best);
+            const int src_lane = __builtin_ctzll(hit);        // lowest lane = lowest w; keys are unique anyway
+            const unsigned lo = (unsigned)v;
+            const float wx = __uint_as_float((unsigned)__shfl((int)lo, src_lane + 1, 64));
+            const float wy = __uint_as_float((unsigned)__shfl((int)lo, src_lane + 2, 64));
+            const float wz = __uint_as_float((unsigned)__shfl((int)lo, src_lane + 3, 64));
+            if (lane == 0)
+                bcast[it & 1] = make_float4(wx, wy, wz, __uint_as_float(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull)));
+        }
+        __syncthreads();
+        const float4 c = bcast[it & 1];
+        cx = c.x; cy = c.y; cz = c.z;
+        far = (int)__float_as_uint(c.w);
+    }
+}
+
 template <int THREADS, int PPT>
 int launch_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, hipStream_t s) {
     constexpr int NW = THREADS / 64;
@@ -272,7 +358,25 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float *__res
 
 extern "C" {
 
-int64_t pn2_fps_workspace_bytes(int B, int N) { return N > 16384 ? (int64_t)B * N * 4 : 0; }
+// Cooperative plan for N > 16384: PPT points per thread and W workgroups per cloud, or W = 0 (single-workgroup
+// fallback) when the W * B workgroups could not all be resident or a cloud would need more than 16 of them.
+static void fps_coop_plan(int B, int N, int *ppt, int *W) {
+    *ppt = 0; *W = 0;
+    if (N <= 16384) return;
+    static const int enabled = [] { const char *e = getenv("PN2_FPS_COOP"); return e ? atoi(e) : 1; }();
+    if (!enabled) return;
+    for (int p = 8; p <= 16; p *= 2) {
+        const int w = (int)pn2_cdiv(N, 1024 * p);
+        if (w <= 16 && (int64_t)w * B <= 128) { *ppt = p; *W = w; return; }
+    }
+}
+
+int64_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
+    int ppt, W;
+    fps_coop_plan(B, N, &ppt, &W);
+    if (W) return (int64_t)B * npoint * W * (int64_t)sizeof(FpsSlot);
+    return N > 16384 ? (int64_t)B * N * 4 : 0;
+}
 
 int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out_idx, void *work,
             pn2_stream_t stream) {
@@ -288,6 +392,17 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, start, npoint, out_idx, s);
     PN2_CHECK_ARG(work != nullptr);
+    int ppt, W;
+    fps_coop_plan(B, N, &ppt, &W);
+    if (W) {
+        FpsSlot *table = reinterpret_cast<FpsSlot *>(work);
+        if (hipMemsetAsync(table, 0, (size_t)B * npoint * W * sizeof(FpsSlot), s) != hipSuccess) return PN2_ELAUNCH;
+        if (ppt == 8)
+            hipLaunchKernelGGL(fps_coop_kernel<8>, dim3(W, B), dim3(1024), 0, s, xyz, N, start, npoint, out_idx, table);
+        else
+            hipLaunchKernelGGL(fps_coop_kernel<16>, dim3(W, B), dim3(1024), 0, s, xyz, N, start, npoint, out_idx, table);
+        return pn2_launch_status();
+    }
     hipLaunchKernelGGL(fps_large_kernel, dim3(B), dim3(1024), 0, s, xyz, N, start, npoint, out_idx, (float *)work);
     return pn2_launch_status();
 }

@@ -263,7 +263,7 @@ def farthest_point_sample(xyz, npoint, start=None):
     start = start.to(device=xyz.device, dtype=torch.int64).contiguous()
     out = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
     lib = _lib.load()
-    nbytes = lib.pn2_fps_workspace_bytes(B, N)
+    nbytes = lib.pn2_fps_workspace_bytes(B, N, npoint)
     work = torch.empty(nbytes, device=xyz.device, dtype=torch.uint8) if nbytes else None
     _check(lib.pn2_fps(_p(xyz), B, N, _p(start), npoint, _p(out), _p(work), _lib.stream()), "pn2_fps")
     return _taped(lambda: out)

@@ -34,8 +34,10 @@ def test_library_exports_every_symbol():
 def test_argument_checks_need_no_gpu():
     lib = _lib.load()
     assert lib.pn2_fps(None, 1, 1, None, 1, None, None, None) == -1
-    assert lib.pn2_fps_workspace_bytes(2, 4096) == 0
-    assert lib.pn2_fps_workspace_bytes(2, 65536) == 2 * 65536 * 4
+    lib.pn2_fps_workspace_bytes.restype = ctypes.c_int64
+    assert lib.pn2_fps_workspace_bytes(2, 4096, 512) == 0
+    assert lib.pn2_fps_workspace_bytes(2, 65536, 1024) == 2 * 1024 * 8 * 32     # 8 cooperating workgroups, 32-byte slots
+    assert lib.pn2_fps_workspace_bytes(200, 65536, 1024) == 200 * 65536 * 4    # too many clouds to co-schedule: fallback
 
 
 def test_cpu_tensors_are_refused():

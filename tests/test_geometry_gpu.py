@@ -42,6 +42,33 @@ def test_fps_every_dispatch_bucket_vs_oracle(dev, N, S):
     assert (mine == ref).all()
 
 
+@pytest.mark.parametrize("B,N,S", [(2, 65536, 300), (3, 25000, 257), (1, 100000, 64), (10, 131072, 40)])
+def test_fps_cooperative_workgroups_vs_oracle(dev, B, N, S):
+    """N > 16384: one cloud across several cooperating workgroups (cfg5's 65 536-point scans; a 25 000-point
+    single-cloud scan with a partly filled last workgroup; 13 workgroups of 8 points per thread; 16 points per
+    thread when 8 would need too many workgroups).  Bit-exact against the oracle, KITTI-shaped duplicates included."""
+    pts, _ = syn.kitti_batch(900 + N % 97, B, min(N, 65536))
+    xyz = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
+    if N > xyz.shape[1]:
+        reps = -(-N // xyz.shape[1])
+        jitter = np.random.default_rng(N).normal(0, 1e-3, (B, reps * xyz.shape[1], 3)).astype(np.float32)
+        xyz = (np.tile(xyz, (1, reps, 1)) + jitter)[:, :N]
+    xyz = np.ascontiguousarray(xyz[:, :N])
+    start = (np.arange(B) * 9973 + 5) % N
+    ref = G.farthest_point_sample(xyz, S, start)
+    mine = U.farthest_point_sample(cu(xyz, dev), S, cu(start, dev)).cpu().numpy()
+    assert (mine == ref).all()
+
+
+def test_fps_large_fallback_when_clouds_cannot_be_coscheduled(dev):
+    """More clouds than the cooperative plan can keep resident at once: the single-workgroup kernel takes over."""
+    rng = np.random.default_rng(3)
+    xyz = rng.uniform(-1, 1, (70, 17000, 3)).astype(np.float32)       # 3 workgroups x 70 clouds > 128
+    start = rng.integers(0, 17000, 70)
+    ref = G.farthest_point_sample(xyz, 6, start)
+    assert (U.farthest_point_sample(cu(xyz, dev), 6, cu(start, dev)).cpu().numpy() == ref).all()
+
+
 def test_fps_full_size_property(dev):
     """B=16 x 4096 -> 1024 (benchmark size): indices distinct until exhaustion, start honoured, oracle-equal."""
     pts, _ = syn.kitti_batch(0, 16, 4096)
