@@ -111,7 +111,7 @@ int pn2_gather_rows_bwd(const float *grad_out, const int64_t *idx, int B, int N,
 /* Grouping of sample_and_group (:127-133) and of the MSG loop (:243-251): gather K
  * neighbours, subtract the centroid from xyz, concatenate with the D features.
  * xyz [B,N,3], points [B,N,D] or NULL (D = 0), new_xyz [B,S,3], idx [B,S,K].
- * out [B*S*K, ld] position-major rows, ld >= 3+D; row = [xyz-c, feat] if xyz_first (SSG, :131)
+ * out [B*S*K, ld] position-major rows, ld >= 3+D and a multiple of 4; row = [xyz-c, feat] if xyz_first (SSG, :131)
  * else [feat, xyz-c] (MSG, :247); columns 3+D..ld-1 are zero.  new_xyz == NULL means
  * "do not centre" (sample_and_group_all, :140-157, with idx = arange). */
 int pn2_group(const float *xyz, const float *points, const float *new_xyz, const int64_t *idx, int B, int N, int S,
