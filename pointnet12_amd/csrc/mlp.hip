@@ -197,7 +197,9 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
     __device__ __forceinline__ void tail(int N) const { run_fin_tail(fin, stats, N, NTHREADS); }
     __device__ __forceinline__ bool want_stats() const { return stats != nullptr; }
     __device__ __forceinline__ void prep(int n, int N, float4 (&c)[4]) const { c[0] = ld4_guard(bias, n, N); }
-    __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], float4 &s0,
+    struct Pre {};
+    __device__ __forceinline__ void pre_issue(Pre &, int64_t, int, bool) const {}
+    __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], const Pre &, float4 &s0,
                                           float4 &s1) const {
         float4 y;
         y.x = acc.x + c[0].x; y.y = acc.y + c[0].y; y.z = acc.z + c[0].z; y.w = acc.w + c[0].w;
@@ -230,9 +232,16 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
         Affine a(aff, lda);     // affine blocks are padded to a multiple of 4 with zeros
         c[0] = ld4(a.mean + n); c[1] = ld4(a.scale + n); c[2] = ld4(a.beta + n); c[3] = ld4(a.invstd + n);
     }
-    __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], float4 &s0,
+    // The previous layer's pre-BN row (for its ReLU mask and BN-backward reduction) is requested before the tile is
+    // staged through LDS, so the HBM round trip runs under the two barriers and the LDS image instead of in front
+    // of every group of stores.
+    struct Pre { float4 y; };
+    __device__ __forceinline__ void pre_issue(Pre &q, int64_t m, int n, bool valid) const {
+        q.y = ld4(valid ? prevY + m * ldp + n : reinterpret_cast<const float *>(pn2_zero_page));
+    }
+    __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], const Pre &q, float4 &s0,
                                           float4 &s1) const {
-        float4 y = ld4(prevY + m * ldp + n);
+        const float4 y = q.y;
         float4 dz;
         dz.x = bn_act(y.x, c[0].x, c[1].x, c[2].x) > 0.f ? acc.x : 0.f;
         dz.y = bn_act(y.y, c[0].y, c[1].y, c[2].y) > 0.f ? acc.y : 0.f;
@@ -259,7 +268,9 @@ struct EpiStore {           // first layer: dX0 = acc (pad lanes are exact zeros
     __device__ __forceinline__ void tail(int) const {}
     __device__ __forceinline__ bool want_stats() const { return false; }
     __device__ __forceinline__ void prep(int, int, float4 (&)[4]) const {}
-    __device__ __forceinline__ void apply(int64_t m, int n, int, float4 acc, const float4 (&)[4], float4 &,
+    struct Pre {};
+    __device__ __forceinline__ void pre_issue(Pre &, int64_t, int, bool) const {}
+    __device__ __forceinline__ void apply(int64_t m, int n, int, float4 acc, const float4 (&)[4], const Pre &, float4 &,
                                           float4 &) const {
         *reinterpret_cast<float4 *>(dX + m * ldx + n) = acc;
     }
@@ -461,6 +472,12 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             ks = 0;
 
             // ---- epilogue: accumulators -> LDS image [BM][LDC] (aliases the operand buffers) -> rows
+            constexpr int EP_IT = (BM + RPP - 1) / RPP;
+            typename Epi::Pre pre[EP_IT];
+            const bool ecol = en < ((N + 3) & ~3) && erow < RPP;    // (NTHREADS % CG) threads have no row when BN = 96
+#pragma unroll
+            for (int i = 0; i < EP_IT; ++i)
+                epi.pre_issue(pre[i], m0 + erow + i * RPP, en, ecol && erow + i * RPP < BM && m0 + erow + i * RPP < P);
             __syncthreads();                               // every wave is done reading the operands
             STAMP(3)
 #pragma unroll
@@ -473,12 +490,14 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             STAMP(4)
             __syncthreads();
             STAMP(5)
-            if (en < ((N + 3) & ~3) && erow < RPP) {        // (NTHREADS % CG) threads have no row when BN = 96
+            if (ecol) {
                 float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-#pragma unroll 4
-                for (int r = erow; r < BM; r += RPP) {
+#pragma unroll
+                for (int i = 0; i < EP_IT; ++i) {
+                    const int r = erow + i * RPP;
                     const int64_t m = m0 + r;
-                    if (m < P) epi.apply(m, en, N, *reinterpret_cast<const float4 *>(&lds[r * LDC + ecg * 4]), ec, s0, s1);
+                    if (r < BM && m < P)
+                        epi.apply(m, en, N, *reinterpret_cast<const float4 *>(&lds[r * LDC + ecg * 4]), ec, pre[i], s0, s1);
                 }
                 if (Epi::kHasStats) {
                     st[0] += (double)s0.x; st[1] += (double)s0.y; st[2] += (double)s0.z; st[3] += (double)s0.w;
