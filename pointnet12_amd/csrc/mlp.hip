@@ -42,7 +42,12 @@ __device__ float4 pn2_zero_page[4];          // always-zero source for predicate
 // and keeping them out of the in-flight register set is what lets the kernels run at 3-4 workgroups per CU
 // without spilling.
 
+// Per-channel constants of the Dy loaders (the four coefficient rows of pn2_bn_bwd_coef) are copied into LDS once per
+// workgroup (kTab rows of K4 floats, dynamic shared memory) and read from there every k-step: a global/L1 round trip
+// right before the operand transform would otherwise sit exposed in front of every LDS store of the dgrad kernel.
 struct LoadPlain {          // X as stored
+    static constexpr int kTab = 0;
+    __device__ __forceinline__ const float *tab_src() const { return nullptr; }
     const float *X; int ldx;
     static constexpr int kRegs = 4;
     template <int IT> struct Raw { float4 x[IT]; };
@@ -56,6 +61,7 @@ struct LoadPlain {          // X as stored
         }
     }
     __device__ __forceinline__ Params params(int, bool) const { return Params(); }
+    __device__ __forceinline__ Params params_tab(const float *, int, int, bool) const { return Params(); }
     template <int IT>
     __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool, const Params &) const { return r.x[i]; }
 };
@@ -63,6 +69,8 @@ struct LoadPlain {          // X as stored
 struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
     const float *X; int ldx; const float *aff;
     static constexpr int kRegs = 4;
+    static constexpr int kTab = 0;          // its constants ride in the prefetched Raw registers
+    __device__ __forceinline__ const float *tab_src() const { return nullptr; }
     template <int IT> struct Raw { float4 x[IT]; float4 mu, sc, be; };   // 12 constant registers: fits at 4 WG/CU
     struct Params {};
     template <int IT>
@@ -81,6 +89,7 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
         }
     }
     __device__ __forceinline__ Params params(int, bool) const { return Params(); }
+    __device__ __forceinline__ Params params_tab(const float *, int, int, bool) const { return Params(); }
     template <int IT>
     __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool valid, const Params &) const {
         const float4 x = r.x[i];
@@ -102,6 +111,16 @@ __device__ __forceinline__ DyParams dy_params(const float *coef, int ldc, int k,
     q.q1 = ld4(kvalid ? coef + ldc + k : zp);
     q.q0 = ld4(kvalid ? coef + 2 * ldc + k : zp);
     q.mu = ld4(kvalid ? coef + 3 * ldc + k : zp);
+    return q;
+}
+
+__device__ __forceinline__ DyParams dy_params_tab(const float *tab, int K4, int k, bool kvalid) {
+    DyParams q;
+    const int kk = kvalid ? k : 0;                 // the table holds the four rows back to back, K4 floats each
+    q.c0 = *reinterpret_cast<const float4 *>(tab + kk);
+    q.q1 = *reinterpret_cast<const float4 *>(tab + K4 + kk);
+    q.q0 = *reinterpret_cast<const float4 *>(tab + 2 * K4 + kk);
+    q.mu = *reinterpret_cast<const float4 *>(tab + 3 * K4 + kk);
     return q;
 }
 
@@ -132,6 +151,11 @@ struct LoadDyDense {
         }
     }
     __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid); }
+    static constexpr int kTab = 4;
+    __device__ __forceinline__ const float *tab_src() const { return coef; }       // 4 rows of pitch ldc == K4
+    __device__ __forceinline__ Params params_tab(const float *tab, int K4, int k, bool kvalid) const {
+        return dy_params_tab(tab, K4, k, kvalid);
+    }
     template <int IT>
     __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool valid, const Params &q) const {
         return valid ? dy_from(r.dz[i], r.y[i], q) : kZero4;
@@ -161,6 +185,11 @@ struct LoadDyPooled {
         }
     }
     __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid); }
+    static constexpr int kTab = 4;
+    __device__ __forceinline__ const float *tab_src() const { return coef; }       // 4 rows of pitch ldc == K4
+    __device__ __forceinline__ Params params_tab(const float *tab, int K4, int k, bool kvalid) const {
+        return dy_params_tab(tab, K4, k, kvalid);
+    }
     template <int IT>
     __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool valid, const Params &q) const {
         const float4 go = r.go[i];
@@ -356,11 +385,18 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     float *As = lds;                                  // [2][BM*LDP]
     float *Bs = lds + 2 * BM * LDP;                   // [2][BROWS*LDBS]
 
+    extern __shared__ __attribute__((aligned(16))) float nt_tab[];   // ALoad::kTab * K4 floats (may be empty)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const int l31 = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const int64_t tiles_m = (P + BM - 1) / BM;
+    if (ALoad::kTab > 0) {                            // per-channel loader constants: global -> LDS once
+        const float *src = aload.tab_src();
+        for (int i = t * 4; i < ALoad::kTab * K4; i += NTHREADS * 4)
+            *reinterpret_cast<float4 *>(nt_tab + i) = ld4(src + i);
+        __syncthreads();
+    }
     const int nk = (K4 + BK - 1) / BK;
     const int lrow = t / TPR, lkq = (t % TPR) * 4;    // loader coordinates
     const int brow = t / TPRB, bcq = (t % TPRB) * 4;  // B loader coordinates (row of the LDS layout, first of 4 columns)
@@ -427,7 +463,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             }
             float *Ab = As + buf * (BM * LDP), *Bb = Bs + buf * (BROWS * LDBS);
             const bool kv = ks * BK + lkq < K4;
-            const typename ALoad::Params ap = aload.params(ks * BK + lkq, kv);
+            const typename ALoad::Params ap = aload.params_tab(nt_tab, K4, ks * BK + lkq, kv);
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
                 *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) =
@@ -548,8 +584,8 @@ int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream
     int64_t cap = (int64_t)pn2_num_cus() * MINB / tiles_n;  // MINB resident workgroups per CU in total
     if (cap < 1) cap = 1;
     unsigned gx = (unsigned)(tiles_m < cap ? tiles_m : cap);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS), 0, s,
-                       aload, bm, P, K4, N, epi);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS),
+                       (size_t)ALoad::kTab * K4 * sizeof(float), s, aload, bm, P, K4, N, epi);
     return pn2_launch_status();
 }
 
