@@ -38,30 +38,50 @@ __global__ __launch_bounds__(256) void group_affine_fwd_kernel(const float *__re
     double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int since = 0;
     if (live) {
-        for (int64_t p = (int64_t)blockIdx.x * RPB + r; p < P; p += (int64_t)gridDim.x * RPB) {
-            const int64_t g = p / K, b = g / S;
-            const int64_t j = idx[p];
-            const float *q = xyz + (b * N + j) * 3, *ctr = new_xyz + g * 3;
-            const float dx = q[0] - ctr[0], dy = q[1] - ctr[1], dz = q[2] - ctr[2];
-            const float4 z = *reinterpret_cast<const float4 *>(Zf + (b * N + j) * ldz + c);
-            float y[4] = {z.x, z.y, z.z, z.w};
+        // four independent rows per trip: idx -> (xyz, centre, Zf row) is a two-deep dependent chain per row; with
+        // the four chains interleaved a trip costs two memory round trips instead of eight
+        const int64_t stride = (int64_t)gridDim.x * RPB;
+        for (int64_t p0 = (int64_t)blockIdx.x * RPB + r; p0 < P; p0 += 4 * stride) {
+            int64_t j[4], g[4], b[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = __builtin_fmaf(wx[e][0], dx, y[e]);
-                y[e] = __builtin_fmaf(wx[e][1], dy, y[e]);
-                y[e] = __builtin_fmaf(wx[e][2], dz, y[e]);
-                if (c + e >= C) y[e] = 0.f;
-                s0[e] += y[e];
-                s1[e] = __builtin_fmaf(y[e], y[e], s1[e]);
+            for (int u = 0; u < 4; ++u) {
+                const int64_t p = p0 + u * stride;
+                const bool v = p < P;
+                g[u] = v ? p / K : 0;
+                b[u] = g[u] / S;
+                j[u] = v ? idx[p] : 0;
             }
-            *reinterpret_cast<float4 *>(Y + p * ldy + c) = make_float4(y[0], y[1], y[2], y[3]);
-            if (++since == 64) {              // fold the fp32 partials into fp64 every 64 rows
+            float4 z[4];
+            float d[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float *q = xyz + (b[u] * N + j[u]) * 3, *ctr = new_xyz + g[u] * 3;
+                d[u][0] = q[0] - ctr[0]; d[u][1] = q[1] - ctr[1]; d[u][2] = q[2] - ctr[2];
+                z[u] = *reinterpret_cast<const float4 *>(Zf + (b[u] * N + j[u]) * ldz + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t p = p0 + u * stride;
+                if (p >= P) break;
+                float y[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    st[e] += (double)s0[e]; st[4 + e] += (double)s1[e];
-                    s0[e] = 0.f; s1[e] = 0.f;
+                    y[e] = __builtin_fmaf(wx[e][0], d[u][0], y[e]);
+                    y[e] = __builtin_fmaf(wx[e][1], d[u][1], y[e]);
+                    y[e] = __builtin_fmaf(wx[e][2], d[u][2], y[e]);
+                    if (c + e >= C) y[e] = 0.f;
+                    s0[e] += y[e];
+                    s1[e] = __builtin_fmaf(y[e], y[e], s1[e]);
                 }
-                since = 0;
+                *reinterpret_cast<float4 *>(Y + p * ldy + c) = make_float4(y[0], y[1], y[2], y[3]);
+                if (++since == 64) {              // fold the fp32 partials into fp64 every 64 rows
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        st[e] += (double)s0[e]; st[4 + e] += (double)s1[e];
+                        s0[e] = 0.f; s1[e] = 0.f;
+                    }
+                    since = 0;
+                }
             }
         }
 #pragma unroll

@@ -982,14 +982,35 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
         Affine a(aff, lda);
         const bool real = c < C;
         const float mu = real ? a.mean[c] : 0.f, is = real ? a.invstd[c] : 0.f;
-        for (int64_t g = (int64_t)blockIdx.y * 4 + gl; g < G; g += (int64_t)gridDim.y * 4) {
-            float o = real ? out[g * ldo + c] : 0.f;
-            dZp[g * ldo + c] = o > 0.f ? dOut[g * ldo + c] : 0.f;
-            if (o > 0.f) {
-                float dz = dOut[g * ldo + c];
-                float y = Y[(g * K + arg[g * ldo + c]) * ldy + c];
-                s0 += (double)dz;
-                s1 += (double)(dz * ((y - mu) * is));
+        // four independent groups per trip: the out / dOut / arg requests of all four go out together and the
+        // dependent Y[arg] gathers follow together -- two memory round trips per four groups instead of three per group
+        const int64_t stride = (int64_t)gridDim.y * 4;
+        for (int64_t g0 = (int64_t)blockIdx.y * 4 + gl; g0 < G; g0 += 4 * stride) {
+            float o[4], dz[4], y[4];
+            int a4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u * stride;
+                const bool v = g < G && real;
+                o[u] = v ? out[g * ldo + c] : 0.f;
+                dz[u] = v ? dOut[g * ldo + c] : 0.f;
+                a4[u] = v ? arg[g * ldo + c] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u * stride;
+                y[u] = (g < G && o[u] > 0.f) ? Y[(g * K + a4[u]) * ldy + c] : mu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u * stride;
+                if (g >= G) break;
+                const bool on = o[u] > 0.f;
+                dZp[g * ldo + c] = on ? dz[u] : 0.f;
+                if (on) {
+                    s0 += (double)dz[u];
+                    s1 += (double)(dz[u] * ((y[u] - mu) * is));
+                }
             }
         }
     }
@@ -1022,12 +1043,26 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
     if (c < C) {
         Affine a(aff, lda);
         const float mu = a.mean[c], is = a.invstd[c];
-        for (int64_t p = (int64_t)blockIdx.y * 4 + gl; p < P; p += (int64_t)gridDim.y * 4) {
-            float dz = out[p * ldo + c] > 0.f ? dOut[p * ldo + c] : 0.f;
-            dZ[p * ldz + c] = dz;
-            float y = Y[p * ldy + c];
-            s0 += (double)dz;
-            s1 += (double)(dz * ((y - mu) * is));
+        const int64_t stride = (int64_t)gridDim.y * 4;
+        for (int64_t p0 = (int64_t)blockIdx.y * 4 + gl; p0 < P; p0 += 4 * stride) {     // four independent rows in flight
+            float o[4], g4[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t p = p0 + u * stride;
+                const bool v = p < P;
+                o[u] = v ? out[p * ldo + c] : 0.f;
+                g4[u] = v ? dOut[p * ldo + c] : 0.f;
+                y[u] = v ? Y[p * ldy + c] : mu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t p = p0 + u * stride;
+                if (p >= P) break;
+                const float dz = o[u] > 0.f ? g4[u] : 0.f;
+                dZ[p * ldz + c] = dz;
+                s0 += (double)dz;
+                s1 += (double)(dz * ((y[u] - mu) * is));
+            }
         }
     }
     sh[0][gl][cl] = s0; sh[1][gl][cl] = s1;
