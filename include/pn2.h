@@ -230,6 +230,23 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       pn2_stream_t stream);
 
+/* ---- scatter-adds of the backward pass as segmented reductions (csrc/scatter.hip) ----------------------------
+ * pn2_invert_index: idx [B, M] int64 with values in [0, T) -> members int32 [B, M], owners int32 [B, M]: the
+ *   positions m of a cloud sorted by the value they point at (a counting sort per cloud; order inside one value is
+ *   unspecified), and that value.  Out-of-range entries are dropped (their slots, at the end of the cloud's array,
+ *   hold -1).  scratch: int32 [B, 2T+1]. */
+int pn2_invert_index(const int64_t *idx, int B, int M, int T, int32_t *members, int32_t *owners, int32_t *scratch,
+                     pn2_stream_t stream);
+/* pn2_three_interp_bwd over the target-sorted 3-NN index (idx viewed as [B, 3N], T = S): runs of equal target are
+ * summed in registers, one atomic row-add per run.  grad_points2 [B,S,D], caller zeroes. */
+int pn2_three_interp_bwd_seg(const float *grad_out, int ld, int col0, const int32_t *members, const int32_t *owners,
+                             const float *weight, int B, int N, int S, int D, float *grad_points2, pn2_stream_t stream);
+/* pn2_group_affine_bwd over the source-sorted ball-query index (idx viewed as [B, S*K], T = N).  G [B*N, ldg],
+ * caller zeroes; dWx accumulated as in pn2_group_affine_bwd.  C <= 256. */
+int pn2_group_affine_bwd_seg(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
+                             const float *new_xyz, const int32_t *members, const int32_t *owners, int B, int N, int S,
+                             int K, int C, float *G, int ldg, float *dWx, int ldwx, pn2_stream_t stream);
+
 /* ---- the loss either side of the path ---------------------------------------
  * Replaces F.nll_loss(pred, target) of semseg.py:143 (weight == NULL) and the class-weighted form of
  * pcdseg.py:179, reduction "mean":

@@ -332,11 +332,32 @@ class _Group(torch.autograd.Function):
         return None, gp, None, None, None, None, None
 
 
+# The scatter-adds of the backward pass (3-NN interpolation, factorised first layer) run as segmented reductions over
+# the neighbour index SORTED BY TARGET (csrc/scatter.hip): ~10x fewer atomics, perfectly balanced.  The index comes
+# from the geometry alone, so the sort is taped with it and runs on the prefetch stream, one step ahead.
+GATHER_BACKWARD = os.environ.get("PN2_GATHER_BWD", "1") == "1"
+
+
+def _inverse_index(idx2d, T):
+    """idx2d [B, M] int64 with values in [0, T) -> (members int32 [B, M], owners int32 [B, M]): the positions of each
+    cloud sorted by the value they point at, and that value."""
+    def compute():
+        B, M = idx2d.shape
+        dev = idx2d.device
+        members = torch.empty(B, M, device=dev, dtype=torch.int32)
+        owners = torch.empty(B, M, device=dev, dtype=torch.int32)
+        scratch = torch.empty(B, 2 * T + 1, device=dev, dtype=torch.int32)
+        _check(_lib.load().pn2_invert_index(_p(idx2d), B, M, T, _p(members), _p(owners), _p(scratch), _lib.stream()),
+               "pn2_invert_index")
+        return (members, owners)
+    return _taped(compute)
+
+
 class _InterpCat(torch.autograd.Function):
     """cat([points1, three_interpolate(points2)], -1) written straight into one [B*N, ld] matrix."""
 
     @staticmethod
-    def forward(ctx, points1, points2, idx, w):
+    def forward(ctx, points1, points2, idx, w, inv_off=None, inv_mem=None):
         B, S, D2 = points2.shape
         N = idx.shape[1]
         D1 = 0 if points1 is None else points1.shape[2]
@@ -346,13 +367,13 @@ class _InterpCat(torch.autograd.Function):
         if D1:
             _check(lib.pn2_copy_cols(_p(points1), D1, 0, _p(rows), ld, 0, B * N, D1, st), "pn2_copy_cols")
         _check(lib.pn2_three_interp(_p(points2), _p(idx), _p(w), B, N, S, D2, _p(rows), ld, D1, 1, st), "pn2_three_interp")
-        ctx.save_for_backward(idx, w)
+        ctx.save_for_backward(idx, w, inv_off, inv_mem)
         ctx.dims = (B, N, S, D1, D2, ld)
         return rows
 
     @staticmethod
     def backward(ctx, grad_rows):
-        idx, w = ctx.saved_tensors
+        idx, w, inv_off, inv_mem = ctx.saved_tensors
         B, N, S, D1, D2, ld = ctx.dims
         grad_rows = grad_rows.contiguous()
         lib, st = _lib.load(), _lib.stream()
@@ -362,9 +383,13 @@ class _InterpCat(torch.autograd.Function):
             _check(lib.pn2_copy_cols(_p(grad_rows), ld, 0, _p(g1), D1, 0, B * N, D1, st), "pn2_copy_cols")
         if ctx.needs_input_grad[1]:
             g2 = torch.zeros(B, S, D2, device=grad_rows.device, dtype=torch.float32)
+        if ctx.needs_input_grad[1] and inv_off is not None:         # segmented reduction over the target-sorted index
+            _check(lib.pn2_three_interp_bwd_seg(_p(grad_rows), ld, D1, _p(inv_off), _p(inv_mem), _p(w), B, N, S, D2, _p(g2), st),
+                   "pn2_three_interp_bwd_seg")
+        elif ctx.needs_input_grad[1]:
             _check(lib.pn2_three_interp_bwd(_p(grad_rows), ld, D1, _p(idx), _p(w), B, N, S, D2, _p(g2), st),
                    "pn2_three_interp_bwd")
-        return g1, g2, None, None
+        return g1, g2, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------- shared MLP
@@ -422,7 +447,7 @@ class _SharedMLP(torch.autograd.Function):
         if geom is None:
             P = rows.shape[0]
         else:
-            g_xyz, g_new, g_idx, g_first = geom
+            g_xyz, g_new, g_idx, g_first, g_inv = geom
             gB, gN, gD = rows.shape
             gS, gK = g_idx.shape[1], g_idx.shape[2]
             P = gB * gS * gK
@@ -479,7 +504,7 @@ class _SharedMLP(torch.autograd.Function):
         _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), out.shape[1], _p(arg), st),
                "pn2_bn_relu_max")
         ctx.meta = (chans, pool, bool(training), P)
-        ctx.geom = None if geom is None else (g_xyz, g_new, g_idx, bool(g_first))   # index/coordinate tensors: no cycle
+        ctx.geom = None if geom is None else (g_xyz, g_new, g_idx, bool(g_first), g_inv)   # index/coordinate tensors: no cycle
         ctx.params = flat                       # leaf parameters / buffers (no grad_fn): no cycle either
         # save_for_backward (not ctx attributes): `out` is this node's own output, and holding it on ctx would close a
         # reference cycle that only the cyclic GC breaks -- gigabytes of saved activations would pile up for several
@@ -620,19 +645,24 @@ class _SharedMLP(torch.autograd.Function):
         """Backward of the factorised first layer: scatter dY to the source points, then two small GEMMs.
         ``w_grad``: None (return dW) or the [co, 3+D] gradient tensor to accumulate into (returns None)."""
         lib, st = _lib.load(), _lib.stream()
-        g_xyz, g_new, g_idx, g_first = ctx.geom
+        g_xyz, g_new, g_idx, g_first, g_inv = ctx.geom
         B, N, D = feats.shape
         S, K = g_idx.shape[1], g_idx.shape[2]
         dev = feats.device
         ldc, ldd = _r4(co), _r4(D)
-        G = torch.zeros(B * N, ldc, device=dev, dtype=torch.float32)
         ident = _ident_coef(co, dev)                  # dY := 1*G + 0*(y-0) + 0
         dW = _zeros_small(4 * co * (3 + D), dev).view(torch.float32).view(co, 3 + D) if w_grad is None else w_grad
         ldw = 3 + D
         x_col, f_col = (0, 3) if g_first else (D, 0)
-        _check(lib.pn2_group_affine_bwd(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new), _p(g_idx),
-                                        B, N, S, K, co, _p(G), ldc, dW.data_ptr() + 4 * x_col, ldw, st),
-               "pn2_group_affine_bwd")
+        G = torch.zeros(B * N, ldc, device=dev, dtype=torch.float32)
+        if g_inv is not None and co <= 256:           # segmented reduction over the source-sorted ball-query index
+            _check(lib.pn2_group_affine_bwd_seg(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new),
+                                                _p(g_inv[0]), _p(g_inv[1]), B, N, S, K, co, _p(G), ldc,
+                                                dW.data_ptr() + 4 * x_col, ldw, st), "pn2_group_affine_bwd_seg")
+        else:
+            _check(lib.pn2_group_affine_bwd(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new),
+                                            _p(g_idx), B, N, S, K, co, _p(G), ldc, dW.data_ptr() + 4 * x_col, ldw, st),
+                   "pn2_group_affine_bwd")
         feat = feats.reshape(B * N, D)
         if ldd != D:
             feat = torch.nn.functional.pad(feat, (0, ldd - D)).contiguous()
@@ -722,7 +752,20 @@ def shared_mlp(rows, c_in, convs, bns, pool, training):
 FACTORISE_MIN_FEATURES = 32      # below this the grouped rows are narrower than the gathered layer-1 output
 
 
-def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training):
+def _factorised(D, n_layers, training):
+    return D >= FACTORISE_MIN_FEATURES and n_layers >= 2 and training
+
+
+def _group_inverse(idx, N, D, n_layers, training):
+    """Inverse of a ball-query index [B,S,K] over the N source points, when the factorised first layer's backward
+    will want it (same predicate in record and replay mode: the tape order must not depend on the mode)."""
+    if not (GATHER_BACKWARD and _factorised(D, n_layers, training)):
+        return None
+    B, S, K = idx.shape
+    return _inverse_index(idx.view(B, S * K), N)
+
+
+def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training, inv=None):
     """Group + shared MLP + max over the K neighbours of one SA scale -> [B*S, C_out].
 
     With enough input features (and a trainable stack of >= 2 layers) the first layer runs factorised over
@@ -730,9 +773,9 @@ def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training):
     """
     B, S, K = idx.shape
     D = 0 if points is None else points.shape[2]
-    if D >= FACTORISE_MIN_FEATURES and len(convs) >= 2 and training:
+    if _factorised(D, len(convs), training):
         flat, cfg = _flat_params(convs, bns)
-        return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx, xyz_first), *flat)
+        return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx, xyz_first, inv), *flat)
     rows = _Group.apply(xyz, points, new_xyz, idx, S, K, xyz_first)
     return shared_mlp(rows, 3 + D, convs, bns, K, training)
 
@@ -806,6 +849,7 @@ class PointNetSetAbstraction(nn.Module):
             fps_idx = farthest_point_sample(xyz, S, fps_start)
             new_xyz = index_points(xyz, fps_idx, _checked=False)
             idx = query_ball_point(self.radius, K, xyz, new_xyz)
+            inv = _group_inverse(idx, N, 0 if pts is None else pts.shape[2], len(self.mlp_convs), self.training)
             rows = None
         c_in = 3 + (0 if pts is None else pts.shape[2])
         if c_in != self.in_channel:
@@ -813,7 +857,7 @@ class PointNetSetAbstraction(nn.Module):
         if _recording():
             return new_xyz.permute(0, 2, 1), _placeholder(B, self.mlp_convs[-1].out_channels, S, xyz.device)
         if rows is None:
-            out = grouped_mlp(xyz, pts, new_xyz, idx, True, self.mlp_convs, self.mlp_bns, self.training)
+            out = grouped_mlp(xyz, pts, new_xyz, idx, True, self.mlp_convs, self.mlp_bns, self.training, inv)
         else:
             out = shared_mlp(rows, c_in, self.mlp_convs, self.mlp_bns, K, self.training)
         return new_xyz.permute(0, 2, 1), out.view(B, S, -1).permute(0, 2, 1)
@@ -868,10 +912,11 @@ class PointNetSetAbstractionMsg(nn.Module):
                 ctx_mgr = contextlib.nullcontext()
             with ctx_mgr:
                 idx = query_ball_point(radius, K, xyz, new_xyz)
+                inv = _group_inverse(idx, N, 0 if pts is None else pts.shape[2], len(self.conv_blocks[i]), self.training)
                 if _recording():
                     continue
                 outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
-                                        self.training))                       # features first (:247)
+                                        self.training, inv))                  # features first (:247)
         if branch:
             for st, o in zip(streams, outs):
                 main.wait_stream(st)
@@ -904,9 +949,12 @@ class PointNetFeaturePropagation(nn.Module):
         p1 = None if points1 is None else _channel_last(points1, "points1")
         B, N, _ = x1.shape
         S = x2.shape[1]
+        want_inv = GATHER_BACKWARD and self.training and S != 1
         if _recording():
             if S != 1:
-                three_nn(x1, x2)
+                idx, _, _ = three_nn(x1, x2)
+                if want_inv:
+                    _inverse_index(idx.view(B, N * 3), S)
             return _placeholder(B, self.mlp_convs[-1].out_channels, N, x1.device)
         if S == 1:                                      # pointnet_util.py:292-293: broadcast the single feature row
             interp = p2.expand(B, N, p2.shape[2])
@@ -918,7 +966,8 @@ class PointNetFeaturePropagation(nn.Module):
             rows = rows.contiguous()
         else:
             idx, _, w = three_nn(x1, x2)
-            rows = _InterpCat.apply(p1, p2, idx, w)
+            inv = _inverse_index(idx.view(B, N * 3), S) if want_inv else (None, None)
+            rows = _InterpCat.apply(p1, p2, idx, w, inv[0], inv[1])
             c_in = p2.shape[2] + (0 if p1 is None else p1.shape[2])
         if c_in != self.in_channel:
             raise RuntimeError("expected %d input channels, got %d" % (self.in_channel, c_in))

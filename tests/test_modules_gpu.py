@@ -350,3 +350,28 @@ def test_fused_bn_tails_match_standalone_launches(dev, direct, monkeypatch):
             assert int(ba[k]) == int(bb[k]) == 2, k
         else:
             assert float((ba[k] - bb[k]).abs().max()) <= 1e-5 * max(1.0, float(ba[k].abs().max())), k
+
+
+def test_segmented_backward_matches_elementwise_atomics(dev, monkeypatch):
+    """The backward scatter-adds (3-NN interpolation, factorised first layer) as segmented reductions over the
+    target-sorted index (pn2_invert_index + pn2_*_bwd_seg, the default) against the element-wise atomic kernels:
+    same sums in another order, on a KITTI-shaped cloud (targets with hundreds of members next to empty ones)."""
+    from pointnet12_amd import synthetic as syn
+    pts, _ = syn.kitti_batch(321, 3, 2048)
+    pts = torch.from_numpy(pts)
+    xyz, feat = pts[:, :3].contiguous().to(dev), torch.randn(3, 64, 2048, generator=torch.Generator().manual_seed(1)).to(dev)
+    grads = []
+    for seg in (True, False):
+        monkeypatch.setattr(U, "GATHER_BACKWARD", seg)
+        torch.manual_seed(11)
+        sa = U.PointNetSetAbstraction(256, 0.2, 32, 64 + 3, [64, 64, 128], False).to(dev).train()
+        fp = U.PointNetFeaturePropagation(128 + 64, [128, 64]).to(dev).train()
+        f = feat.clone().requires_grad_(True)
+        torch.manual_seed(12)
+        new_xyz, new_feat = sa(xyz, f)                       # factorised first layer (D = 64 >= 32)
+        out = fp(xyz, new_xyz, f, new_feat)                  # 3-NN interpolation back onto the 2048 points
+        (out * torch.linspace(-1, 1, out.numel(), device=dev).view_as(out)).sum().backward()
+        grads.append([f.grad.clone()] + [p.grad.clone() for p in list(sa.parameters()) + list(fp.parameters())])
+    for a, b in zip(*grads):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-4 * scale
