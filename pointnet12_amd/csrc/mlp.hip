@@ -912,16 +912,20 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, double inv_
 // order, so a strict `>` keeps the first -- and the 64/LPR row-lanes of a column are folded with xor-shuffles
 // (greater value, or equal value and smaller k).  K == 1 (FeaturePropagation outputs: BN + ReLU only) maps
 // the row-lanes to consecutive groups instead.
+// ksplit != 0 (few groups, e.g. the 16 group_all rows of sa3 or the 2048 groups of sa2): the four waves of a workgroup
+// share ONE group, each takes a quarter of its K rows, and the partial (max, first k) pairs meet in LDS.
 template <bool kPooled>
 __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restrict__ Y, int ldy,
                                                           const float *__restrict__ aff, int lda, int64_t G, int K,
-                                                          int lpr_log2, float *__restrict__ out, int ldo,
+                                                          int lpr_log2, int ksplit, float *__restrict__ out, int ldo,
                                                           int32_t *__restrict__ arg) {
-    const int lane = threadIdx.x & 63;
+    __shared__ float sh_v[4][64][4];
+    __shared__ int sh_k[4][64][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int LPR = 1 << lpr_log2, RPW = 64 >> lpr_log2;
     const int cq = (blockIdx.x * LPR + (lane & (LPR - 1))) * 4;      // first of this lane's four channels
     const int rsub = lane >> lpr_log2;
-    const int64_t w = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);  // wave index
+    const int64_t w = ksplit ? (int64_t)blockIdx.y : (int64_t)blockIdx.y * 4 + wv;   // group (pooled) / wave index
     const bool colv = cq < lda;
     Affine a(aff, lda);
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
@@ -939,13 +943,15 @@ __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restric
         if (arg) *reinterpret_cast<int4 *>(arg + g * ldo + cq) = make_int4(0, 0, 0, 0);
         return;
     }
-    if (w >= G) return;                           // wave-uniform
+    if (w >= G) return;                           // wave-uniform (workgroup-uniform with ksplit)
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int bk[4] = {0, 0, 0, 0};
+    const int kq = ksplit ? (K + 3) >> 2 : K;     // rows of this wave: [k_lo, k_hi)
+    const int k_lo = ksplit ? wv * kq : 0, k_hi = k_lo + kq < K ? k_lo + kq : K;
     if (colv) {
         const float *y = Y + w * K * ldy + cq;
-#pragma unroll 4
-        for (int k = rsub; k < K; k += RPW) {
+#pragma unroll 8
+        for (int k = k_lo + rsub; k < k_hi; k += RPW) {
             const float4 v = ld4(y + (int64_t)k * ldy);
             const float o[4] = {fmaxf(bn_act(v.x, mu.x, sc.x, be.x), 0.f), fmaxf(bn_act(v.y, mu.y, sc.y, be.y), 0.f),
                                 fmaxf(bn_act(v.z, mu.z, sc.z, be.z), 0.f), fmaxf(bn_act(v.w, mu.w, sc.w, be.w), 0.f)};
@@ -961,6 +967,22 @@ __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restric
             const int ok = __shfl_xor(bk[e], off, 64);
             if (ov > best[e] || (ov == best[e] && ok < bk[e])) { best[e] = ov; bk[e] = ok; }
         }
+    }
+    if (ksplit) {                                 // quarters are in ascending k: "greater, or equal and smaller k" again
+        if (rsub == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sh_v[wv][lane][e] = best[e]; sh_k[wv][lane][e] = bk[e]; }
+        }
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ov = sh_v[q][lane & (LPR - 1)][e];
+                const int ok = sh_k[q][lane & (LPR - 1)][e];
+                if (ov > best[e] || (ov == best[e] && ok < bk[e])) { best[e] = ov; bk[e] = ok; }
+            }
     }
     if (colv && rsub == 0) {
         *reinterpret_cast<float4 *>(out + w * ldo + cq) = make_float4(best[0], best[1], best[2], best[3]);
@@ -1171,6 +1193,11 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
     const int rpw = 64 >> lpr_log2;
     const unsigned gx = (unsigned)pn2_cdiv(cg, 1 << lpr_log2);
     const int64_t waves = K == 1 ? pn2_cdiv(G, rpw) : G;
+    if (K >= 32 && G * gx <= 4096 && G <= 65535) {      // too few groups to fill the chip with one wave each: split K
+        hipLaunchKernelGGL(bn_relu_max_kernel<true>, dim3(gx, (unsigned)G), dim3(256), 0, pn2_s(stream), Y, ldy, affine, ld, G, K,
+                           lpr_log2, 1, out, ldo, arg);
+        return pn2_launch_status();
+    }
     // grid.y is limited to 65535 blocks of four waves: issue slabs
     const int64_t slab = 65535LL * 4;
     for (int64_t done = 0; done < waves; done += slab) {
@@ -1179,10 +1206,10 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
         const dim3 grid(gx, (unsigned)pn2_cdiv(take, 4));
         if (K == 1)
             hipLaunchKernelGGL(bn_relu_max_kernel<false>, grid, dim3(256), 0, pn2_s(stream), Y + g0 * ldy, ldy, affine, ld,
-                               G - g0, K, lpr_log2, out + g0 * ldo, ldo, arg ? arg + g0 * ldo : nullptr);
+                               G - g0, K, lpr_log2, 0, out + g0 * ldo, ldo, arg ? arg + g0 * ldo : nullptr);
         else
             hipLaunchKernelGGL(bn_relu_max_kernel<true>, grid, dim3(256), 0, pn2_s(stream), Y + g0 * K * ldy, ldy, affine, ld,
-                               G - g0, K, lpr_log2, out + g0 * ldo, ldo, arg ? arg + g0 * ldo : nullptr);
+                               G - g0, K, lpr_log2, 0, out + g0 * ldo, ldo, arg ? arg + g0 * ldo : nullptr);
     }
     return pn2_launch_status();
 }
@@ -1192,8 +1219,8 @@ int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int3
                         pn2_stream_t stream) {
     PN2_CHECK_ARG(dOut && out && arg && Y && affine && dZp && red && G > 0 && K > 0 && C > 0 && ldo >= ((C + 3) & ~3) &&
                   coef_tail_ok(tail, red));
-    int64_t gy = pn2_cdiv(G, 4 * 16);
-    if (gy > 256) gy = 256;
+    int64_t gy = pn2_cdiv(G, 4 * 4);                    // one trip of four groups per thread where the grid allows
+    if (gy > 1024) gy = 1024;                           // (x 8 reduction replicas: same-address queues of <= 128)
     hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((unsigned)pn2_cdiv((C + 3) & ~3, 64), (unsigned)gy), dim3(256), 0, pn2_s(stream), dOut,
                        ldo, out, arg, Y, ldy, affine, (C + 3) & ~3, G, K, C, dZp, red, make_coef_tail(tail, G * K));
     return pn2_launch_status();
