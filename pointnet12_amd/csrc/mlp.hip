@@ -363,7 +363,9 @@ struct NtLds {
 
 template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi>
 __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi) {
-    static_assert(WR * WC == 4, "four waves");
+    constexpr int KS = 4 / (WR * WC);                // waves sharing one wave tile: they split every k-step between them
+    static_assert(WR * WC * KS == 4 && (KS == 1 || KS == 2), "four waves");
+    static_assert((BK / 8) % KS == 0, "k-step must split evenly over the K-sharing waves");
     constexpr int WTM = BM / WR, WTN = BN / WC;      // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;      // MFMA tiles per wave
     constexpr int LDP = BK + 4;                      // LDS row pitch: 16 consecutive rows cover all 64 banks once
@@ -387,7 +389,8 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
 
     extern __shared__ __attribute__((aligned(16))) float nt_tab[];   // ALoad::kTab * K4 floats (may be empty)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = wave / WC, wc = wave % WC;
+    const int kh = wave / (WR * WC);                 // which share of the k-step this wave multiplies (KS == 1: 0)
+    const int wr = (wave % (WR * WC)) / WC, wc = wave % WC;
     const int l31 = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const int64_t tiles_m = (P + BM - 1) / BM;
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             __syncthreads();
             STAMP(1)
 #pragma unroll
-            for (int kb = 0; kb < BK / 8; ++kb) {
+            for (int kbi = 0; kbi < BK / 8 / KS; ++kbi) {
+                const int kb = kbi * KS + kh;
                 float4 a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -516,13 +520,27 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
                 epi.pre_issue(pre[i], m0 + erow + i * RPP, en, ecol && erow + i * RPP < BM && m0 + erow + i * RPP < P);
             __syncthreads();                               // every wave is done reading the operands
             STAMP(3)
+            if (KS == 1 || kh == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)           // D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                        lds[(wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wc * WTN + j * 32 + l31] = acc[i][j][r];
+                        for (int r = 0; r < 16; ++r)       // D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                            lds[(wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wc * WTN + j * 32 + l31] = acc[i][j][r];
+            }
+            if (KS > 1) {                                  // the other half of every k-step: add it into the image
+                __syncthreads();
+                if (kh == 1) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                lds[(wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wc * WTN + j * 32 + l31] += acc[i][j][r];
+                }
+            }
             STAMP(4)
             __syncthreads();
             STAMP(5)
@@ -597,6 +615,13 @@ inline int pn2_env_int(const char *name, int dflt) {
 template <bool BNN, class ALoad, class Epi>
 int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     static const int cfg = pn2_env_int("PN2_NT_CFG", 0);     // tuning hook (tools/bench_kernels.py)
+    // Few rows (the sa3 / fp3 / fp2 stages: P = 2 k .. 8 k): 64x128 tiles would leave most CUs without a workgroup
+    // -- 64x64 tiles double the workgroup count (fwd 2048 x 1536 -> 256: 64 workgroups -> 128)
+    // -- and 32x64 tiles whose four waves split every k-step in two (summed in the LDS image) double it again.
+    if (N > 32 && cfg != 7 && cfg != 8 && pn2_cdiv(P, 64) * pn2_cdiv(N, 64) * 2 <= pn2_num_cus())
+        return launch_nt<32, 64, 32, 1, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    if (N > 32 && cfg != 7 && pn2_cdiv(P, 64) * pn2_cdiv(N, 128) * 2 <= pn2_num_cus())
+        return launch_nt<64, 64, 32, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     // 65..96 output channels (64->96, 128->96 in MSG sa1): an exact 96-wide tile instead of 25 % padding MFMAs
@@ -621,6 +646,8 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
 template <bool BNN, class ALoad, class Epi>
 int dispatch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     if (bm.vec) return dispatch_nt_vec<BNN>(aload, bm, P, K4, N, epi, s);
+    if (N > 32 && pn2_cdiv(P, 64) * pn2_cdiv(N, 128) * 2 <= pn2_num_cus())
+        return launch_nt<64, 64, 32, 2, 2, 4, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
     if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
     if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
     return launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
