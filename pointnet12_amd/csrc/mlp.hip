@@ -898,6 +898,9 @@ int dispatch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, 
     // 10-30 % on the long reductions; short ones (P < 128 k) prefer fewer, fatter workgroups.  The pooled dY
     // loader keeps three tensors per row in flight and gets one workgroup per CU less (register budget).
     constexpr bool heavy = DyLoad::kRegs >= 13;
+    // few rows (sa3 / fp3 / fp2 stages): the split over P is short, so small tiles -- four times fewer atomics per
+    // multiply than 128x128, and enough tiles to fill the chip without a deep split (small-P wgrad 350 -> 259 us/step)
+    if (P <= 16384 && cfg != 3) return launch_tn<64, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
     if (cfg == 1 || P < 131072) {
         if (narrow_n) return launch_tn<128, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
         if (M <= 64) return launch_tn<64, 128, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
