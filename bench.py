@@ -207,8 +207,8 @@ def main():
         from pointnet12_amd.graph import GraphedStep
         torch.manual_seed(4321)
         geometry = None
-        if args.workload != "sa" and not args.no_prefetch:
-            geometry = lambda: net.features(pts)    # geometry-only pass (recording tape) over the next batch
+        if not args.no_prefetch:                    # geometry-only pass (recording tape) over the next batch
+            geometry = (lambda: net(pts[:, :3, :], pts[:, 3:, :])) if args.workload == "sa" else (lambda: net.features(pts))
         graphed = GraphedStep(compute, dev, geometry_fn=geometry)   # one hipGraph launch per step (failures raise)
     else:
         graphed = compute
@@ -319,7 +319,7 @@ def main():
             "config": {"workload": WORKLOADS[args.workload], "clouds_per_gpu": batch, "points_per_cloud": n_points,
                        "channels": 9, "global_batch": batch * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
-                       "geometry": "in-step" if (args.no_graph or args.no_prefetch or args.workload == "sa")
+                       "geometry": "in-step" if (args.no_graph or args.no_prefetch)
                        else "next batch's FPS/ball-query/3-NN prefetched on a side stream inside the same graph",
                        "grad_bucket_bytes": bucket.nbytes},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
