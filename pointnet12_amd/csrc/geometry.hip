@@ -78,14 +78,35 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         }
         float bm = -1.0f;
         int bj = 0;
+        if (PPT >= 2) {
+            // two points per instruction: v_pk_add_f32 / v_pk_mul_f32 are IEEE single operations on both halves, so
+            // ((dx*dx + dy*dy) + dz*dz) keeps its exact un-fused form (the file is built with -ffp-contract=off)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            int j = t + i * THREADS;
-            float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
-            float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-            float d = (xx + yy) + zz;
-            md[i] = d < md[i] ? d : md[i];
-            if (j < N && md[i] > bm) { bm = md[i]; bj = j; }
+            for (int i = 0; i + 1 < PPT; i += 2) {
+                const f2 x = {px[i], px[i + 1]}, y = {py[i], py[i + 1]}, z = {pz[i], pz[i + 1]};
+                const f2 dx = x - cx2, dy = y - cy2, dz = z - cz2;
+                const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                const f2 d = (xx + yy) + zz;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = t + (i + h) * THREADS;
+                    const float dh = h ? d.y : d.x;
+                    md[i + h] = dh < md[i + h] ? dh : md[i + h];
+                    if (j < N && md[i + h] > bm) { bm = md[i + h]; bj = j; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                int j = t + i * THREADS;
+                float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+                float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                float d = (xx + yy) + zz;
+                md[i] = d < md[i] ? d : md[i];
+                if (j < N && md[i] > bm) { bm = md[i]; bj = j; }
+            }
         }
         unsigned long long key = bm < 0.f ? 0ull
                                           : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
