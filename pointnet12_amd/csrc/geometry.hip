@@ -220,10 +220,10 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
         FpsSlot *row = tab + (size_t)it * W;
         if (mine == key && mine != 0ull) {                    // exactly one thread (indices are unique): publish
             const unsigned long long tag = (unsigned long long)(unsigned)(it + 1) << 32;
-            __hip_atomic_exchange(&row[w].w[1], tag | __float_as_uint(bx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_exchange(&row[w].w[2], tag | __float_as_uint(by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_exchange(&row[w].w[3], tag | __float_as_uint(bz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_exchange(&row[w].w[0], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&row[w].w[1], tag | __float_as_uint(bx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&row[w].w[2], tag | __float_as_uint(by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&row[w].w[3], tag | __float_as_uint(bz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&row[w].w[0], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (wave == 0) {                                      // lanes 0 .. 4W-1 poll one word each
             const bool act = lane < 4 * W;
