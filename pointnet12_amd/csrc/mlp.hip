@@ -85,7 +85,17 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
+#ifdef PN2_X_NOALOAD
+            r.x[i] = ld4(zp + ((mi ^ k) & 0));          // ablation build: the operand stream is never fetched
+#elif defined(PN2_X_NTLOAD)
+            {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f xv = __builtin_nontemporal_load(reinterpret_cast<const v4f *>((kvalid && mi < rows) ? X + mi * ldx + k : zp));
+                r.x[i] = make_float4(xv.x, xv.y, xv.z, xv.w);
+            }
+#else
             r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : zp);
+#endif
         }
     }
     __device__ __forceinline__ Params params(int, bool) const { return Params(); }
@@ -238,7 +248,16 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
             y.w = 0.f;
         }
 #ifndef PN2_X_NOSTORE
+#ifndef PN2_X_PLAINSTORE
+        {   // streaming store: Y is read again only by later kernels; keeping it out of the L2 leaves the cache to the
+            // operand stream and the weights (+2..6 % on the forward GEMMs, tools/bench_kernels.py)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f yv = {y.x, y.y, y.z, y.w};
+            __builtin_nontemporal_store(yv, reinterpret_cast<v4f *>(Y + m * ldy + n));
+        }
+#else
         *reinterpret_cast<float4 *>(Y + m * ldy + n) = y;
+#endif
 #endif
         s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
         s1.x = __builtin_fmaf(y.x, y.x, s1.x); s1.y = __builtin_fmaf(y.y, y.y, s1.y);
@@ -276,7 +295,11 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
         dz.y = bn_act(y.y, c[0].y, c[1].y, c[2].y) > 0.f ? acc.y : 0.f;
         dz.z = bn_act(y.z, c[0].z, c[1].z, c[2].z) > 0.f ? acc.z : 0.f;
         dz.w = bn_act(y.w, c[0].w, c[1].w, c[2].w) > 0.f ? acc.w : 0.f;
-        *reinterpret_cast<float4 *>(dX + m * ldx + n) = dz;     // pad lanes: scale = beta = 0 -> 0
+        {   // streaming store (see EpiFwd); pad lanes: scale = beta = 0 -> 0
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f dv = {dz.x, dz.y, dz.z, dz.w};
+            __builtin_nontemporal_store(dv, reinterpret_cast<v4f *>(dX + m * ldx + n));
+        }
         s0.x += dz.x; s0.y += dz.y; s0.z += dz.z; s0.w += dz.w;
         s1.x = __builtin_fmaf(dz.x, (y.x - c[0].x) * c[3].x, s1.x);
         s1.y = __builtin_fmaf(dz.y, (y.y - c[0].y) * c[3].y, s1.y);

@@ -8,12 +8,12 @@ from pointnet12_amd._lib import ptr as p
 lib = _lib.load(); raw = ctypes.CDLL(_lib.LIB_PATH)
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
 names = ["lds_store+fetch(vmcnt)", "barrier_k", "mfma_loop", "barrier_epi", "stage_write", "barrier_stage", "readback+store", "barrier_end"]
-for P, K, N in [(1048576, 96, 128), (262144, 323, 128), (1048576, 64, 96)]:
+for P, K, N in [(1048576, 96, 128), (262144, 196, 256), (1048576, 64, 96)]:
     X = torch.randn(P, K, device=dev); W = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
-    Y = torch.empty(P, N, device=dev); stats = torch.zeros(2 * N, device=dev, dtype=torch.float64)
+    Y = torch.empty(P, N, device=dev); stats = torch.zeros(8 * 2 * N, device=dev, dtype=torch.float64)
     aff = torch.ones(4 * K, device=dev)
     for _ in range(3):
-        lib.pn2_conv1x1_fwd(p(X), K, p(aff), p(W), K, p(b), p(Y), N, P, K, N, p(stats), st)
+        lib.pn2_conv1x1_fwd(p(X), K, p(aff), p(W), K, p(b), p(Y), N, P, K, N, p(stats), None, st)
     buf = (ctypes.c_ulonglong * (8 * 512))()
     raw.pn2_debug_stamps(buf, 8 * 512)
     a = np.array(buf, dtype=np.float64).reshape(512, 8)
