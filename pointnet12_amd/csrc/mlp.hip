@@ -471,6 +471,21 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
         fetch(ra[d], rb[d], ptile, pks);             // beyond the last tile every lane is predicated off (m >= P)
         if (++pks == nk) { pks = 0; ptile += gridDim.x; }
     }
+    // The first k-step of a tile takes its operands from `fa` / `fb`: already transformed, in registers.  They are
+    // produced BEFORE the previous tile's epilogue issues its global stores (gfx9 has one vmcnt for loads and stores
+    // alike: waiting for a prefetched operand after the stores means waiting for the stores' HBM acknowledgements --
+    // 1-2 us per tile in front of its first MFMA; an ablation build without the stores ran 12 % faster).
+    constexpr bool PF = DEPTH == 1;
+    float4 fa[A_IT], fb[B_IT];
+    auto prefinish = [&](int64_t nt) {
+        const bool kv0 = lkq < K4 && nt < tiles_m;
+        const typename ALoad::Params ap0 = aload.params_tab(nt_tab, K4, lkq, kv0);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) fa[i] = aload.template finish<A_IT>(ra[0], i, kv0 && (nt * BM + lrow + i * RPL < P), ap0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) fb[i] = rb[0][i];
+    };
+    if (PF) prefinish(tile);
     int buf = 0;
     f32x16 acc[TM][TN];
     STAMP_DECL
@@ -488,16 +503,25 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
                         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
             float *Ab = As + buf * (BM * LDP), *Bb = Bs + buf * (BROWS * LDBS);
-            const bool kv = ks * BK + lkq < K4;
-            const typename ALoad::Params ap = aload.params_tab(nt_tab, K4, ks * BK + lkq, kv);
+            if (PF && ks == 0) {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i)
-                *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) =
-                    aload.template finish<A_IT>(ra[d], i, kv && (m0 + lrow + i * RPL < P), ap);
+                for (int i = 0; i < A_IT; ++i) *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) = fa[i];
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i)
-                if ((NTHREADS % TPRB == 0 && BROWS % RPLB == 0) || (brow < RPLB && brow + i * RPLB < BROWS))
-                    *reinterpret_cast<float4 *>(&Bb[(brow + i * RPLB) * LDBS + bcq]) = rb[d][i];
+                for (int i = 0; i < B_IT; ++i)
+                    if ((NTHREADS % TPRB == 0 && BROWS % RPLB == 0) || (brow < RPLB && brow + i * RPLB < BROWS))
+                        *reinterpret_cast<float4 *>(&Bb[(brow + i * RPLB) * LDBS + bcq]) = fb[i];
+            } else {
+                const bool kv = ks * BK + lkq < K4;
+                const typename ALoad::Params ap = aload.params_tab(nt_tab, K4, ks * BK + lkq, kv);
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i)
+                    *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) =
+                        aload.template finish<A_IT>(ra[d], i, kv && (m0 + lrow + i * RPL < P), ap);
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i)
+                    if ((NTHREADS % TPRB == 0 && BROWS % RPLB == 0) || (brow < RPLB && brow + i * RPLB < BROWS))
+                        *reinterpret_cast<float4 *>(&Bb[(brow + i * RPLB) * LDBS + bcq]) = rb[d][i];
+            }
             fetch(ra[d], rb[d], ptile, pks);
             if (++pks == nk) { pks = 0; ptile += gridDim.x; }
             STAMP(0)
@@ -535,6 +559,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             ks = 0;
 
             // ---- epilogue: accumulators -> LDS image [BM][LDC] (aliases the operand buffers) -> rows
+            if (PF) prefinish(tile + gridDim.x);           // next tile's first operands: consumed before any store goes out
             constexpr int EP_IT = (BM + RPP - 1) / RPP;
             typename Epi::Pre pre[EP_IT];
             const bool ecol = en < ((N + 3) & ~3) && erow < RPP;    // (NTHREADS % CG) threads have no row when BN = 96
@@ -641,10 +666,12 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
     // Few rows (the sa3 / fp3 / fp2 stages: P = 2 k .. 8 k): 64x128 tiles would leave most CUs without a workgroup
     // -- 64x64 tiles double the workgroup count (fwd 2048 x 1536 -> 256: 64 workgroups -> 128)
     // -- and 32x64 tiles whose four waves split every k-step in two (summed in the LDS image) double it again.
+    // (register budget: three workgroups per CU for the loaders that keep two or three tensors in flight)
+    constexpr int SMALL_MINB = ALoad::kRegs >= 8 ? 2 : 3;
     if (N > 32 && cfg != 7 && cfg != 8 && pn2_cdiv(P, 64) * pn2_cdiv(N, 64) * 2 <= pn2_num_cus())
-        return launch_nt<32, 64, 32, 1, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+        return launch_nt<32, 64, 32, 1, 2, SMALL_MINB, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     if (N > 32 && cfg != 7 && pn2_cdiv(P, 64) * pn2_cdiv(N, 128) * 2 <= pn2_num_cus())
-        return launch_nt<64, 64, 32, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+        return launch_nt<64, 64, 32, 2, 2, SMALL_MINB, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     // 65..96 output channels (64->96, 128->96 in MSG sa1): an exact 96-wide tile instead of 25 % padding MFMAs
@@ -670,7 +697,7 @@ template <bool BNN, class ALoad, class Epi>
 int dispatch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     if (bm.vec) return dispatch_nt_vec<BNN>(aload, bm, P, K4, N, epi, s);
     if (N > 32 && pn2_cdiv(P, 64) * pn2_cdiv(N, 128) * 2 <= pn2_num_cus())
-        return launch_nt<64, 64, 32, 2, 2, 4, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
+        return launch_nt<64, 64, 32, 2, 2, ALoad::kRegs >= 8 ? 2 : 3, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
     if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
     if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
     return launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
