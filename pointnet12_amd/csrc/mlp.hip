@@ -676,19 +676,15 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
     if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     // 65..96 output channels (64->96, 128->96 in MSG sa1): an exact 96-wide tile instead of 25 % padding MFMAs
     if (N <= 96 && cfg != 9) {
-        if (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);   // no spills
-        return launch_nt<128, 96, 16, 4, 1, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+        if constexpr (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);   // no spills
+        else return launch_nt<128, 96, 16, 4, 1, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     }
-    if (cfg == 1) return launch_nt<128, 128, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     // 64x128 tiles, 16-deep k-steps: more, smaller workgroups per CU hide the operand stream's latency better than
-    // 128x128x32 at two per CU (+10..17 %, tools/bench_kernels.py).  Loaders with a large in-flight register set
-    // (two or three tensors per operand row) get a 168-VGPR budget (3 per CU) instead of 128 (4 per CU): no spills.
-    if (cfg == 3) return launch_nt<64, 128, 16, 2, 2, 3, 2, BNN, true>(aload, bm, P, K4, N, epi, s);
-    if (cfg == 5) return launch_nt<64, 128, 16, 2, 2, 3, 3, BNN, true>(aload, bm, P, K4, N, epi, s);
-    if (cfg == 6) return launch_nt<64, 128, 16, 2, 2, 2, 4, BNN, true>(aload, bm, P, K4, N, epi, s);
-    if (cfg == 4) return launch_nt<64, 128, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
-    if (ALoad::kRegs >= 8 || cfg == 2) return launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
-    return launch_nt<64, 128, 16, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    // 128x128x32 at two per CU (+10..17 %); deeper register prefetch rings (2..4 k-steps) were measured: no gain.
+    // Loaders with a large in-flight register set (two or three tensors per operand row) get a 168-VGPR budget
+    // (3 per CU) instead of 128 (4 per CU): no spills.
+    if constexpr (ALoad::kRegs >= 8) return launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    else return launch_nt<64, 128, 16, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
 }
 
 // Weights whose rows cannot be read as float4 (C_in = 9, 137, ...; column slices of a wider matrix) take guarded
