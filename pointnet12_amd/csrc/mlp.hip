@@ -378,7 +378,7 @@ template <int BM, int BN, int BK, bool BNN = false>
 struct NtLds {
     static constexpr int kB = BNN ? BK * (BN + 8) : BN * (BK + 4);
     static constexpr int kOperands = 2 * (BM * (BK + 4) + kB);       // floats, double buffered
-    static constexpr int kStage = BM * (BN + 4);                      // floats, aliases the operands
+    static constexpr int kStage = BM * (BN + 8);                      // floats, aliases the operands
     static constexpr int kReduce = NTHREADS * 8 * 2;                  // floats (256 x 8 doubles)
     static constexpr int kFloats = kOperands > kStage ? (kOperands > kReduce ? kOperands : kReduce)
                                                       : (kStage > kReduce ? kStage : kReduce);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
                                                      // 4 * (BN + 8) = 32 mod 64 banks -> the two half-waves never collide)
     constexpr int CG = BN / 4;                       // float4 column groups of the output tile
     constexpr int RPP = NTHREADS / CG;               // rows per epilogue pass
-    constexpr int LDC = BN + 4;
+    constexpr int LDC = BN + 8;                      // lanes 32..63 of an accumulator store sit 4 rows down: 4 * LDC = 32 mod 64 banks
     static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 loader threads");
 
     __shared__ __attribute__((aligned(16))) float lds[NtLds<BM, BN, BK, BNN>::kFloats];
