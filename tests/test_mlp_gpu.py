@@ -30,6 +30,9 @@ def torch_mlp(rows, convs, bns, pool, training, dtype):
 @pytest.mark.parametrize("P,pool,chans", [
     (4096, 32, [12, 32, 32, 64]), (1000, 0, [7, 20, 196]), (640, 64, [323, 128, 196, 256]),
     (96, 3, [5, 8]), (2048, 16, [67, 64, 300]), (130, 0, [1539, 256, 32]), (32 * 200, 200, [515, 256, 512, 1024]),
+    # benchmark-sized rows: the large-P tile choices (64x128 / 128x96 NT, 128x128 / 128x64 / 64x128 TN), the pooled
+    # loaders, the streaming first-layer wgrad -- the MSG sa1 stacks at a quarter of their B=16 row count
+    (262144, 128, [9, 64, 96, 128]), (262144, 64, [9, 64, 64, 128]), (131072, 0, [137, 128, 196, 256]),
 ])
 def test_shared_mlp_vs_torch(dev, P, pool, chans):
     gen = torch.Generator().manual_seed(P + len(chans))
