@@ -167,6 +167,7 @@ def index_points(points, idx, _checked=True):
 
 
 MSG_SCALE_STREAMS = os.environ.get("PN2_MSG_STREAMS", "1") == "1"     # measured: 10.36 -> 9.90 ms/step (MSG-SemSeg)
+MSG_LAST_SCALE_ON_MAIN = os.environ.get("PN2_MSG_MAIN_LAST", "1") == "1"
 _scale_stream_pool = {}
 
 
@@ -900,9 +901,13 @@ class PointNetSetAbstractionMsg(nn.Module):
         if branch:
             main = torch.cuda.current_stream(xyz.device)
             streams = _scale_streams(xyz.device, len(self.radius_list))
+        n_scales = len(self.radius_list)
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
-            if branch:
+            # the last scale stays on the calling stream: one branch fewer (a captured step then has four concurrent
+            # branches with the geometry prefetch -- as many as the graph executor has hardware queues)
+            on_side = branch and not (MSG_LAST_SCALE_ON_MAIN and i == n_scales - 1)
+            if on_side:
                 streams[i].wait_stream(main)
                 for t in (xyz, pts, new_xyz):              # allocated on the main stream, read on the branch
                     if t is not None:
@@ -918,7 +923,9 @@ class PointNetSetAbstractionMsg(nn.Module):
                 outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
                                         self.training, inv))                  # features first (:247)
         if branch:
-            for st, o in zip(streams, outs):
+            for i, (st, o) in enumerate(zip(streams, outs)):
+                if MSG_LAST_SCALE_ON_MAIN and i == n_scales - 1:
+                    continue
                 main.wait_stream(st)
                 o.record_stream(main)                      # produced on the branch, concatenated on the main stream
         if _recording():
