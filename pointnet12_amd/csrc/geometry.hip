@@ -417,7 +417,7 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
     fps_coop_plan(B, N, &ppt, &W);
     if (W) {
         FpsSlot *table = reinterpret_cast<FpsSlot *>(work);
-        if (hipMemsetAsync(table, 0, (size_t)B * npoint * W * sizeof(FpsSlot), s) != hipSuccess) return PN2_ELAUNCH;
+        pn2_fill_u32(table, 0u, (int64_t)B * npoint * W * (int64_t)(sizeof(FpsSlot) / 4), s);
         if (ppt == 8)
             hipLaunchKernelGGL(fps_coop_kernel<8>, dim3(W, B), dim3(1024), 0, s, xyz, N, start, npoint, out_idx, table);
         else

@@ -60,6 +60,21 @@ __device__ __forceinline__ unsigned long long pn2_wave_max_u64_dpp(unsigned long
     return best;
 }
 
+// Buffer clears are plain kernels, not hipMemsetAsync: a memset NODE captured into a hipGraph on memory that was
+// allocated during the capture faults at replay on this ROCm ("write access to a read-only page").
+namespace {
+__global__ __launch_bounds__(256) void pn2_fill_u32_kernel(unsigned *__restrict__ p, unsigned value, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+}  // namespace
+
+static inline void pn2_fill_u32(void *p, unsigned value, int64_t n_words, hipStream_t s) {
+    if (n_words <= 0) return;
+    hipLaunchKernelGGL(pn2_fill_u32_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<unsigned *>(p), value, n_words);
+}
+
 __device__ __forceinline__ double pn2_wave_sum_f64(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

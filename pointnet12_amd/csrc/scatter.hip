@@ -12,6 +12,7 @@
 // KITTI-shaped cloud has targets with hundreds of members next to targets with none: one-wave-per-target gathers ran
 // 2x SLOWER than the atomics), and ~10x fewer atomics than the element-wise scatter.
 #include "pn2_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -258,9 +259,9 @@ int pn2_invert_index(const int64_t *idx, int B, int M, int T, int32_t *members, 
     PN2_CHECK_ARG(idx && members && owners && scratch && B > 0 && M > 0 && T > 0 && B <= 65535);
     hipStream_t s = pn2_s(stream);
     int32_t *counts = scratch, *offsets = scratch + (size_t)B * T;        // scratch: int32 [B, 2T + 1]
-    if (hipMemsetAsync(counts, 0, (size_t)B * T * sizeof(int32_t), s) != hipSuccess) return PN2_ELAUNCH;
+    pn2_fill_u32(counts, 0u, (int64_t)B * T, s);
     // out-of-range entries are dropped: their slots at the end of a cloud's member array must read "no member"
-    if (hipMemsetAsync(members, 0xFF, (size_t)B * M * sizeof(int32_t), s) != hipSuccess) return PN2_ELAUNCH;
+    pn2_fill_u32(members, 0xFFFFFFFFu, (int64_t)B * M, s);
     const dim3 grid((unsigned)pn2_cdiv(M, 256), (unsigned)B);
     hipLaunchKernelGGL(invert_count_kernel, grid, dim3(256), 0, s, idx, M, T, counts);
     hipLaunchKernelGGL(invert_scan_kernel, dim3((unsigned)B), dim3(1024), 0, s, counts, T, offsets);
