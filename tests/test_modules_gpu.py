@@ -375,3 +375,28 @@ def test_segmented_backward_matches_elementwise_atomics(dev, monkeypatch):
     for a, b in zip(*grads):
         scale = float(a.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-4 * scale
+
+
+def test_graphed_step_benchmark_size_without_prefetch(dev):
+    """The whole-step graph with the geometry INSIDE the step (no prefetch branch) at B=8 x 4096: every buffer the
+    step clears is allocated during the capture here.  (hipMemsetAsync nodes on such allocations faulted at replay
+    -- "write access to a read-only page" -- while the 2 x 1024 case above passed; the library clears with kernels.)"""
+    from pointnet12_amd import parallel, synthetic as syn
+    from pointnet12_amd.graph import GraphedStep
+    pts_np, labels_np = syn.kitti_batch(40, 8, 4096)
+    pts, labels = torch.from_numpy(pts_np).to(dev), torch.from_numpy(labels_np).to(dev)
+    torch.manual_seed(3)
+    net = M.PointNet2SemSeg(13, 6).to(dev).train()
+    bucket = parallel.FlatGradBucket(net)
+
+    def compute():
+        bucket.zero()
+        lp = net(pts)
+        loss = F.nll_loss(lp.reshape(-1, 13), labels.reshape(-1))
+        loss.backward()
+        return loss
+    step = GraphedStep(compute, dev, warmup=1)
+    losses = [float(step()) for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and 1.0 < losses[-1] < 4.0, losses
+    assert bool(torch.isfinite(bucket.flat).all()) and float(bucket.flat.abs().max()) > 0
