@@ -140,9 +140,11 @@ int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, cons
 /* Inverse-distance interpolation, model/pointnet_util.py:301: out[b,n,col0+c] =
  * ((p2[i0,c]*w0 + p2[i1,c]*w1) + p2[i2,c]*w2).  points2 [B,S,D]; out rows of pitch ld
  * (so the result lands directly inside the concatenated FP input, :305).  zero_tail != 0: the columns
- * col0+D .. ld-1 of every row are cleared as well (the pad lanes of a float4-pitched row; nobody pre-clears it). */
+ * col0+D .. ld-1 of every row are cleared as well (the pad lanes of a float4-pitched row; nobody pre-clears it).
+ * points1 != NULL ([B,N,col0] contiguous): the same launch copies it into columns 0..col0-1, i.e. the whole
+ * cat([points1, interpolated], -1) of :305 is one kernel. */
 int pn2_three_interp(const float *points2, const int64_t *idx, const float *weight, int B, int N, int S, int D,
-                     float *out, int ld, int col0, int zero_tail, pn2_stream_t stream);
+                     float *out, int ld, int col0, int zero_tail, const float *points1, pn2_stream_t stream);
 /* backward: grad_points2 [B,S,D] += w_k * grad_out[b,n,col0+c] (caller zeroes). */
 int pn2_three_interp_bwd(const float *grad_out, int ld, int col0, const int64_t *idx, const float *weight, int B,
                          int N, int S, int D, float *grad_points2, pn2_stream_t stream);

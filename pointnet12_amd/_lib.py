@@ -28,7 +28,7 @@ SIGNATURES = {
     "pn2_group_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "pn2_group_affine_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_group_affine_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
-    "pn2_three_interp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "pn2_three_interp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "pn2_three_interp_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_copy_cols": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
     "pn2_conv1x1_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),

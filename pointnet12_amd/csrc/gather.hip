@@ -94,19 +94,26 @@ __global__ __launch_bounds__(TPB) void group_bwd_kernel(const float *__restrict_
     atomicAdd(grad_points + (b * N + j) * D + cf, gval);
 }
 
-// pointnet_util.py:301: interpolated[b,n,c] = ((p2[i0,c]*w0 + p2[i1,c]*w1) + p2[i2,c]*w2)
+// pointnet_util.py:301: interpolated[b,n,c] = ((p2[i0,c]*w0 + p2[i1,c]*w1) + p2[i2,c]*w2), written at column col0 + c of
+// the concatenated row; with points1 != NULL the same launch also copies points1[b,n,0..col0) in front of it (:305,
+// cat([points1, interpolated], -1)) -- one kernel per FeaturePropagation input instead of two.
 __global__ __launch_bounds__(TPB) void three_interp_kernel(const float *__restrict__ points2,
                                                            const int64_t *__restrict__ idx,
                                                            const float *__restrict__ w, int N, int S, int D,
                                                            int64_t total, float *__restrict__ out, int ld, int col0,
-                                                           int zero_tail) {
+                                                           int zero_tail, const float *__restrict__ points1) {
     int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (e >= total) return;
-    int c = (int)(e % D);
-    int64_t r = e / D;            // b*N + n
+    const int W = points1 ? col0 + D : D;        // columns this launch fills
+    int c = (int)((unsigned long long)e % (unsigned)W);
+    int64_t r = (int64_t)((unsigned long long)e / (unsigned)W);            // b*N + n
+    if (points1) {
+        if (c < col0) { out[r * ld + c] = points1[r * col0 + c]; return; }
+        c -= col0;
+    }
+    int64_t b = r / N;
     if (zero_tail && c == D - 1)
         for (int t = col0 + D; t < ld; ++t) out[r * ld + t] = 0.f;
-    int64_t b = r / N;
     const int64_t *i3 = idx + r * 3;
     const float *w3 = w + r * 3;
     const float *base = points2 + b * S * D + c;
@@ -194,11 +201,12 @@ int pn2_group_bwd(const float *grad_rows, const int64_t *idx, int B, int N, int 
 }
 
 int pn2_three_interp(const float *points2, const int64_t *idx, const float *weight, int B, int N, int S, int D,
-                     float *out, int ld, int col0, int zero_tail, pn2_stream_t stream) {
+                     float *out, int ld, int col0, int zero_tail, const float *points1, pn2_stream_t stream) {
     PN2_CHECK_ARG(points2 && idx && weight && out && B > 0 && N > 0 && S > 0 && D > 0 && col0 >= 0 && ld >= col0 + D);
-    int64_t total = (int64_t)B * N * D;
+    PN2_CHECK_ARG(points1 == nullptr || col0 > 0);
+    int64_t total = (int64_t)B * N * (points1 ? col0 + D : D);
     hipLaunchKernelGGL(three_interp_kernel, dim3(blocks_for(total)), dim3(TPB), 0, pn2_s(stream), points2, idx, weight, N,
-                       S, D, total, out, ld, col0, zero_tail);
+                       S, D, total, out, ld, col0, zero_tail, points1);
     return pn2_launch_status();
 }
 

@@ -365,9 +365,9 @@ class _InterpCat(torch.autograd.Function):
         rows = _empty_rows(B * N, D1 + D2, points2.device)
         ld = rows.shape[1]
         lib, st = _lib.load(), _lib.stream()
-        if D1:
-            _check(lib.pn2_copy_cols(_p(points1), D1, 0, _p(rows), ld, 0, B * N, D1, st), "pn2_copy_cols")
-        _check(lib.pn2_three_interp(_p(points2), _p(idx), _p(w), B, N, S, D2, _p(rows), ld, D1, 1, st), "pn2_three_interp")
+        p1 = points1.contiguous() if D1 else None       # one launch: copy of points1 + interpolation behind it
+        _check(lib.pn2_three_interp(_p(points2), _p(idx), _p(w), B, N, S, D2, _p(rows), ld, D1, 1, _p(p1), st),
+               "pn2_three_interp")
         ctx.save_for_backward(idx, w, inv_off, inv_mem)
         ctx.dims = (B, N, S, D1, D2, ld)
         return rows
@@ -380,8 +380,7 @@ class _InterpCat(torch.autograd.Function):
         lib, st = _lib.load(), _lib.stream()
         g1 = g2 = None
         if D1 and ctx.needs_input_grad[0]:
-            g1 = torch.empty(B, N, D1, device=grad_rows.device, dtype=torch.float32)
-            _check(lib.pn2_copy_cols(_p(grad_rows), ld, 0, _p(g1), D1, 0, B * N, D1, st), "pn2_copy_cols")
+            g1 = grad_rows.view(B, N, ld)[:, :, :D1]        # a strided view: no copy kernel
         if ctx.needs_input_grad[1]:
             g2 = torch.zeros(B, S, D2, device=grad_rows.device, dtype=torch.float32)
         if ctx.needs_input_grad[1] and inv_off is not None:         # segmented reduction over the target-sorted index
