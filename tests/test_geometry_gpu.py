@@ -180,3 +180,23 @@ def test_sample_and_group_api(dev):
     a, b = U.sample_and_group_all(xyz, feat)
     assert a.shape == (2, 1, 3) and float(a.abs().max()) == 0 and b.shape == (2, 1, 512, 9)
     assert torch.equal(b[:, 0, :, :3], xyz) and torch.equal(b[:, 0, :, 3:], feat)
+
+
+def test_fps_cooperative_under_graph_replay(dev):
+    """The multi-workgroup FPS clears its slot table at every launch; as a graph node that clear must run on every
+    replay (a hipMemsetAsync node did not: stale slots let the pollers run ahead of the publishers -- silently wrong
+    samples).  Three replays with different start indices, each bit-exact against the oracle."""
+    pts, _ = syn.kitti_batch(77, 2, 25000)
+    xyz_np = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
+    xyz = cu(xyz_np, dev)
+    start = torch.zeros(2, dtype=torch.int64, device=dev)
+    U.farthest_point_sample(xyz, 200, start)                 # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = U.farthest_point_sample(xyz, 200, start)
+    for s0 in ([5, 17], [24999, 0], [123, 20000]):
+        start.copy_(torch.tensor(s0))
+        g.replay()
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == G.farthest_point_sample(xyz_np, 200, np.array(s0))).all(), s0
