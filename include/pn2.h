@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 2
+#define PN2_ABI_VERSION 3
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -265,6 +265,37 @@ int pn2_nll_loss_fwd(const float *logp, int ld, const int64_t *target, const flo
  * every element of dlogp [R, ld] is written. */
 int pn2_nll_loss_bwd(const int64_t *target, const float *weight, int64_t R, int C, int64_t ignore_index,
                      const float *grad_loss, const float *denom, float *dlogp, int ld, pn2_stream_t stream);
+
+/* ---- the optimiser step and the loader's per-cloud preparation --------------
+ * pn2_adam_step replaces torch.optim.Adam(params, lr, betas=(0.9, 0.999), eps=1e-08, weight_decay) of
+ * semseg.py:106-111 / pcdseg.py:133-138 (amsgrad off, L2 decay folded into the gradient) over ONE flat fp32 buffer
+ * that all parameters alias; grad / exp_avg / exp_avg_sq are flat buffers of the same layout.  One launch:
+ *     g += weight_decay * p;  m = lerp(m, g, 1 - beta1);  v = beta2 * v + (1 - beta2) * g * g;
+ *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * `step` is t (>= 1) of this call.  step_dev != NULL: device int64[2] {steps taken so far, 0}; t = step_dev[0] + 1
+ * is read on the device and step_dev[0] advanced by the launch itself (hipGraph replay needs no new arguments);
+ * `step` is then ignored.  lr_dev != NULL: the learning rate is read from device memory instead of `lr`
+ * (pcdseg.py:159-163 rewrites param_group['lr'] every epoch).  zero_grad != 0 also clears grad (the next
+ * optimizer.zero_grad(), semseg.py:137) in the same pass. */
+int pn2_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int64_t step, const float *lr_dev, int64_t *step_dev,
+                  int zero_grad, pn2_stream_t stream);
+/* pn2_prepare_clouds replaces SemKITTI_Loader.__getitem__ (data_utils/SemKITTI_Loader.py:93-113) for a batch:
+ * pcd_normalize (:23-30: x/70, y/70, z/3, (i-0.5)*2, clip to [-1,1]), pcd_jitter (:17-21: += noise) and
+ * `pcd[choice]`, `label[choice]` (:110-113).
+ *   raw        [rows, 4] fp32 x,y,z,intensity (the .bin row format, kitti_utils.py:200) of any number of scans kept
+ *              resident in HBM; cloud b of the batch is rows [row_begin[b], row_begin[b] + row_count[b])
+ *              (int64[B] each, device memory).
+ *   raw_label  int32[rows] class per raw point, or NULL.
+ *   noise      [*, 4] fp32 clipped jitter rows, one per RAW point (the reference jitters before it resamples, so
+ *              duplicates share their noise); cloud b's rows start at noise_begin[b] (int64[B], device; NULL: the
+ *              same rows as raw).  noise == NULL: no jitter (evaluation).
+ *   choice     int64[B, N] row numbers inside each cloud (np.random.choice(M, N, replace=True)).
+ * Outputs points [B, N, 4] fp32 and labels int64[B, N] (or NULL).  A choice outside [0, row_count[b]) sets
+ * *bad_index (device int, caller zeroes, may be NULL) and reads row 0 (numpy raises IndexError). */
+int pn2_prepare_clouds(const float *raw, const int64_t *row_begin, const int64_t *row_count, const int32_t *raw_label,
+                       const float *noise, const int64_t *noise_begin, const int64_t *choice, int B, int N,
+                       float *points, int64_t *labels, int *bad_index, pn2_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpn2_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/pn2.h one to one (tests check the header against this table)
 SIGNATURES = {
@@ -48,10 +48,12 @@ SIGNATURES = {
     "pn2_nll_loss_workspace_bytes": (_i64, [_i64]),
     "pn2_nll_loss_fwd": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp]),
     "pn2_nll_loss_bwd": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp]),
+    "pn2_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i64, _vp, _vp, _i, _vp]),
+    "pn2_prepare_clouds": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class BnFinalizeTail(ctypes.Structure):

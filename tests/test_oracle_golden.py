@@ -123,3 +123,43 @@ def test_rng_draw_order():
     torch.manual_seed(int(g["fwd_seed"]))
     starts = np.stack([T.draw_start(2, n).numpy() for n in (1024, 1024, 256, 64)])
     assert (starts == g["ssg/starts"]).all()
+
+
+def test_loader_restatement_golden():
+    """oracle.train_ref.prepare_cloud against the reference's pcd_normalize / pcd_jitter / resampling outputs."""
+    from oracle import train_ref as TR
+    g = golden("g8_train.npz")
+    for tag in g["loader_cases"]:
+        np.random.seed(int(g[tag + "/np_seed"]))
+        pts, lab, _, choice = TR.prepare_cloud(g[tag + "/raw"], g[tag + "/label"], g[tag + "/points"].shape[0],
+                                               bool(g[tag + "/train"]))
+        assert (choice == g[tag + "/choice"]).all(), tag
+        assert (bits(pts) == bits(g[tag + "/points"])).all(), tag
+        assert (lab == g[tag + "/labels"]).all(), tag
+    # out-of-range rows are clipped to [-1, 1] before the jitter is added (SemKITTI_Loader.py:29)
+    n = TR.normalize(g["eval/raw"][:5])
+    assert n[0].tolist() == [1.0, -1.0, 1.0, 1.0] and n[1].tolist() == [-1.0, 1.0, -1.0, -1.0]
+
+
+def test_adam_restatement_golden():
+    """oracle.train_ref.adam_step against 12 steps of torch.optim.Adam as semseg.py:106-111 configures it."""
+    from oracle import train_ref as TR
+    g = golden("g8_train.npz")
+    p = g["adam/param0"].copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for t, (grad, lr, ref) in enumerate(zip(g["adam/grads"], g["adam/lr"], g["adam/after"]), 1):
+        TR.adam_step(p, grad, m, v, t, lr=float(lr), weight_decay=float(g["adam/weight_decay"]))
+        assert np.abs(p - ref).max() <= 2e-7 * np.abs(ref).max(), t
+    assert np.abs(m - g["adam/exp_avg"]).max() <= 1e-6 * np.abs(g["adam/exp_avg"]).max()
+    assert np.abs(v - g["adam/exp_avg_sq"]).max() <= 1e-6 * np.abs(g["adam/exp_avg_sq"]).max()
+    # and against torch.optim.Adam itself, which travels with the image (no weight decay, another lr)
+    torch.manual_seed(3)
+    q = torch.nn.Parameter(torch.randn(1001))
+    opt = torch.optim.Adam([q], lr=3e-3, betas=(0.9, 0.999), eps=1e-08)
+    p = q.detach().numpy().copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for t in range(1, 6):
+        q.grad = torch.randn(1001)
+        opt.step()
+        TR.adam_step(p, q.grad.numpy(), m, v, t, lr=3e-3)
+        assert np.abs(p - q.detach().numpy()).max() <= 2e-7 * np.abs(p).max()
