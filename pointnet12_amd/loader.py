@@ -56,9 +56,10 @@ def pcd_jitter_noise(M, C=4, sigma=0.01, clip=0.05):
     return np.clip(sigma * np.random.randn(M, C), -1 * clip, clip).astype(np.float32)
 
 
-def prepare_batch(store, scan_ids, npoints, train=True, rng="numpy", sigma=0.01, clip=0.05):
+def prepare_batch(store, scan_ids, npoints, train=True, rng="numpy", sigma=0.01, clip=0.05, out=None):
     """Batch of ``len(scan_ids)`` clouds: ``(points [B, npoints, 4] fp32, labels [B, npoints] int64 | None)`` on the
-    device.  ``points.transpose(2, 1)`` is the ``[B, 4, N]`` tensor semseg.py:131 feeds the network."""
+    device.  ``points.transpose(2, 1)`` is the ``[B, 4, N]`` tensor semseg.py:131 feeds the network.  ``out``: a
+    ``(points, labels)`` pair of contiguous tensors to write into (the static inputs of a captured step)."""
     lib, st = _lib.load(), _lib.stream()
     ids = torch.as_tensor(scan_ids, dtype=torch.int64)
     B = ids.numel()
@@ -89,8 +90,17 @@ def prepare_batch(store, scan_ids, npoints, train=True, rng="numpy", sigma=0.01,
         raise ValueError('prepare_batch: rng must be "numpy" or a device torch.Generator')
     ids_dev = ids.to(dev)
     begin, count = store._begin_dev[ids_dev], store._count_dev[ids_dev]
-    points = torch.empty(B, npoints, 4, device=dev, dtype=torch.float32)
-    labels = torch.empty(B, npoints, device=dev, dtype=torch.int64) if store.label is not None else None
+    if out is not None:
+        points, labels = out
+        if points.shape != (B, npoints, 4) or points.dtype != torch.float32 or not points.is_contiguous() or \
+                (labels is not None and (labels.shape != (B, npoints) or labels.dtype != torch.int64
+                                         or not labels.is_contiguous())):
+            raise ValueError("prepare_batch: out must be contiguous ([B, npoints, 4] float32, [B, npoints] int64)")
+        if labels is not None and store.label is None:
+            raise ValueError("prepare_batch: the store holds no labels")
+    else:
+        points = torch.empty(B, npoints, 4, device=dev, dtype=torch.float32)
+        labels = torch.empty(B, npoints, device=dev, dtype=torch.int64) if store.label is not None else None
     _lib.check(lib.pn2_prepare_clouds(_p(store.raw), _p(begin), _p(count), _p(store.label), _p(noise), _p(noise_begin),
                                       _p(choice), B, npoints, _p(points), _p(labels), None, st), "pn2_prepare_clouds")
     return points, labels
