@@ -381,9 +381,22 @@ extern "C" {
 
 // Cooperative plan for N > 16384: PPT points per thread and W workgroups per cloud, or W = 0 (single-workgroup
 // fallback) when the W * B workgroups could not all be resident or a cloud would need more than 16 of them.
+// Largest cloud the register-resident single-workgroup kernel takes.  One CU's VALU rate bounds that kernel
+// (0.8 us per iteration at N = 4096, 1.83 at 16 384, 2.11 at 20 000, 2.77 at 28 672 = 28 points per thread, the most
+// that fits 1024 threads' 128-VGPR budget without spilling); the cooperative kernel's iteration costs 2.3-2.4 us up to
+// N = 32 768 (its cross-CU exchange), so the hand-over sits at 20 480.  PN2_FPS_SINGLE_MAX moves it for A/B runs.
+static int fps_single_max() {
+    static const int n = [] {
+        const char *e = getenv("PN2_FPS_SINGLE_MAX");
+        const int v = e ? atoi(e) : 20480;
+        return v < 16384 ? 16384 : (v > 28672 ? 28672 : v);
+    }();
+    return n;
+}
+
 static void fps_coop_plan(int B, int N, int *ppt, int *W) {
     *ppt = 0; *W = 0;
-    if (N <= 16384) return;
+    if (N <= fps_single_max()) return;
     static const int enabled = [] { const char *e = getenv("PN2_FPS_COOP"); return e ? atoi(e) : 1; }();
     if (!enabled) return;
     for (int p = 8; p <= 16; p *= 2) {
@@ -396,7 +409,7 @@ int64_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     int ppt, W;
     fps_coop_plan(B, N, &ppt, &W);
     if (W) return (int64_t)B * npoint * W * (int64_t)sizeof(FpsSlot);
-    return N > 16384 ? (int64_t)B * N * 4 : 0;
+    return N > fps_single_max() ? (int64_t)B * N * 4 : 0;
 }
 
 int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out_idx, void *work,
@@ -412,6 +425,11 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
     if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= fps_single_max()) {
+        if (N <= 20480) return launch_fps<1024, 20>(xyz, B, N, start, npoint, out_idx, s);
+        if (N <= 24576) return launch_fps<1024, 24>(xyz, B, N, start, npoint, out_idx, s);
+        return launch_fps<1024, 28>(xyz, B, N, start, npoint, out_idx, s);
+    }
     PN2_CHECK_ARG(work != nullptr);
     int ppt, W;
     fps_coop_plan(B, N, &ppt, &W);

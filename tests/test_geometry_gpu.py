@@ -31,7 +31,8 @@ def test_fps_golden(dev):
 
 
 @pytest.mark.parametrize("N,S", [(1, 1), (63, 7), (65, 65), (129, 40), (257, 64), (513, 128), (1025, 100),
-                                 (2049, 33), (4097, 64), (8193, 32), (12000, 16), (16385, 8), (20000, 8)])
+                                 (2049, 33), (4097, 64), (8193, 32), (12000, 16), (16385, 8), (20000, 8),
+                                 (20481, 8), (24576, 8), (24577, 8), (28672, 12), (28673, 6)])
 def test_fps_every_dispatch_bucket_vs_oracle(dev, N, S):
     rng = np.random.default_rng(N)
     xyz = rng.uniform(-1, 1, (3, N, 3)).astype(np.float32)
@@ -44,8 +45,8 @@ def test_fps_every_dispatch_bucket_vs_oracle(dev, N, S):
 
 @pytest.mark.parametrize("B,N,S", [(2, 65536, 300), (3, 25000, 257), (1, 100000, 64), (10, 131072, 40)])
 def test_fps_cooperative_workgroups_vs_oracle(dev, B, N, S):
-    """N > 16384: one cloud across several cooperating workgroups (cfg5's 65 536-point scans; a 25 000-point
-    single-cloud scan with a partly filled last workgroup; 13 workgroups of 8 points per thread; 16 points per
+    """N > 20 480: one cloud across several cooperating workgroups (cfg5's 65 536-point scans; a 25 000-point
+    scan with a partly filled last workgroup; 13 workgroups of 8 points per thread; 16 points per
     thread when 8 would need too many workgroups).  Bit-exact against the oracle, KITTI-shaped duplicates included."""
     pts, _ = syn.kitti_batch(900 + N % 97, B, min(N, 65536))
     xyz = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
@@ -63,8 +64,8 @@ def test_fps_cooperative_workgroups_vs_oracle(dev, B, N, S):
 def test_fps_large_fallback_when_clouds_cannot_be_coscheduled(dev):
     """More clouds than the cooperative plan can keep resident at once: the single-workgroup kernel takes over."""
     rng = np.random.default_rng(3)
-    xyz = rng.uniform(-1, 1, (70, 17000, 3)).astype(np.float32)       # 3 workgroups x 70 clouds > 128
-    start = rng.integers(0, 17000, 70)
+    xyz = rng.uniform(-1, 1, (70, 29000, 3)).astype(np.float32)       # 4 workgroups x 70 clouds > 128
+    start = rng.integers(0, 29000, 70)
     ref = G.farthest_point_sample(xyz, 6, start)
     assert (U.farthest_point_sample(cu(xyz, dev), 6, cu(start, dev)).cpu().numpy() == ref).all()
 
@@ -186,7 +187,7 @@ def test_fps_cooperative_under_graph_replay(dev):
     """The multi-workgroup FPS clears its slot table at every launch; as a graph node that clear must run on every
     replay (a hipMemsetAsync node did not: stale slots let the pollers run ahead of the publishers -- silently wrong
     samples).  Three replays with different start indices, each bit-exact against the oracle."""
-    pts, _ = syn.kitti_batch(77, 2, 25000)
+    pts, _ = syn.kitti_batch(77, 2, 40000)
     xyz_np = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
     xyz = cu(xyz_np, dev)
     start = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -195,7 +196,7 @@ def test_fps_cooperative_under_graph_replay(dev):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         out = U.farthest_point_sample(xyz, 200, start)
-    for s0 in ([5, 17], [24999, 0], [123, 20000]):
+    for s0 in ([5, 17], [39999, 0], [123, 20000]):
         start.copy_(torch.tensor(s0))
         g.replay()
         torch.cuda.synchronize()
