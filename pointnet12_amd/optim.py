@@ -11,6 +11,9 @@ gradients into another (``parallel.FlatGradBucket`` -- the buffer the data-paral
 ``exp_avg`` / ``exp_avg_sq`` are flat twins, so ``step()`` is a single ``pn2_adam_step`` launch over 28 B/element
 instead of ~10 foreach launches over ~150 tensors, and ``zero_grad()`` is one fill (or free: ``fused_zero_grad``).
 
+Construct it BEFORE capturing a step into a hipGraph (graph.GraphedStep): a captured launch holds the parameter
+addresses it saw, and construction moves the parameters into the flat buffer.
+
 One semantic difference, by construction: a parameter whose gradient was never written still sees a zero gradient
 (torch.optim.Adam skips ``grad is None`` parameters).  Every parameter of the reference's networks receives a
 gradient in every step.
