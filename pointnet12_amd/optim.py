@@ -115,7 +115,8 @@ class Adam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         """One fill per group (the flat buffers stay attached: ``set_to_none`` is ignored)."""
-        if self._grads_clear:
+        if self._grads_clear:                                # the last step() already cleared them; only once
+            self._grads_clear = False
             return
         for rec in self._flat:
             rec["g"].zero_()
