@@ -946,7 +946,11 @@ int dispatch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, 
     constexpr bool heavy = DyLoad::kRegs >= 13;
     // few rows (sa3 / fp3 / fp2 stages): the split over P is short, so small tiles -- four times fewer atomics per
     // multiply than 128x128, and enough tiles to fill the chip without a deep split (small-P wgrad 350 -> 259 us/step)
-    if (P <= 16384 && cfg != 3) return launch_tn<64, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    // (the same holds up to P = 65 536 -- 65 536 x 128 x 128: 52.6 -> 35.5 us, 32 768 x 256 x 320: 90 -> 81 us -- and at
+    // P = 131 072 for a 128 x 128 product, 72 -> 65 us, but not for 256 x 128, 118 -> 140 us)
+    static const int small_p = pn2_env_int("PN2_TN_SMALLP", 65536);
+    if ((P <= small_p || (P <= 2 * (int64_t)small_p && (int64_t)M * N <= 16384)) && cfg != 3)
+        return launch_tn<64, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
     if (cfg == 1 || P < 131072) {
         if (narrow_n) return launch_tn<128, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
         if (M <= 64) return launch_tn<64, 128, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
