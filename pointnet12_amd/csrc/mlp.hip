@@ -706,7 +706,9 @@ int dispatch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStre
 // core (register prefetch under the MFMAs, double-buffered LDS, one barrier per step) and adds its
 // partial tile with fp32 atomics (256 contiguous bytes per wave-instruction).
 
-template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad>
+// KS > 1 (narrow products, M and N <= 64): the tile has fewer than four 32x32 wave tiles, so KS waves share one and
+// take every KS-th pair of positions of a stage; each adds its own partial tile (a 32x32 tile is 1024 atomics).
+template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad, int KS = 1>
 __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk,
                                                               int M, int N, float *__restrict__ dW, int lddw,
                                                               float *__restrict__ dbias) {
@@ -715,11 +717,13 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
     constexpr int A_IT = WG_BP * (BM / 4) / NTHREADS, B_IT = WG_BP * (BN / 4) / NTHREADS;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
+    static_assert(WR * WC * KS == 4 && (WG_BP / 2) % KS == 0, "four waves");
     __shared__ __attribute__((aligned(16))) float As[2][WG_BP * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][WG_BP * LDB];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = wave / WC, wc = wave % WC;
+    const int ks = wave / (WR * WC), wt = wave % (WR * WC);
+    const int wr = wt / WC, wc = wt % WC;
     const int l31 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int64_t p_begin = (int64_t)blockIdx.z * chunk;
@@ -763,7 +767,8 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
         if (p0 + WG_BP < p_end) fetch(p0 + WG_BP);
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < WG_BP / 2; ++kk) {
+        for (int kq = 0; kq < WG_BP / 2 / KS; ++kq) {
+            const int kk = kq * KS + ks;
             float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = Ab[(kk * 2 + lh) * LDA + wr * WTM + i * 32 + l31];
@@ -778,6 +783,33 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
         buf ^= 1;
     }
 
+    if constexpr (KS > 1) {
+        // fold the KS partial tiles in LDS first: dW is tiny here (<= 64x32) and every workgroup adds to the same
+        // few cache lines -- KS times the atomics per address cost more than the split gained
+        static_assert((KS - 1) * WR * WC * TM * TN * 16 * 64 <= 2 * WG_BP * LDA, "fold buffer");
+        __syncthreads();
+        float *fold = As[0];
+        if (ks > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        fold[((((ks - 1) * (WR * WC) + wt) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (ks > 0) goto tn_bias;
+#pragma unroll
+        for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] += fold[(((q * (WR * WC) + wt) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -793,6 +825,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
 #endif
             }
         }
+tn_bias:
     if (dbias != nullptr && blockIdx.y == 0) {      // combine the AR row-threads of each column group in LDS: one atomic per channel
         __syncthreads();
         float *sh = As[0];
@@ -916,11 +949,12 @@ int launch_skinny(const float *dZ, int ldz, const float *Y, int ldy, const float
     return pn2_launch_status();
 }
 
-template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad>
-int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
+template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, int KS = 1, class DyLoad, class XLoad>
+int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s,
+              int per_cu = MINB) {
     unsigned tm = (unsigned)pn2_cdiv(M, BM), tn = (unsigned)pn2_cdiv(N, BN);
     static const int splitdiv = pn2_env_int("PN2_TN_SPLITDIV", 1);
-    int64_t want = (int64_t)pn2_num_cus() * MINB / ((int64_t)tm * tn) / splitdiv;   // MINB resident workgroups per CU
+    int64_t want = (int64_t)pn2_num_cus() * per_cu / ((int64_t)tm * tn) / splitdiv;   // resident workgroups per CU
     if (want < 1) want = 1;
     int64_t max_split = pn2_cdiv(P, 8 * WG_BP);
     int64_t split = want < max_split ? want : max_split;
@@ -928,7 +962,7 @@ int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, in
     if (split > 65535) split = 65535;
     int64_t chunk = pn2_cdiv(pn2_cdiv(P, split), WG_BP) * WG_BP;
     split = pn2_cdiv(P, chunk);
-    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad>), dim3(tm, tn, (unsigned)split), dim3(NTHREADS), 0, s,
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad, KS>), dim3(tm, tn, (unsigned)split), dim3(NTHREADS), 0, s,
                        dyload, xload, P, chunk, M, N, dW, lddw, dbias);
     return pn2_launch_status();
 }
@@ -936,6 +970,15 @@ int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, in
 template <class DyLoad, class XLoad>
 int dispatch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
     static const int cfg = pn2_env_int("PN2_TN_CFG", 0);     // tuning hook (tools/bench_kernels.py)
+    // narrow products (the 32-channel layers of sa1): tiles of one or two 32x32 wave tiles, the four waves split the
+    // positions of a stage between them (KS) -- no loader thread idles on zero-page columns as in the 128x32 tile:
+    // 524 288 x 32 x 32: 78 -> 43 us, 524 288 x 64 x 32 (pooled): 93 -> 57 us.  Every workgroup ends with atomics on
+    // the same <= 2048 words, so the 32x32 case asks for two workgroups per CU, not four.
+    static const int narrow = pn2_env_int("PN2_TN_NARROW", 1);
+    constexpr bool heavy_dy = DyLoad::kRegs >= 13;
+    if (narrow && N <= 32 && M <= 32)
+        return launch_tn<32, 32, 64, 1, 1, heavy_dy ? 3 : 4, 4>(dyload, xload, P, M, N, dW, lddw, dbias, s, 2);
+    if (narrow && N <= 32 && M <= 64) return launch_tn<64, 32, 32, 2, 1, heavy_dy ? 3 : 4, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
     if (N <= 32) return launch_tn<128, 32, 32, 4, 1, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
     if (M <= 32) return launch_tn<32, 128, 32, 1, 4, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
     if (M <= 64 && N <= 64) return launch_tn<64, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);

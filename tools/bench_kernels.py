@@ -21,7 +21,7 @@ FWD = [(1048576, 9, 64), (1048576, 64, 96), (1048576, 96, 128), (524288, 64, 64)
 # backward shapes: (P, C_l, C_{l-1}, pooled K or 0)
 BWD = [(1048576, 64, 9, 0), (524288, 64, 9, 0), (262144, 32, 9, 0), (1048576, 128, 96, 128), (1048576, 96, 64, 0), (262144, 256, 196, 128), (262144, 196, 128, 0), (262144, 128, 323, 0),
        (524288, 128, 64, 64), (524288, 64, 64, 0), (131072, 256, 128, 64), (65536, 128, 128, 0),
-       (131072, 128, 128, 0), (65536, 128, 137, 0), (262144, 64, 32, 32), (262144, 32, 32, 0), (32768, 256, 256, 0), (32768, 256, 320, 0)]
+       (131072, 128, 128, 0), (65536, 128, 137, 0), (262144, 64, 32, 32), (262144, 32, 32, 0), (524288, 64, 32, 32), (524288, 32, 32, 0), (32768, 256, 256, 0), (32768, 256, 320, 0)]
 
 
 def r4(c):
