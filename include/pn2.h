@@ -34,6 +34,7 @@ extern "C" {
  * same-address atomic queues stay short; pn2_bn_finalize / pn2_bn_bwd_coef sum the copies.  The caller
  * allocates and zeroes PN2_STAT_REPLICAS * 2 * C doubles. */
 #define PN2_STAT_REPLICAS 8
+#define PN2_DWX_REPLICAS 32   /* copies of the dWx partial block in pn2_group_affine_bwd_seg's scratch */
 
 #define PN2_OK 0
 #define PN2_EINVAL (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -244,10 +245,14 @@ int pn2_invert_index(const int64_t *idx, int B, int M, int T, int32_t *members, 
 int pn2_three_interp_bwd_seg(const float *grad_out, int ld, int col0, const int32_t *members, const int32_t *owners,
                              const float *weight, int B, int N, int S, int D, float *grad_points2, pn2_stream_t stream);
 /* pn2_group_affine_bwd over the source-sorted ball-query index (idx viewed as [B, S*K], T = N).  G [B*N, ldg],
- * caller zeroes; dWx accumulated as in pn2_group_affine_bwd.  C <= 256. */
+ * caller zeroes; dWx accumulated as in pn2_group_affine_bwd.  C <= 256.  dwx_scratch: float[PN2_DWX_REPLICAS * 3 *
+ * round4(C)] zeroed by the caller, or NULL.  With it the per-workgroup dWx partials are added to one of
+ * PN2_DWX_REPLICAS copies and a second small launch folds the copies into dWx (all resident workgroups finish
+ * together; their 3*C same-word atomics on dWx itself cost up to 4x the rest of the launch). */
 int pn2_group_affine_bwd_seg(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
                              const float *new_xyz, const int32_t *members, const int32_t *owners, int B, int N, int S,
-                             int K, int C, float *G, int ldg, float *dWx, int ldwx, pn2_stream_t stream);
+                             int K, int C, float *G, int ldg, float *dWx, int ldwx, float *dwx_scratch,
+                             pn2_stream_t stream);
 
 /* ---- the loss either side of the path ---------------------------------------
  * Replaces F.nll_loss(pred, target) of semseg.py:143 (weight == NULL) and the class-weighted form of

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void group_affine_bwd_seg_kernel(const float *
                                                                    const int *__restrict__ owners, int N, int S, int K,
                                                                    int C, int lpr_log2, int chunks_per_cloud,
                                                                    int64_t chunks, float *__restrict__ G, int ldg,
-                                                                   float *__restrict__ dWx, int ldwx) {
+                                                                   float *__restrict__ dWx, int ldwx,
+                                                                   float *__restrict__ rep) {
     __shared__ float red[256 * 12];
     const int t = threadIdx.x, lane = t & 63;
     const int LPR = 1 << lpr_log2, GPW = 64 >> lpr_log2;
@@ -237,16 +238,32 @@ __global__ __launch_bounds__(256) void group_affine_bwd_seg_kernel(const float *
         for (int a = 0; a < 3; ++a) red[t * 12 + k * 3 + a] = wacc[k][a];
     __syncthreads();
     if (t < LPR && cv) {
+        // All resident workgroups finish together and each adds 3*C values: straight into dWx that is up to 1024
+        // same-address atomics per word on a handful of cache lines (280 us of a 350 us launch when dWx is a dense
+        // [C,3] block).  With a scratch block the adds go to one of PN2_DWX_REPLICAS copies (32x less contention per
+        // line) and dwx_fold_kernel sums the copies into dWx.
+        float *dst = rep ? rep + (size_t)(blockIdx.x % PN2_DWX_REPLICAS) * 3 * C4 : nullptr;
         for (int k = 0; k < 4; ++k) {
             if (c + k >= C) break;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
             for (int r = t; r < 256; r += LPR) {
                 s0 += red[r * 12 + k * 3]; s1 += red[r * 12 + k * 3 + 1]; s2 += red[r * 12 + k * 3 + 2];
             }
-            atomicAdd(dWx + (int64_t)(c + k) * ldwx, s0);
-            atomicAdd(dWx + (int64_t)(c + k) * ldwx + 1, s1);
-            atomicAdd(dWx + (int64_t)(c + k) * ldwx + 2, s2);
+            float *o = dst ? dst + (c + k) * 3 : dWx + (int64_t)(c + k) * ldwx;
+            atomicAdd(o, s0);
+            atomicAdd(o + 1, s1);
+            atomicAdd(o + 2, s2);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void dwx_fold_kernel(const float *__restrict__ rep, int C, int C4,
+                                                       float *__restrict__ dWx, int ldwx) {
+    for (int j = threadIdx.x; j < 3 * C; j += 256) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < PN2_DWX_REPLICAS; ++r) s += rep[(size_t)r * 3 * C4 + j];
+        atomicAdd(dWx + (int64_t)(j / 3) * ldwx + j % 3, s);
     }
 }
 
@@ -285,18 +302,22 @@ int pn2_three_interp_bwd_seg(const float *grad_out, int ld, int col0, const int3
 
 int pn2_group_affine_bwd_seg(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
                              const float *new_xyz, const int32_t *members, const int32_t *owners, int B, int N, int S,
-                             int K, int C, float *G, int ldg, float *dWx, int ldwx, pn2_stream_t stream) {
+                             int K, int C, float *G, int ldg, float *dWx, int ldwx, float *dwx_scratch,
+                             pn2_stream_t stream) {
     PN2_CHECK_ARG(dZ && Y && coef && xyz && new_xyz && members && owners && G && dWx && B > 0 && N > 0 && S > 0 && K > 0 &&
                   C > 0 && C <= 256);
     PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldg % 4 == 0 && ldg >= ((C + 3) & ~3) && ldwx >= 3);
     int lpr_log2 = 0;
     while ((4 << lpr_log2) < C && lpr_log2 < 6) ++lpr_log2;
+    const int C4 = (C + 3) & ~3;
     const int cpc = (int)pn2_cdiv((int64_t)S * K, kChunk);
     const int64_t chunks = (int64_t)B * cpc;
     int64_t blocks = pn2_cdiv(pn2_cdiv(chunks, 64 >> lpr_log2), 4);
-    if (blocks > 1024) blocks = 1024;                  // every workgroup ends with 3*C same-address atomics on dWx
+    if (blocks > 1024) blocks = 1024;                  // every workgroup ends with 3*C atomics for dWx
     hipLaunchKernelGGL(group_affine_bwd_seg_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), dZ, ldz, Y, ldy, coef,
-                       (C + 3) & ~3, xyz, new_xyz, members, owners, N, S, K, C, lpr_log2, cpc, chunks, G, ldg, dWx, ldwx);
+                       C4, xyz, new_xyz, members, owners, N, S, K, C, lpr_log2, cpc, chunks, G, ldg, dWx, ldwx, dwx_scratch);
+    if (dwx_scratch)
+        hipLaunchKernelGGL(dwx_fold_kernel, dim3(1), dim3(256), 0, pn2_s(stream), dwx_scratch, C, C4, dWx, ldwx);
     return pn2_launch_status();
 }
 

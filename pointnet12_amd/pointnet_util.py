@@ -394,6 +394,9 @@ class _InterpCat(torch.autograd.Function):
 
 # --------------------------------------------------------------------------------------- shared MLP
 
+# the factorised first layer's dWx partials go through replicated scratch copies (pn2_group_affine_bwd_seg); 0 = straight
+# atomics on the weight gradient, for A/B runs
+DWX_REPLICAS_SCRATCH = os.environ.get("PN2_DWX_REPLICAS", "1") != "0"
 _DIRECT_GRADS = False
 # Statistics -> affine block / backward coefficients inside the kernel that finishes the reduction (the "tails" of
 # include/pn2.h) instead of pn2_bn_finalize / pn2_bn_bwd_coef launches.  Measured on MI355X: no gain (MSG-SemSeg
@@ -656,9 +659,10 @@ class _SharedMLP(torch.autograd.Function):
         x_col, f_col = (0, 3) if g_first else (D, 0)
         G = torch.zeros(B * N, ldc, device=dev, dtype=torch.float32)
         if g_inv is not None and co <= 256:           # segmented reduction over the source-sorted ball-query index
+            scratch = _zeros_small(4 * _lib.DWX_REPLICAS * 3 * ldc, dev) if DWX_REPLICAS_SCRATCH else None
             _check(lib.pn2_group_affine_bwd_seg(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new),
                                                 _p(g_inv[0]), _p(g_inv[1]), B, N, S, K, co, _p(G), ldc,
-                                                dW.data_ptr() + 4 * x_col, ldw, st), "pn2_group_affine_bwd_seg")
+                                                dW.data_ptr() + 4 * x_col, ldw, _p(scratch), st), "pn2_group_affine_bwd_seg")
         else:
             _check(lib.pn2_group_affine_bwd(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new),
                                             _p(g_idx), B, N, S, K, co, _p(G), ldc, dW.data_ptr() + 4 * x_col, ldw, st),
