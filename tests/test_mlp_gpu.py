@@ -33,6 +33,9 @@ def torch_mlp(rows, convs, bns, pool, training, dtype):
     # benchmark-sized rows: the large-P tile choices (64x128 / 128x96 NT, 128x128 / 128x64 / 64x128 TN), the pooled
     # loaders, the streaming first-layer wgrad -- the MSG sa1 stacks at a quarter of their B=16 row count
     (262144, 128, [9, 64, 96, 128]), (262144, 64, [9, 64, 64, 128]), (131072, 0, [137, 128, 196, 256]),
+    # the 32-channel stack of sa1 (SSG and MSG scale 1): 32x32 / 64x32 wgrad tiles whose waves split a stage, pooled K = 32;
+    # and a few-row stage on the 64x64 wgrad tiles (P <= 65 536)
+    (131072, 32, [9, 32, 32, 64]), (65536, 0, [131, 128, 128]),
 ])
 def test_shared_mlp_vs_torch(dev, P, pool, chans):
     gen = torch.Generator().manual_seed(P + len(chans))
