@@ -261,3 +261,49 @@ def test_adam_keeps_the_network_wired(dev):
     finally:
         from pointnet12_amd import pointnet_util
         pointnet_util.set_direct_grad_accumulation(False)
+
+
+def test_adam_two_parameter_groups(dev):
+    """Per-group lr / weight_decay (torch.optim's param_groups API): one flat buffer and one launch per group."""
+    torch.manual_seed(21)
+    init = [torch.randn(50, 7), torch.randn(50), torch.randn(9, 3, 1)]
+    a = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    b = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    spec = lambda ps: [{"params": ps[:2], "lr": 1e-3, "weight_decay": 1e-4}, {"params": ps[2:], "lr": 5e-3}]
+    ref = torch.optim.Adam(spec(a), lr=1e-2, betas=(0.9, 0.999), eps=1e-08)
+    mine = optim.Adam(spec(b), lr=1e-2, betas=(0.9, 0.999), eps=1e-08)
+    assert len(mine.param_groups) == 2 and mine.param_groups[1]["weight_decay"] == 0
+    for _ in range(5):
+        grads = [torch.randn_like(p) for p in a]
+        mine.zero_grad()
+        for p, q, gr in zip(a, b, grads):
+            p.grad = gr
+            q.grad.copy_(gr)
+        ref.step()
+        mine.step()
+    assert rel(flat(b), flat(a)) <= ADAM_TOL
+    assert mine.steps_taken() == [5, 5]
+    with pytest.raises(NotImplementedError):
+        optim.Adam([torch.nn.Parameter(torch.zeros(3, device=dev))], amsgrad=True)
+    with pytest.raises(Exception):
+        optim.Adam([torch.nn.Parameter(torch.zeros(3))])            # CPU parameters: no fallback
+
+
+def test_prepare_batch_without_labels_and_into_static_buffers(dev):
+    rng = np.random.default_rng(8)
+    scans = [rng.uniform(-50, 50, (m, 4)).astype(np.float32) for m in (300, 5000)]
+    store = loader.ScanStore(scans, None, dev)
+    np.random.seed(3)
+    pts, lab = loader.prepare_batch(store, [1, 0], 512, train=False)
+    assert lab is None and pts.shape == (2, 512, 4)
+    np.random.seed(3)
+    out = torch.full((2, 512, 4), 7.0, device=dev)
+    again, _ = loader.prepare_batch(store, [1, 0], 512, train=False, out=(out, None))
+    assert again.data_ptr() == out.data_ptr() and torch.equal(out, pts)
+    np.random.seed(3)
+    ref = [TR.prepare_cloud(scans[i], np.zeros(len(scans[i]), np.int32), 512, False)[0] for i in (1, 0)]
+    assert (bits(pts.cpu().numpy()) == bits(np.stack(ref))).all()
+    with pytest.raises(ValueError):
+        loader.prepare_batch(store, [0], 512, out=(torch.empty(1, 512, 3, device=dev), None))
+    with pytest.raises(ValueError):
+        loader.prepare_batch(store, [], 512)
