@@ -127,6 +127,23 @@ def test_ball_query_full_size_vs_oracle(dev):
         assert (mine == G.query_ball_point(r, k, xyz, new)).all()
 
 
+def test_ball_query_and_three_nn_at_cfg5_size_vs_oracle(dev):
+    """BASELINE cfg5: one 65 536-point scan (22.9 % duplicated locations), the MSG x16 level sizes (8192 centroids)."""
+    pts, _ = syn.kitti_batch(40, 1, 65536)
+    xyz = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
+    start = np.array([11])
+    fps = U.farthest_point_sample(cu(xyz, dev), 8192, cu(start, dev))
+    new = xyz[0][fps.cpu().numpy()[0]][None]
+    sub = np.ascontiguousarray(new[:, ::4])                      # 2048 of the centroids keep the scalar oracle in seconds
+    for r, k in [(0.1, 32), (0.4, 128)]:
+        mine = U.query_ball_point(r, k, cu(xyz, dev), cu(sub, dev)).cpu().numpy()
+        assert (mine == G.query_ball_point(r, k, xyz, sub)).all(), (r, k)
+    idx, dist, w = U.three_nn(cu(xyz, dev), cu(new, dev))        # fp1 of cfg5: 65 536 targets over 8192 sources
+    oi, od = G.three_nn(xyz, new)
+    assert (idx.cpu().numpy() == oi).all()
+    assert (bits(dist.cpu().numpy()) == bits(od)).all()
+
+
 def test_square_distance_bits(dev):
     g = golden("g3_sqdist.npz")
     d = U.square_distance(cu(g["new_xyz"], dev), cu(g["xyz"], dev)).cpu().numpy()
