@@ -232,7 +232,7 @@ __device__ __forceinline__ float4 ld4_guard(const float *p, int n, int N) {
 struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y) -> stats (-> affine block, fused tail)
     float *Y; int ldy; const float *bias; double *stats; FinTail fin;
     static constexpr bool kHasStats = true;
-    __device__ __forceinline__ unsigned *ticket() const { return fin.ticket; }
+    __host__ __device__ __forceinline__ unsigned *ticket() const { return fin.ticket; }
     __device__ __forceinline__ void tail(int N) const { run_fin_tail(fin, stats, N, NTHREADS); }
     __device__ __forceinline__ bool want_stats() const { return stats != nullptr; }
     __device__ __forceinline__ void prep(int n, int N, float4 (&c)[4]) const { c[0] = ld4_guard(bias, n, N); }
@@ -273,7 +273,7 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
 struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev), sum(dZprev*yhat_prev) -> red
     float *dX; int ldx; const float *prevY; int ldp; const float *aff; int lda; double *red; CoefTail ct;
     static constexpr bool kHasStats = true;
-    __device__ __forceinline__ unsigned *ticket() const { return ct.ticket; }
+    __host__ __device__ __forceinline__ unsigned *ticket() const { return ct.ticket; }
     __device__ __forceinline__ void tail(int N) const { run_coef_tail(ct, red, N, NTHREADS); }
     __device__ __forceinline__ bool want_stats() const { return red != nullptr; }
     __device__ __forceinline__ void prep(int n, int N, float4 (&c)[4]) const {
@@ -316,7 +316,7 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
 struct EpiStore {           // first layer: dX0 = acc (pad lanes are exact zeros: weight columns n >= N are never fetched)
     float *dX; int ldx;
     static constexpr bool kHasStats = false;
-    __device__ __forceinline__ unsigned *ticket() const { return nullptr; }
+    __host__ __device__ __forceinline__ unsigned *ticket() const { return nullptr; }
     __device__ __forceinline__ void tail(int) const {}
     __device__ __forceinline__ bool want_stats() const { return false; }
     __device__ __forceinline__ void prep(int, int, float4 (&)[4]) const {}
@@ -385,7 +385,7 @@ struct NtLds {
 };
 
 template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi>
-__global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi) {
+__global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, int n_lo) {
     constexpr int KS = 4 / (WR * WC);                // waves sharing one wave tile: they split every k-step between them
     static_assert(WR * WC * KS == 4 && (KS == 1 || KS == 2), "four waves");
     static_assert((BK / 8) % KS == 0, "k-step must split evenly over the K-sharing waves");
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     const int kh = wave / (WR * WC);                 // which share of the k-step this wave multiplies (KS == 1: 0)
     const int wr = (wave % (WR * WC)) / WC, wc = wave % WC;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = n_lo + blockIdx.y * BN;           // n_lo > 0: this launch covers the output columns from n_lo on
     const int64_t tiles_m = (P + BM - 1) / BM;
     if (ALoad::kTab > 0) {                            // per-channel loader constants: global -> LDS once
         const float *src = aload.tab_src();
@@ -644,14 +644,14 @@ inline int pn2_num_cus() {
 }
 
 template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi>
-int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
+int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, int n_lo = 0, int n_hi = 0) {
     int64_t tiles_m = pn2_cdiv(P, BM);
-    unsigned tiles_n = (unsigned)pn2_cdiv(N, BN);
+    unsigned tiles_n = (unsigned)pn2_cdiv((n_hi ? n_hi : N) - n_lo, BN);     // output columns [n_lo, n_hi) of N
     int64_t cap = (int64_t)pn2_num_cus() * MINB / tiles_n;  // MINB resident workgroups per CU in total
     if (cap < 1) cap = 1;
     unsigned gx = (unsigned)(tiles_m < cap ? tiles_m : cap);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS),
-                       (size_t)ALoad::kTab * K4 * sizeof(float), s, aload, bm, P, K4, N, epi);
+                       (size_t)ALoad::kTab * K4 * sizeof(float), s, aload, bm, P, K4, N, epi, n_lo);
     return pn2_launch_status();
 }
 
@@ -678,6 +678,21 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
     if (N <= 96 && cfg != 9) {
         if constexpr (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);   // no spills
         else return launch_nt<128, 96, 16, 4, 1, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    }
+    // 129..224 output channels (128->196, 256->196 of MSG sa2): 128 columns on the 64x128 tile and the remainder on the
+    // narrowest tile that holds it, as a second launch, instead of a second 128-wide tile that is 47 % padding at 196.
+    // (Not with a fused BatchNorm tail: its ticket counts the workgroups of ONE launch.)
+    static const int nsplit = pn2_env_int("PN2_NT_NSPLIT", 1);
+    if (nsplit && N > 128 && N <= 224 && epi.ticket() == nullptr) {
+        int rc;
+        if constexpr (ALoad::kRegs >= 8) rc = launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 0, 128);
+        else rc = launch_nt<64, 128, 16, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 0, 128);
+        if (rc != PN2_OK) return rc;
+        const int rem = N - 128;
+        if (rem <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 128);
+        if (rem <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 128);
+        if constexpr (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 128);
+        else return launch_nt<128, 96, 16, 4, 1, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 128);
     }
     // 64x128 tiles, 16-deep k-steps: more, smaller workgroups per CU hide the operand stream's latency better than
     // 128x128x32 at two per CU (+10..17 %); deeper register prefetch rings (2..4 k-steps) were measured: no gain.
