@@ -307,3 +307,23 @@ def test_prepare_batch_without_labels_and_into_static_buffers(dev):
         loader.prepare_batch(store, [0], 512, out=(torch.empty(1, 512, 3, device=dev), None))
     with pytest.raises(ValueError):
         loader.prepare_batch(store, [], 512)
+
+
+def test_kitti_files_to_device_batch(dev, tmp_path):
+    """.bin / .label files -> ScanStore -> one evaluation batch: every row is a normalised row of the filtered scan."""
+    import os
+    from pointnet12_amd import kitti
+    g = golden("g9_kitti.npz")
+    fv, fl = os.path.join(tmp_path, "a.bin"), os.path.join(tmp_path, "a.label")
+    g["bin"].tofile(fv)
+    g["label"].tofile(fl)
+    lmap = {int(k): int(v) for k, v in zip(g["map_keys"], g["map_values"])}
+    store = kitti.load_scans([(fv, fl), (fv, fl)], lmap, "inview", dev)
+    assert len(store) == 2 and int(store.row_count[0]) == len(g["inview/points"])
+    np.random.seed(1)
+    pts, lab = loader.prepare_batch(store, [0, 1], 4096, train=False)
+    np.random.seed(1)
+    for b in range(2):
+        ref_p, ref_l, _, _ = TR.prepare_cloud(g["inview/points"], g["inview/labels"], 4096, False)
+        assert (bits(pts[b].cpu().numpy()) == bits(ref_p)).all()
+        assert (lab[b].cpu().numpy() == ref_l).all()
