@@ -400,3 +400,56 @@ def test_graphed_step_benchmark_size_without_prefetch(dev):
     torch.cuda.synchronize()
     assert all(np.isfinite(losses)) and 1.0 < losses[-1] < 4.0, losses
     assert bool(torch.isfinite(bucket.flat).all()) and float(bucket.flat.abs().max()) > 0
+
+
+def test_full_size_batch_permutation_equivariance(dev):
+    """BASELINE cfg3 size (MSG-SemSeg B=16 x 4096 x 9, train mode): clouds are independent units apart from the
+    BatchNorm batch statistics, so permuting the clouds of the batch -- with their FPS start indices
+    -- must permute the outputs and the input gradients and leave every parameter gradient unchanged, up to the
+    summation order of the statistics and the gradient atomics.  Needs no oracle: a size-independent property of the
+    whole forward + backward path."""
+    from pointnet12_amd import pointnet2, synthetic as syn
+    torch.manual_seed(5)
+    net = pointnet2.PointNet2SemSegMsg(13, 6).to(dev).train()
+    pts_np, _ = syn.kitti_batch(0, 16, 4096)
+    pts = torch.from_numpy(pts_np).to(dev)
+    g = torch.Generator().manual_seed(9)
+    perm = torch.randperm(16, generator=g).to(dev)
+    starts = [torch.randint(0, 4096, (16,), generator=g).to(dev), torch.randint(0, 512, (16,), generator=g).to(dev)]
+    proj = torch.randn(16, 128, 4096, generator=g).to(dev) / 64
+
+    class Feed:
+        def __init__(self, seq):
+            self.seq, self.i = seq, 0
+
+        def take(self, B, N, device):
+            self.i += 1
+            return self.seq[self.i - 1]
+
+    def run(x, st, w):
+        x = x.clone().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        U.set_fps_start_feed(Feed(st))
+        try:
+            out = net.features(x)
+        finally:
+            U.set_fps_start_feed(None)
+        (out * w).sum().backward()
+        return out.detach(), x.grad.detach(), [p.grad.detach().clone() for p in net.parameters() if p.grad is not None]
+
+    out_a, gin_a, gp_a = run(pts, starts, proj)
+    out_b, gin_b, gp_b = run(pts[perm], [s[perm] for s in starts], proj[perm])
+    assert out_a.shape == (16, 128, 4096)
+    assert float((out_b - out_a[perm]).abs().max()) <= 2e-5 * max(1.0, float(out_a.abs().max()))
+    scale = float(gin_a[:, 3:].abs().max())                 # xyz columns carry no gradient (SURVEY.md 8(b))
+    assert scale > 0
+    d = (gin_b - gin_a[perm])[:, 3:]
+    # statistics summed in another order flip a few max-pool winners / ReLU signs: whole rows of gradient move
+    # (measured 3.4e-3 of the norm; a wrong pairing of clouds gives O(1))
+    assert float(d.norm()) <= 1e-2 * float(gin_a[:, 3:].norm())
+    assert len(gp_a) == len(gp_b) and len(gp_a) > 60
+    typical = float(torch.stack([a.norm() for a in gp_a]).median())
+    for a, b in zip(gp_a, gp_b):
+        # conv biases in front of a BatchNorm have a mathematically zero gradient: what is there is rounding noise,
+        # measured against the typical gradient norm instead of its own
+        assert float((a - b).norm()) <= 2e-2 * float(a.norm()) + 1e-4 * typical, a.shape
