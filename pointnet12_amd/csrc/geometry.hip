@@ -59,7 +59,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
             if (XYZ_LDS) cloud[j] = make_float4(px[i], py[i], pz[i], 0.f);
         } else {
             px[i] = py[i] = pz[i] = 0.f;
-            md[i] = 0.f;
+            md[i] = -1.f;                             // never a candidate: distances are >= 0
         }
     }
     if (XYZ_LDS) __syncthreads();
@@ -76,8 +76,6 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
             int f = __builtin_amdgcn_readfirstlane(far);
             cx = p[3 * f]; cy = p[3 * f + 1]; cz = p[3 * f + 2];
         }
-        float bm = -1.0f;
-        int bj = 0;
         if (PPT >= 2) {
             // two points per instruction: v_pk_add_f32 / v_pk_mul_f32 are IEEE single operations on both halves, so
             // ((dx*dx + dy*dy) + dz*dz) keeps its exact un-fused form (the file is built with -ffp-contract=off)
@@ -89,25 +87,27 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
                 const f2 dx = x - cx2, dy = y - cy2, dz = z - cz2;
                 const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
                 const f2 d = (xx + yy) + zz;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int j = t + (i + h) * THREADS;
-                    const float dh = h ? d.y : d.x;
-                    md[i + h] = dh < md[i + h] ? dh : md[i + h];
-                    if (j < N && md[i + h] > bm) { bm = md[i + h]; bj = j; }
-                }
+                md[i] = __builtin_fminf(d.x, md[i]);              // slots past N hold -1 and stay there
+                md[i + 1] = __builtin_fminf(d.y, md[i + 1]);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
-                int j = t + i * THREADS;
                 float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
                 float xx = dx * dx, yy = dy * dy, zz = dz * dz;
                 float d = (xx + yy) + zz;
-                md[i] = d < md[i] ? d : md[i];
-                if (j < N && md[i] > bm) { bm = md[i]; bj = j; }
+                md[i] = __builtin_fminf(d, md[i]);
             }
         }
+        // per-thread argmax: the maximum first (v_max3_f32 tree), then the LOWEST slot that holds it -- half the
+        // compare/select pairs of a running (max, index) chain, and no dependent chain through the maximum
+        float bm = md[0];
+#pragma unroll
+        for (int i = 1; i < PPT; ++i) bm = __builtin_fmaxf(bm, md[i]);
+        int bi = PPT - 1;
+#pragma unroll
+        for (int i = PPT - 2; i >= 0; --i) bi = md[i] == bm ? i : bi;
+        const int bj = t + bi * THREADS;
         unsigned long long key = bm < 0.f ? 0ull
                                           : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
         key = pn2_wave_max_u64_dpp(key);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
     for (int i = 0; i < PPT; ++i) {
         const int j = base + t + i * 1024;
         if (j < N) { px[i] = p[3 * j]; py[i] = p[3 * j + 1]; pz[i] = p[3 * j + 2]; md[i] = 1e10f; }
-        else { px[i] = py[i] = pz[i] = 0.f; md[i] = 0.f; }
+        else { px[i] = py[i] = pz[i] = 0.f; md[i] = -1.f; }      // never a candidate: distances are >= 0
     }
     int far = (int)start[b];
     float cx = p[3 * far], cy = p[3 * far + 1], cz = p[3 * far + 2];
@@ -200,17 +200,24 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
     for (int it = 0; it < npoint; ++it) {
         if (w == 0 && t == 0) o[it] = far;
         if (it == npoint - 1) break;                          // the last sample needs no successor
-        float bm = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
-        int bj = 0;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const int j = base + t + i * 1024;
             const float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
             const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
             const float d = (xx + yy) + zz;
-            md[i] = d < md[i] ? d : md[i];
-            if (j < N && md[i] > bm) { bm = md[i]; bj = j; bx = px[i]; by = py[i]; bz = pz[i]; }
+            md[i] = __builtin_fminf(d, md[i]);                 // slots past N hold -1 and stay there
         }
+        float bm = md[0];                                     // maximum first, then the lowest slot that holds it
+#pragma unroll
+        for (int i = 1; i < PPT; ++i) bm = __builtin_fmaxf(bm, md[i]);
+        int bi = PPT - 1;
+        float bx = px[PPT - 1], by = py[PPT - 1], bz = pz[PPT - 1];
+#pragma unroll
+        for (int i = PPT - 2; i >= 0; --i) {
+            const bool hit = md[i] == bm;
+            bi = hit ? i : bi; bx = hit ? px[i] : bx; by = hit ? py[i] : by; bz = hit ? pz[i] : bz;
+        }
+        const int bj = base + t + bi * 1024;
         const unsigned long long mine = bm < 0.f ? 0ull
                                                  : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
         unsigned long long key = pn2_wave_max_u64_dpp(mine);

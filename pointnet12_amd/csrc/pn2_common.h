@@ -27,37 +27,53 @@ __device__ __forceinline__ unsigned long long pn2_wave_max_u64(unsigned long lon
     return v;
 }
 
-// 64-bit max over each row of 16 lanes with DPP (no LDS round trip): xor-1 and xor-2 inside the quads
-// (quad_perm), then row_half_mirror and row_mirror fold the quads; every lane of the row ends with the row max.
-__device__ __forceinline__ unsigned long long pn2_row_max_u64(unsigned long long v) {
-#define PN2_DPP_MAX_STEP(ctrl)                                                                  \
-    {                                                                                           \
-        const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);                         \
-        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false); \
-        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false); \
-        const unsigned long long o = ((unsigned long long)ohi << 32) | olo;                     \
-        v = o > v ? o : v;                                                                      \
-    }
-    PN2_DPP_MAX_STEP(0xB1)    // quad_perm [1,0,3,2]
-    PN2_DPP_MAX_STEP(0x4E)    // quad_perm [2,3,0,1]
-    PN2_DPP_MAX_STEP(0x141)   // row_half_mirror
-    PN2_DPP_MAX_STEP(0x140)   // row_mirror
-#undef PN2_DPP_MAX_STEP
+// 32-bit max over each row of 16 lanes with DPP: xor-1 and xor-2 inside the quads (quad_perm), then row_half_mirror and
+// row_mirror fold the quads; every lane of the row ends with the row max.  Written as v_max_u32 with a DPP operand (one
+// instruction per step; through __builtin_amdgcn_update_dpp the compiler emits mov + nop + dpp-mov + max).  The
+// hazard recogniser does not look inside inline asm, so the two wait states a DPP read needs after a VALU write of
+// the same register are spelled out.
+__device__ __forceinline__ unsigned pn2_row_max_u32(unsigned v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
     return v;
 }
 
-// 64-bit max over the wave, result uniform (SGPRs): DPP inside the four rows, then four readlanes.
+// 64-bit max over each row of 16 lanes as two 32-bit reductions: the maximum of the high words, then the maximum of
+// the low words among the lanes that hold that high word (a 64-bit compare-and-select step costs eight instructions,
+// a 32-bit DPP max one; the FPS iteration is bound by exactly this instruction count).
+__device__ __forceinline__ unsigned long long pn2_row_max_u64(unsigned long long v) {
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mh = pn2_row_max_u32(hi);
+    const unsigned ml = pn2_row_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
+}
+
+// 32-bit max over the wave, result uniform: DPP inside the four rows, row_bcast:15 / row_bcast:31 across them (the
+// gfx9 wave64 idiom: lane 63 ends with the maximum), one readlane.
+__device__ __forceinline__ unsigned pn2_wave_max_u32(unsigned v) {
+    v = pn2_row_max_u32(v);
+    asm volatile("v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"      // rows 1, 3 take rows 0, 2
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"      // rows 2, 3 take lane 31
+                 "s_nop 1"
+                 : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// 64-bit max over the wave, result uniform (SGPRs).
 __device__ __forceinline__ unsigned long long pn2_wave_max_u64_dpp(unsigned long long v) {
-    v = pn2_row_max_u64(v);
-    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-    unsigned long long best = 0;
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        const unsigned long long r = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, row * 16) << 32) |
-                                     (unsigned)__builtin_amdgcn_readlane(lo, row * 16);
-        best = r > best ? r : best;
-    }
-    return best;
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mh = pn2_wave_max_u32(hi);
+    const unsigned ml = pn2_wave_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
 }
 
 // Buffer clears are plain kernels, not hipMemsetAsync: a memset NODE captured into a hipGraph on memory that was
