@@ -76,7 +76,7 @@ const char *pn2_error_string(int code);
  * xyz [B,N,3]; start [B] = the randint draw of :75 (host code owns the RNG);
  * out_idx [B,npoint].  work: caller scratch of pn2_fps_workspace_bytes(B,N,npoint) bytes (may be
  * NULL when that is 0; contents need not be initialised).  Distance form ((dx*dx+dy*dy)+dz*dz)
- * un-fused, argmax ties to the lowest index.  N <= 20480: one workgroup per cloud, cloud and running
+ * un-fused, argmax ties to the lowest index.  N <= 24576: one workgroup per cloud, cloud and running
  * distances in registers; larger clouds are spread over up to 16 cooperating workgroups each. */
 int64_t pn2_fps_workspace_bytes(int B, int N, int npoint);
 int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out_idx,

@@ -389,13 +389,13 @@ extern "C" {
 // Cooperative plan for N > 16384: PPT points per thread and W workgroups per cloud, or W = 0 (single-workgroup
 // fallback) when the W * B workgroups could not all be resident or a cloud would need more than 16 of them.
 // Largest cloud the register-resident single-workgroup kernel takes.  One CU's VALU rate bounds that kernel
-// (0.8 us per iteration at N = 4096, 1.83 at 16 384, 2.11 at 20 000, 2.77 at 28 672 = 28 points per thread, the most
-// that fits 1024 threads' 128-VGPR budget without spilling); the cooperative kernel's iteration costs 2.3-2.4 us up to
-// N = 32 768 (its cross-CU exchange), so the hand-over sits at 20 480.  PN2_FPS_SINGLE_MAX moves it for A/B runs.
+// (0.59 us per iteration at N = 4096, 1.48 at 16 384, 1.65 at 20 000, 2.25 at 28 672 = 28 points per thread, the most
+// that fits 1024 threads' 128-VGPR budget without spilling); the cooperative kernel's iteration costs 2.2 us up to
+// N = 32 768 (its cross-CU exchange), so the hand-over sits at 24 576.  PN2_FPS_SINGLE_MAX moves it for A/B runs.
 static int fps_single_max() {
     static const int n = [] {
         const char *e = getenv("PN2_FPS_SINGLE_MAX");
-        const int v = e ? atoi(e) : 20480;
+        const int v = e ? atoi(e) : 24576;
         return v < 16384 ? 16384 : (v > 28672 ? 28672 : v);
     }();
     return n;

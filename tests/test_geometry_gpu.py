@@ -45,7 +45,7 @@ def test_fps_every_dispatch_bucket_vs_oracle(dev, N, S):
 
 @pytest.mark.parametrize("B,N,S", [(2, 65536, 300), (3, 25000, 257), (1, 100000, 64), (10, 131072, 40)])
 def test_fps_cooperative_workgroups_vs_oracle(dev, B, N, S):
-    """N > 20 480: one cloud across several cooperating workgroups (cfg5's 65 536-point scans; a 25 000-point
+    """N > 24 576: one cloud across several cooperating workgroups (cfg5's 65 536-point scans; a 25 000-point
     scan with a partly filled last workgroup; 13 workgroups of 8 points per thread; 16 points per
     thread when 8 would need too many workgroups).  Bit-exact against the oracle, KITTI-shaped duplicates included."""
     pts, _ = syn.kitti_batch(900 + N % 97, B, min(N, 65536))
