@@ -34,8 +34,8 @@ __device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float n
 // Each of the npoint dependent iterations costs: PPT distance updates, a per-thread argmax,
 // a 64-lane DPP max on a packed (distance bits, ~index) key -- distances are >= 0 so their
 // fp32 bit patterns order like unsigned ints and "largest key" = largest distance, lowest
-// index -- one LDS slot per wave and ONE barrier (slots are double-buffered by iteration
-// parity).  pointnet_util.py:77-83.
+// index -- one ds_max_u64 per wave on a shared LDS word and ONE barrier (three words in rotation).
+// pointnet_util.py:77-83.
 // ---------------------------------------------------------------------------------------------
 template <int THREADS, int PPT, bool XYZ_LDS>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ xyz, int N,
@@ -44,9 +44,9 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
     constexpr int NW = THREADS / 64;
     extern __shared__ float4 fps_lds[];
     float4 *cloud = fps_lds;                                                     // [N] when XYZ_LDS
-    unsigned long long *slots = reinterpret_cast<unsigned long long *>(fps_lds + (XYZ_LDS ? N : 0));  // [2][NW]
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(fps_lds + (XYZ_LDS ? N : 0));  // [3] (+ spare)
 
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const float *p = xyz + (size_t)b * N * 3;
 
     float px[PPT], py[PPT], pz[PPT], md[PPT];
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
             md[i] = -1.f;                             // never a candidate: distances are >= 0
         }
     }
-    if (XYZ_LDS) __syncthreads();
+    if (NW > 1 && t < 3) slots[t] = 0ull;
+    if (XYZ_LDS || NW > 1) __syncthreads();
+    int rot = 0;
 
     int far = (int)start[b];
     int64_t *o = out + (size_t)b * npoint;
@@ -112,11 +114,15 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
                                           : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
         key = pn2_wave_max_u64_dpp(key);
         if (NW > 1) {
-            unsigned long long *s = slots + (it & 1) * NW;
-            if (lane == 0) s[wave] = key;
+            // the waves meet in ONE LDS word: lane 0 of each issues a ds_max_u64, everybody reads the word back after the
+            // barrier (no per-wave slots to reduce again).  Three words in rotation: the next one is cleared here, two
+            // barriers after its last reader.
+            unsigned long long *cur = slots + rot;
+            rot = rot == 2 ? 0 : rot + 1;
+            if (lane == 0) __hip_atomic_fetch_max(cur, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (t == 0) slots[rot] = 0ull;
             __syncthreads();
-            // NW <= 16 slots replicated over each row of 16 lanes: one more DPP row reduction combines them
-            key = pn2_row_max_u64(s[lane & (NW - 1)]);
+            key = *cur;
         }
         far = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
     }
@@ -180,7 +186,7 @@ template <int PPT>
 __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict__ xyz, int N,
                                                         const int64_t *__restrict__ start, int npoint,
                                                         int64_t *__restrict__ out, FpsSlot *__restrict__ table) {
-    __shared__ unsigned long long slots[2][16];
+    __shared__ unsigned long long red[3];                 // the waves' ds_max_u64 meeting word, three in rotation
     __shared__ float4 bcast[2];
     const int W = gridDim.x, w = blockIdx.x, b = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -193,6 +199,9 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
         if (j < N) { px[i] = p[3 * j]; py[i] = p[3 * j + 1]; pz[i] = p[3 * j + 2]; md[i] = 1e10f; }
         else { px[i] = py[i] = pz[i] = 0.f; md[i] = -1.f; }      // never a candidate: distances are >= 0
     }
+    if (t < 3) red[t] = 0ull;
+    __syncthreads();
+    int rot = 0;
     int far = (int)start[b];
     float cx = p[3 * far], cy = p[3 * far + 1], cz = p[3 * far + 2];
     int64_t *o = out + (size_t)b * npoint;
@@ -221,9 +230,12 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
         const unsigned long long mine = bm < 0.f ? 0ull
                                                  : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
         unsigned long long key = pn2_wave_max_u64_dpp(mine);
-        if (lane == 0) slots[it & 1][wave] = key;
+        unsigned long long *cur = red + rot;
+        rot = rot == 2 ? 0 : rot + 1;
+        if (lane == 0) __hip_atomic_fetch_max(cur, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t == 0) red[rot] = 0ull;                          // cleared two barriers after its last reader
         __syncthreads();
-        key = pn2_row_max_u64(slots[it & 1][lane & 15]);     // 16 waves: every thread now holds the workgroup's best
+        key = *cur;                                           // every thread now holds the workgroup's best
         FpsSlot *row = tab + (size_t)it * W;
         if (mine == key && mine != 0ull) {                    // exactly one thread (indices are unique): publish
             const unsigned long long tag = (unsigned long long)(unsigned)(it + 1) << 32;
@@ -258,9 +270,8 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
 
 template <int THREADS, int PPT>
 int launch_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, hipStream_t s) {
-    constexpr int NW = THREADS / 64;
-    const bool in_lds = (size_t)N * 16 + 2 * NW * 8 <= 160 * 1024;  // gfx950: 160 KiB of LDS per workgroup
-    size_t lds = (in_lds ? (size_t)N * 16 : 0) + 2 * NW * 8;
+    const bool in_lds = (size_t)N * 16 + 32 <= 160 * 1024;  // gfx950: 160 KiB of LDS per workgroup
+    size_t lds = (in_lds ? (size_t)N * 16 : 0) + 32;           // + the three rotating reduction words
     if (in_lds) {
         if (lds > 64 * 1024) {   // above the default dynamic-LDS window: opt in once per instantiation
             static bool raised = false;
