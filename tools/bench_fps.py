@@ -10,7 +10,7 @@ from pointnet12_amd import pointnet_util as U
 from pointnet12_amd import synthetic as syn
 
 dev = torch.device("cuda:0")
-for B, N, S in [(16, 4096, 1024), (8, 4096, 1024), (8, 65536, 1024), (8, 65536, 8192), (1, 16384, 1024), (1, 20000, 1024), (1, 25000, 1024), (1, 28672, 1024), (8, 25000, 1024),
+for B, N, S in [(16, 4096, 1024), (8, 4096, 1024), (16, 1024, 256), (16, 2048, 512), (16, 8192, 1024), (8, 65536, 1024), (8, 65536, 8192), (1, 16384, 1024), (1, 20000, 1024), (1, 25000, 1024), (1, 28672, 1024), (8, 25000, 1024),
                 (1, 65536, 1024)]:
     pts, _ = syn.kitti_batch(1, B, min(N, 65536))
     xyz = torch.from_numpy(pts[:, :3].transpose(0, 2, 1).copy()).to(dev)[:, :N].contiguous()
