@@ -16,6 +16,14 @@ __device__ __forceinline__ float sq_norm3(float x, float y, float z) {
     return (xx + yy) + zz;
 }
 
+// min of two non-NaN floats as ONE v_min_f32: __builtin_fminf adds a canonicalising v_max_f32 x, x per operand in IEEE
+// mode, and the FPS iteration is bound by its instruction count.
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float nq, float px, float py, float pz,
                                            float np) {
     float dot = qx * px;
@@ -89,8 +97,8 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
                 const f2 dx = x - cx2, dy = y - cy2, dz = z - cz2;
                 const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
                 const f2 d = (xx + yy) + zz;
-                md[i] = __builtin_fminf(d.x, md[i]);              // slots past N hold -1 and stay there
-                md[i + 1] = __builtin_fminf(d.y, md[i + 1]);
+                md[i] = min_raw(d.x, md[i]);                      // slots past N hold -1 and stay there
+                md[i + 1] = min_raw(d.y, md[i + 1]);
             }
         } else {
 #pragma unroll
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
                 float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
                 float xx = dx * dx, yy = dy * dy, zz = dz * dz;
                 float d = (xx + yy) + zz;
-                md[i] = __builtin_fminf(d, md[i]);
+                md[i] = min_raw(d, md[i]);
             }
         }
         // per-thread argmax: the maximum first (v_max3_f32 tree), then the LOWEST slot that holds it -- half the
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
             const float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
             const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
             const float d = (xx + yy) + zz;
-            md[i] = __builtin_fminf(d, md[i]);                 // slots past N hold -1 and stay there
+            md[i] = min_raw(d, md[i]);                         // slots past N hold -1 and stay there
         }
         float bm = md[0];                                     // maximum first, then the lowest slot that holds it
 #pragma unroll
