@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpn2_hip.so")
+LIB_PATH = os.environ.get("PN2_LIB_PATH") or os.path.join(_HERE, "libpn2_hip.so")   # override: A/B runs of two builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double

@@ -112,6 +112,43 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
     }
 };
 
+// The same operand for the TN (wgrad) kernel: there a thread's channel quad is fixed for the whole launch, so the three
+// constant rows are fetched ONCE (params(), hoisted in front of the position loop) instead of with every stage.
+struct LoadBnReluFixed {
+    const float *X; int ldx; const float *aff;
+    static constexpr int kRegs = 4;
+    template <int IT> struct Raw { float4 x[IT]; };
+    struct Params { float4 mu, sc, be; };
+    template <int IT>
+    __device__ __forceinline__ void issue(Raw<IT> &r, int64_t m, int stride, int k, int64_t rows, bool kvalid) const {
+        const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int64_t mi = m + (int64_t)i * stride;
+            r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : zp);
+        }
+    }
+    __device__ __forceinline__ Params params(int k, bool kvalid) const {
+        Affine a(aff, ldx);
+        const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+        Params q;
+        q.mu = ld4(kvalid ? a.mean + k : zp);          // pad / invalid columns: scale = beta = 0 -> operand 0
+        q.sc = ld4(kvalid ? a.scale + k : zp);
+        q.be = ld4(kvalid ? a.beta + k : zp);
+        return q;
+    }
+    template <int IT>
+    __device__ __forceinline__ float4 finish(const Raw<IT> &r, int i, bool valid, const Params &q) const {
+        const float4 x = r.x[i];
+        float4 o;
+        o.x = fmaxf(bn_act(x.x, q.mu.x, q.sc.x, q.be.x), 0.f);
+        o.y = fmaxf(bn_act(x.y, q.mu.y, q.sc.y, q.be.y), 0.f);
+        o.z = fmaxf(bn_act(x.z, q.mu.z, q.sc.z, q.be.z), 0.f);
+        o.w = fmaxf(bn_act(x.w, q.mu.w, q.sc.w, q.be.w), 0.f);
+        return valid ? o : kZero4;
+    }
+};
+
 struct DyParams { float4 c0, q1, q0, mu; };
 
 __device__ __forceinline__ DyParams dy_params(const float *coef, int ldc, int k, bool kvalid) {
@@ -763,12 +800,13 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
         xload.template issue<B_IT>(rb, p0 + brow, BR, n0 + bcq, p_end, n0 + bcq < N);
     };
 
+    // a thread's channel quads are fixed for the whole launch: the per-channel constants are fetched once
+    const typename DyLoad::Params dp = dyload.params(m0 + acq, m0 + acq < M);
+    const typename XLoad::Params xp = xload.params(n0 + bcq, n0 + bcq < N);
     if (p_begin < p_end) fetch(p_begin);
     int buf = 0;
     for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_BP) {
         float *Ab = As[buf], *Bb = Bs[buf];
-        const typename DyLoad::Params dp = dyload.params(m0 + acq, m0 + acq < M);
-        const typename XLoad::Params xp = xload.params(n0 + bcq, n0 + bcq < N);
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const float4 v = dyload.template finish<A_IT>(ra, i, (p0 + arow + i * AR < p_end) && (m0 + acq < M), dp);
@@ -1430,12 +1468,12 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
             }
         }
         LoadDyDense dy{dZ, ldz, Y, ldy, coef, ldc};
-        if (x_affine) return dispatch_tn(dy, LoadBnRelu{X, ldx, x_affine}, P, M, N, dW, lddw, dbias, s);
+        if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine}, P, M, N, dW, lddw, dbias, s);
         return dispatch_tn(dy, LoadPlain{X, ldx}, P, M, N, dW, lddw, dbias, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= round4(M));
     LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc};
-    if (x_affine) return dispatch_tn(dy, LoadBnRelu{X, ldx, x_affine}, P, M, N, dW, lddw, dbias, s);
+    if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine}, P, M, N, dW, lddw, dbias, s);
     return dispatch_tn(dy, LoadPlain{X, ldx}, P, M, N, dW, lddw, dbias, s);
 }
 
