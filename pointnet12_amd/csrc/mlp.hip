@@ -37,6 +37,16 @@ __device__ __forceinline__ int4 ld4i(const int32_t *p) { return *reinterpret_cas
 
 const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};
 __device__ float4 pn2_zero_page[4];          // always-zero source for predicated-off operand requests
+// Its address travels to the kernels as an argument (last member of every loader / of BMat / of the dgrad epilogue): a
+// __device__ symbol is reached through the GOT, and inside the stage loops that was one s_load + s_waitcnt lgkmcnt(0)
+// per predicated request -- the wait also drains the LDS stores issued just before it.
+static const float *zero_page_dev() {
+    static const float *p = [] {
+        void *q = nullptr;
+        return hipGetSymbolAddress(&q, HIP_SYMBOL(pn2_zero_page)) == hipSuccess ? reinterpret_cast<const float *>(q) : nullptr;
+    }();
+    return p;
+}
 
 // The per-channel constants of a loader's 4 columns are (re)loaded by params() at finish time -- they hit L1/L2,
 // and keeping them out of the in-flight register set is what lets the kernels run at 3-4 workgroups per CU
@@ -48,7 +58,7 @@ __device__ float4 pn2_zero_page[4];          // always-zero source for predicate
 struct LoadPlain {          // X as stored
     static constexpr int kTab = 0;
     __device__ __forceinline__ const float *tab_src() const { return nullptr; }
-    const float *X; int ldx;
+    const float *X; int ldx; const float *zp;
     static constexpr int kRegs = 4;
     template <int IT> struct Raw { float4 x[IT]; };
     struct Params {};
@@ -57,7 +67,7 @@ struct LoadPlain {          // X as stored
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
-            r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : reinterpret_cast<const float *>(pn2_zero_page));
+            r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : zp);
         }
     }
     __device__ __forceinline__ Params params(int, bool) const { return Params(); }
@@ -67,7 +77,7 @@ struct LoadPlain {          // X as stored
 };
 
 struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
-    const float *X; int ldx; const float *aff;
+    const float *X; int ldx; const float *aff; const float *zp;
     static constexpr int kRegs = 4;
     static constexpr int kTab = 0;          // its constants ride in the prefetched Raw registers
     __device__ __forceinline__ const float *tab_src() const { return nullptr; }
@@ -78,7 +88,6 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
         Affine a(aff, ldx);
         // every request is always issued (invalid ones read the zero page): straight-line code lets the compiler
         // count the outstanding requests instead of draining them
-        const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
         r.mu = ld4(kvalid ? a.mean + k : zp);          // pad / invalid columns: scale = beta = 0 -> operand 0
         r.sc = ld4(kvalid ? a.scale + k : zp);
         r.be = ld4(kvalid ? a.beta + k : zp);
@@ -115,13 +124,12 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
 // The same operand for the TN (wgrad) kernel: there a thread's channel quad is fixed for the whole launch, so the three
 // constant rows are fetched ONCE (params(), hoisted in front of the position loop) instead of with every stage.
 struct LoadBnReluFixed {
-    const float *X; int ldx; const float *aff;
+    const float *X; int ldx; const float *aff; const float *zp;
     static constexpr int kRegs = 4;
     template <int IT> struct Raw { float4 x[IT]; };
     struct Params { float4 mu, sc, be; };
     template <int IT>
     __device__ __forceinline__ void issue(Raw<IT> &r, int64_t m, int stride, int k, int64_t rows, bool kvalid) const {
-        const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
@@ -130,7 +138,6 @@ struct LoadBnReluFixed {
     }
     __device__ __forceinline__ Params params(int k, bool kvalid) const {
         Affine a(aff, ldx);
-        const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
         Params q;
         q.mu = ld4(kvalid ? a.mean + k : zp);          // pad / invalid columns: scale = beta = 0 -> operand 0
         q.sc = ld4(kvalid ? a.scale + k : zp);
@@ -151,9 +158,8 @@ struct LoadBnReluFixed {
 
 struct DyParams { float4 c0, q1, q0, mu; };
 
-__device__ __forceinline__ DyParams dy_params(const float *coef, int ldc, int k, bool kvalid) {
+__device__ __forceinline__ DyParams dy_params(const float *coef, int ldc, int k, bool kvalid, const float *zp) {
     DyParams q;
-    const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
     q.c0 = ld4(kvalid ? coef + k : zp);
     q.q1 = ld4(kvalid ? coef + ldc + k : zp);
     q.q0 = ld4(kvalid ? coef + 2 * ldc + k : zp);
@@ -182,7 +188,7 @@ __device__ __forceinline__ float4 dy_from(const float4 dz, const float4 y, const
 }
 
 struct LoadDyDense {
-    const float *dZ; int ldz; const float *Y; int ldy; const float *coef; int ldc;
+    const float *dZ; int ldz; const float *Y; int ldy; const float *coef; int ldc; const float *zp;
     static constexpr int kRegs = 8;
     template <int IT> struct Raw { float4 dz[IT], y[IT]; };
     typedef DyParams Params;
@@ -192,12 +198,11 @@ struct LoadDyDense {
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
             const bool v = kvalid && mi < rows;
-            const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
-            r.dz[i] = ld4(v ? dZ + mi * ldz + k : zp);
+                r.dz[i] = ld4(v ? dZ + mi * ldz + k : zp);
             r.y[i] = ld4(v ? Y + mi * ldy + k : zp);
         }
     }
-    __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid); }
+    __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid, zp); }
     static constexpr int kTab = 4;
     __device__ __forceinline__ const float *tab_src() const { return coef; }       // 4 rows of pitch ldc == K4
     __device__ __forceinline__ Params params_tab(const float *tab, int K4, int k, bool kvalid) const {
@@ -213,7 +218,7 @@ struct LoadDyDense {
 // dZp = dOut * (out > 0) was written once by pn2_pool_bwd_reduce (keeps this loader at 3 requests per row).
 struct LoadDyPooled {
     const float *dZp; int ldo; const int32_t *arg; int Kp;
-    const float *Y; int ldy; const float *coef; int ldc;
+    const float *Y; int ldy; const float *coef; int ldc; const float *zp;
     static constexpr int kRegs = 13;
     template <int IT> struct Raw { float4 go[IT], y[IT]; int4 a[IT]; int kk[IT]; };
     typedef DyParams Params;
@@ -225,13 +230,12 @@ struct LoadDyPooled {
             const bool v = kvalid && mi < rows;
             const unsigned g = (unsigned)mi / (unsigned)Kp;         // P < 2^31 (checked by the host wrapper)
             r.kk[i] = (int)((unsigned)mi - g * (unsigned)Kp);
-            const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
-            r.go[i] = ld4(v ? dZp + (int64_t)g * ldo + k : zp);           // invalid: dZp = 0 -> dz = 0 whatever arg says
-            r.a[i] = ld4i(v ? arg + (int64_t)g * ldo + k : reinterpret_cast<const int32_t *>(pn2_zero_page));
+                r.go[i] = ld4(v ? dZp + (int64_t)g * ldo + k : zp);           // invalid: dZp = 0 -> dz = 0 whatever arg says
+            r.a[i] = ld4i(v ? arg + (int64_t)g * ldo + k : reinterpret_cast<const int32_t *>(zp));
             r.y[i] = ld4(v ? Y + mi * ldy + k : zp);
         }
     }
-    __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid); }
+    __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid, zp); }
     static constexpr int kTab = 4;
     __device__ __forceinline__ const float *tab_src() const { return coef; }       // 4 rows of pitch ldc == K4
     __device__ __forceinline__ Params params_tab(const float *tab, int K4, int k, bool kvalid) const {
@@ -308,7 +312,7 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
 };
 
 struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev), sum(dZprev*yhat_prev) -> red
-    float *dX; int ldx; const float *prevY; int ldp; const float *aff; int lda; double *red; CoefTail ct;
+    float *dX; int ldx; const float *prevY; int ldp; const float *aff; int lda; double *red; CoefTail ct; const float *zp;
     static constexpr bool kHasStats = true;
     __host__ __device__ __forceinline__ unsigned *ticket() const { return ct.ticket; }
     __device__ __forceinline__ void tail(int N) const { run_coef_tail(ct, red, N, NTHREADS); }
@@ -322,7 +326,7 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
     // of every group of stores.
     struct Pre { float4 y; };
     __device__ __forceinline__ void pre_issue(Pre &q, int64_t m, int n, bool valid) const {
-        q.y = ld4(valid ? prevY + m * ldp + n : reinterpret_cast<const float *>(pn2_zero_page));
+        q.y = ld4(valid ? prevY + m * ldp + n : zp);
     }
     __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], const Pre &q, float4 &s0,
                                           float4 &s1) const {
@@ -404,11 +408,11 @@ __device__ unsigned long long pn2_stamp_buf[8 * 2048];
 //                            dX = dY * W needs W[k = c_out][n = c_in], so no transposed copy is ever made)
 // vec != 0: rows are 16-byte aligned (pointer and pitch) and whole float4 reads stay inside a row; otherwise
 // the tile is fetched with guarded scalar loads (weights sliced out of a wider matrix, C_in not a multiple of 4).
-struct BMat { const float *p; int ld; int K; int vec; };
+struct BMat { const float *p; int ld; int K; int vec; const float *zp; };
 
 inline BMat make_bmat(const float *p, int ld, int K, int contiguous_len) {
     const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (contiguous_len & 3) == 0;
-    return BMat{p, ld, K, vec ? 1 : 0};
+    return BMat{p, ld, K, vec ? 1 : 0, zero_page_dev()};
 }
 
 template <int BM, int BN, int BK, bool BNN = false>
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
         const int k = ks * BK + lkq;
         const bool kvalid = k < K4 && tile < tiles_m;
         aload.template issue<A_IT>(qa, tile * BM + lrow, RPL, k, P, kvalid);
-        const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+        const float *zp = bm.zp;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int r = brow + i * RPLB;
@@ -1341,8 +1345,8 @@ int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float
     const int K4 = round4(K);
     EpiFwd epi{Y, ldy, bias, stats, make_fin_tail(fin, P)};
     const BMat bm = make_bmat(W, ldw, K, K);
-    if (in_affine) return dispatch_nt<false>(LoadBnRelu{X, ldx, in_affine}, bm, P, K4, N, epi, pn2_s(stream));
-    return dispatch_nt<false>(LoadPlain{X, ldx}, bm, P, K4, N, epi, pn2_s(stream));
+    if (in_affine) return dispatch_nt<false>(LoadBnRelu{X, ldx, in_affine, zero_page_dev()}, bm, P, K4, N, epi, pn2_s(stream));
+    return dispatch_nt<false>(LoadPlain{X, ldx, zero_page_dev()}, bm, P, K4, N, epi, pn2_s(stream));
 }
 
 int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, const float *beta, float eps,
@@ -1434,17 +1438,17 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     hipStream_t s = pn2_s(stream);
     if (dZ) {
         PN2_CHECK_ARG(ldz % 4 == 0 && ldz >= K4);
-        LoadDyDense ld{dZ, ldz, Y, ldy, coef, ldc};
+        LoadDyDense ld{dZ, ldz, Y, ldy, coef, ldc, zero_page_dev()};
         if (prev_Y)
             return dispatch_nt<true>(ld, bm, P, K4, N,
-                                     EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct}, s);
+                                     EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s);
         return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= K4);
-    LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc};
+    LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev()};
     if (prev_Y)
         return dispatch_nt<true>(ld, bm, P, K4, N,
-                                 EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct}, s);
+                                 EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s);
     return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
 }
 
@@ -1467,14 +1471,14 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
                 default: return launch_skinny<4>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
             }
         }
-        LoadDyDense dy{dZ, ldz, Y, ldy, coef, ldc};
-        if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine}, P, M, N, dW, lddw, dbias, s);
-        return dispatch_tn(dy, LoadPlain{X, ldx}, P, M, N, dW, lddw, dbias, s);
+        LoadDyDense dy{dZ, ldz, Y, ldy, coef, ldc, zero_page_dev()};
+        if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
+        return dispatch_tn(dy, LoadPlain{X, ldx, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= round4(M));
-    LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc};
-    if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine}, P, M, N, dW, lddw, dbias, s);
-    return dispatch_tn(dy, LoadPlain{X, ldx}, P, M, N, dW, lddw, dbias, s);
+    LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev()};
+    if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
+    return dispatch_tn(dy, LoadPlain{X, ldx, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
 }
 
 }  // extern "C"
