@@ -536,6 +536,9 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             if (tile >= tiles_m) break;
             const int64_t m0 = tile * BM;
             if (ks == 0) {
+                // keep this a (uniform) branch: if-converted it became one v_cndmask per accumulator register in EVERY
+                // k-step, sitting between dependent MFMAs on the same accumulators
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll

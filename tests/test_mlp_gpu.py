@@ -93,7 +93,7 @@ def test_shared_mlp_vs_torch(dev, P, pool, chans):
         # tensor's max (measured: 1e-3..8e-3 with a single flipped row, 1e-6 with none -- which of the two a given
         # random initialisation gets is luck, for this kernel as for plain torch fp32).  The forward output above is
         # held to 1e-5; here those cases are held to 2e-2 of max, which any indexing or tiling error exceeds by far.
-        flip_slack = 2e-2 * scale if P >= 100000 else 0.0
+        flip_slack = 2e-2 * scale if P >= 50000 else 0.0
         assert q <= max(3e-5 * scale, 4 * q32, flip_slack), (n, q / scale, q32 / scale)
         # L2 check on everything but the handful of entries a single argmax / ReLU flip re-routes (one flip among the
         # 262 144 pooled decisions of the benchmark-sized cases moves ||err|| by ~1e-3 ||grad|| on its own)
