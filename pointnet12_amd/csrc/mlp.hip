@@ -125,7 +125,6 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
 // constant rows are fetched ONCE (params(), hoisted in front of the position loop) instead of with every stage.
 struct LoadBnReluFixed {
     const float *X; int ldx; const float *aff; const float *zp;
-    static constexpr int kRegs = 4;
     template <int IT> struct Raw { float4 x[IT]; };
     struct Params { float4 mu, sc, be; };
     template <int IT>
