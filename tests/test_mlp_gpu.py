@@ -159,3 +159,28 @@ def test_nll_loss_all_ignored_is_nan(dev):
     lp = torch.log_softmax(torch.randn(64, 4), dim=-1).to(dev)
     assert np.isnan(float(nll_loss(lp, torch.full((64,), -100))))
     assert np.isnan(float(F.nll_loss(lp.cpu(), torch.full((64,), -100))))
+
+
+@pytest.mark.parametrize("P,ci,co", [(70001, 32, 32), (40000, 32, 64), (9000, 20, 32), (150000, 128, 13), (4096, 196, 196),
+                                     (300000, 64, 96)])
+def test_plain_conv1x1_bias_and_weight_gradients(dev, P, ci, co):
+    """The per-point linear layer without BatchNorm (segmentation-head classifier, model/pointnet2.py:174): here the
+    bias gradient is NOT zero, so this is the check of the wgrad kernels' column-sum path -- including the 32x32 / 64x32
+    tiles whose waves split a stage, the 64x64 few-row tiles and the 128 + remainder column split."""
+    import torch.nn as nn
+    from pointnet12_amd import pointnet_util as U
+    torch.manual_seed(P + ci)
+    conv = nn.Conv1d(ci, co, 1).to(dev)
+    x = torch.randn(P, ci, device=dev)
+    gw = torch.randn(P, co, device=dev)
+    xm = x.clone().requires_grad_(True)
+    y = U.conv1x1(xm, conv)
+    (y * gw).sum().backward()
+    mine = [y.detach(), xm.grad, conv.weight.grad.clone(), conv.bias.grad.clone()]
+    W, b = conv.weight.detach().double()[:, :, 0], conv.bias.detach().double()
+    xd, gd = x.double(), gw.double()
+    ref = [xd @ W.t() + b, gd @ W, gd.t() @ xd, gd.sum(0)]
+    for name, a, r in zip(("y", "dx", "dW", "db"), mine, ref):
+        a = a.double().reshape(r.shape)
+        tol = 2e-6 * float(r.abs().max()) * max(1.0, (ci if name in ("y",) else co if name == "dx" else P) ** 0.5 / 8)
+        assert float((a - r).abs().max()) <= tol, (name, float((a - r).abs().max()), tol)
