@@ -553,6 +553,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
                 for (int i = 0; i < B_IT; ++i)
                     if ((NTHREADS % TPRB == 0 && BROWS % RPLB == 0) || (brow < RPLB && brow + i * RPLB < BROWS))
                         *reinterpret_cast<float4 *>(&Bb[(brow + i * RPLB) * LDBS + bcq]) = fb[i];
+                asm volatile("" ::: "memory");      // keep these stores here: merged with the other branch's they cost 12 v_mov per k-step
             } else {
                 const bool kv = ks * BK + lkq < K4;
                 const typename ALoad::Params ap = aload.params_tab(nt_tab, K4, ks * BK + lkq, kv);
