@@ -173,7 +173,7 @@ int pn2_copy_cols(const float *src, int lds, int scol0, float *dst, int ldd, int
  * weight -- with guarded scalar loads).  Y pitch ldy (multiple of 4, >= round4(N); pad lanes are
  * written as zeros).  in_affine: NULL (X is used as is) or the affine block (4*ldx floats) of
  * the layer that produced X.  stats: NULL or a replicated double[2*N] block (see PN2_STAT_REPLICAS; caller zeroes) receiving
- * sum(y) and sum(y*y) per output channel over the P rows (training-mode BN statistics). */
+ * sum(y) and sum(y*y) per output channel over the P rows (training-mode BN statistics).  P < 2^31 rows for the three conv1x1 entry points (PN2_EINVAL otherwise). */
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias,
                     float *Y, int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin,
                     pn2_stream_t stream);

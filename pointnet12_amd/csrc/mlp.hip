@@ -36,6 +36,14 @@ __device__ __forceinline__ int4 ld4i(const int32_t *p) { return *reinterpret_cas
 // Rows of one loader thread are m + i*stride, i < IT, all at the same 4 columns k..k+3.
 
 const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};
+
+// Element offset of a row of a position-major matrix.  The GEMM entry points take P < 2^31 rows (checked on the host),
+// so row * pitch is ONE v_mad_u64_u32 -- as int64 * int the compiler forms it from two 32-bit multiplies, a 64-bit
+// multiply-add and an add3, per request and k-step.
+__device__ __forceinline__ int64_t row_off(int64_t row, int ld) {
+    return (int64_t)((uint64_t)(uint32_t)row * (uint64_t)(uint32_t)ld);
+}
+
 __device__ float4 pn2_zero_page[4];          // always-zero source for predicated-off operand requests
 // Its address travels to the kernels as an argument (last member of every loader / of BMat / of the dgrad epilogue): a
 // __device__ symbol is reached through the GOT, and inside the stage loops that was one s_load + s_waitcnt lgkmcnt(0)
@@ -67,7 +75,7 @@ struct LoadPlain {          // X as stored
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
-            r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : zp);
+            r.x[i] = ld4((kvalid && mi < rows) ? X + row_off(mi, ldx) + k : zp);
         }
     }
     __device__ __forceinline__ Params params(int, bool) const { return Params(); }
@@ -99,11 +107,11 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
 #elif defined(PN2_X_NTLOAD)
             {
                 typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f xv = __builtin_nontemporal_load(reinterpret_cast<const v4f *>((kvalid && mi < rows) ? X + mi * ldx + k : zp));
+                const v4f xv = __builtin_nontemporal_load(reinterpret_cast<const v4f *>((kvalid && mi < rows) ? X + row_off(mi, ldx) + k : zp));
                 r.x[i] = make_float4(xv.x, xv.y, xv.z, xv.w);
             }
 #else
-            r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : zp);
+            r.x[i] = ld4((kvalid && mi < rows) ? X + row_off(mi, ldx) + k : zp);
 #endif
         }
     }
@@ -132,7 +140,7 @@ struct LoadBnReluFixed {
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
-            r.x[i] = ld4((kvalid && mi < rows) ? X + mi * ldx + k : zp);
+            r.x[i] = ld4((kvalid && mi < rows) ? X + row_off(mi, ldx) + k : zp);
         }
     }
     __device__ __forceinline__ Params params(int k, bool kvalid) const {
@@ -197,8 +205,8 @@ struct LoadDyDense {
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
             const bool v = kvalid && mi < rows;
-                r.dz[i] = ld4(v ? dZ + mi * ldz + k : zp);
-            r.y[i] = ld4(v ? Y + mi * ldy + k : zp);
+                r.dz[i] = ld4(v ? dZ + row_off(mi, ldz) + k : zp);
+            r.y[i] = ld4(v ? Y + row_off(mi, ldy) + k : zp);
         }
     }
     __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid, zp); }
@@ -229,9 +237,9 @@ struct LoadDyPooled {
             const bool v = kvalid && mi < rows;
             const unsigned g = (unsigned)mi / (unsigned)Kp;         // P < 2^31 (checked by the host wrapper)
             r.kk[i] = (int)((unsigned)mi - g * (unsigned)Kp);
-                r.go[i] = ld4(v ? dZp + (int64_t)g * ldo + k : zp);           // invalid: dZp = 0 -> dz = 0 whatever arg says
-            r.a[i] = ld4i(v ? arg + (int64_t)g * ldo + k : reinterpret_cast<const int32_t *>(zp));
-            r.y[i] = ld4(v ? Y + mi * ldy + k : zp);
+                r.go[i] = ld4(v ? dZp + row_off(g, ldo) + k : zp);           // invalid: dZp = 0 -> dz = 0 whatever arg says
+            r.a[i] = ld4i(v ? arg + row_off(g, ldo) + k : reinterpret_cast<const int32_t *>(zp));
+            r.y[i] = ld4(v ? Y + row_off(mi, ldy) + k : zp);
         }
     }
     __device__ __forceinline__ Params params(int k, bool kvalid) const { return dy_params(coef, ldc, k, kvalid, zp); }
@@ -293,10 +301,10 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
             // operand stream and the weights (+2..6 % on the forward GEMMs, tools/bench_kernels.py)
             typedef float v4f __attribute__((ext_vector_type(4)));
             const v4f yv = {y.x, y.y, y.z, y.w};
-            __builtin_nontemporal_store(yv, reinterpret_cast<v4f *>(Y + m * ldy + n));
+            __builtin_nontemporal_store(yv, reinterpret_cast<v4f *>(Y + row_off(m, ldy) + n));
         }
 #else
-        *reinterpret_cast<float4 *>(Y + m * ldy + n) = y;
+        *reinterpret_cast<float4 *>(Y + row_off(m, ldy) + n) = y;
 #endif
 #endif
         s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
@@ -325,7 +333,7 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
     // of every group of stores.
     struct Pre { float4 y; };
     __device__ __forceinline__ void pre_issue(Pre &q, int64_t m, int n, bool valid) const {
-        q.y = ld4(valid ? prevY + m * ldp + n : zp);
+        q.y = ld4(valid ? prevY + row_off(m, ldp) + n : zp);
     }
     __device__ __forceinline__ void apply(int64_t m, int n, int N, float4 acc, const float4 (&c)[4], const Pre &q, float4 &s0,
                                           float4 &s1) const {
@@ -338,7 +346,7 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
         {   // streaming store (see EpiFwd); pad lanes: scale = beta = 0 -> 0
             typedef float v4f __attribute__((ext_vector_type(4)));
             const v4f dv = {dz.x, dz.y, dz.z, dz.w};
-            __builtin_nontemporal_store(dv, reinterpret_cast<v4f *>(dX + m * ldx + n));
+            __builtin_nontemporal_store(dv, reinterpret_cast<v4f *>(dX + row_off(m, ldx) + n));
         }
         s0.x += dz.x; s0.y += dz.y; s0.z += dz.z; s0.w += dz.w;
         s1.x = __builtin_fmaf(dz.x, (y.x - c[0].x) * c[3].x, s1.x);
@@ -364,7 +372,7 @@ struct EpiStore {           // first layer: dX0 = acc (pad lanes are exact zeros
     __device__ __forceinline__ void pre_issue(Pre &, int64_t, int, bool) const {}
     __device__ __forceinline__ void apply(int64_t m, int n, int, float4 acc, const float4 (&)[4], const Pre &, float4 &,
                                           float4 &) const {
-        *reinterpret_cast<float4 *>(dX + m * ldx + n) = acc;
+        *reinterpret_cast<float4 *>(dX + row_off(m, ldx) + n) = acc;
     }
     __device__ __forceinline__ void flush(int, int, double, double) const {}
 };
@@ -1343,7 +1351,7 @@ extern "C" {
 
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
                     int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin, pn2_stream_t stream) {
-    PN2_CHECK_ARG(X && W && bias && Y && P > 0 && K > 0 && N > 0 && fin_tail_ok(fin, stats));
+    PN2_CHECK_ARG(X && W && bias && Y && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && fin_tail_ok(fin, stats));
     PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= round4(K) && ldw >= K && ldy % 4 == 0 && ldy >= round4(N));
     const int K4 = round4(K);
     EpiFwd epi{Y, ldy, bias, stats, make_fin_tail(fin, P)};
@@ -1430,7 +1438,7 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
 int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
                       double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail, pn2_stream_t stream) {
-    PN2_CHECK_ARG(Y && coef && W && dXout && P > 0 && K > 0 && N > 0 && coef_tail_ok(prev_tail, prev_red) &&
+    PN2_CHECK_ARG(Y && coef && W && dXout && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && coef_tail_ok(prev_tail, prev_red) &&
                   (prev_tail == nullptr || prev_Y != nullptr));
     const CoefTail ct = make_coef_tail(prev_tail, P);
     PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
@@ -1458,7 +1466,7 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
 int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       pn2_stream_t stream) {
-    PN2_CHECK_ARG(Y && coef && X && dW && P > 0 && M > 0 && N > 0);
+    PN2_CHECK_ARG(Y && coef && X && dW && P > 0 && P < (1LL << 31) && M > 0 && N > 0);
     PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
     PN2_CHECK_ARG(ldy % 4 == 0 && ldy >= round4(M) && ldx % 4 == 0 && ldx >= round4(N) && lddw >= N);
     const int ldc = round4(M);
