@@ -48,6 +48,13 @@ __device__ float4 pn2_zero_page[4];          // always-zero source for predicate
 // Its address travels to the kernels as an argument (last member of every loader / of BMat / of the dgrad epilogue): a
 // __device__ symbol is reached through the GOT, and inside the stage loops that was one s_load + s_waitcnt lgkmcnt(0)
 // per predicated request -- the wait also drains the LDS stores issued just before it.
+static inline int pow2_shift(int v) {          // log2(v) for a power of two, else -1
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int sft = 0;
+    while ((1 << sft) < v) ++sft;
+    return sft;
+}
+
 static const float *zero_page_dev() {
     static const float *p = [] {
         void *q = nullptr;
@@ -225,7 +232,7 @@ struct LoadDyDense {
 // dZp = dOut * (out > 0) was written once by pn2_pool_bwd_reduce (keeps this loader at 3 requests per row).
 struct LoadDyPooled {
     const float *dZp; int ldo; const int32_t *arg; int Kp;
-    const float *Y; int ldy; const float *coef; int ldc; const float *zp;
+    const float *Y; int ldy; const float *coef; int ldc; const float *zp; int kshift;   // kshift: log2(Kp) or -1
     static constexpr int kRegs = 13;
     template <int IT> struct Raw { float4 go[IT], y[IT]; int4 a[IT]; int kk[IT]; };
     typedef DyParams Params;
@@ -235,7 +242,9 @@ struct LoadDyPooled {
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
             const bool v = kvalid && mi < rows;
-            const unsigned g = (unsigned)mi / (unsigned)Kp;         // P < 2^31 (checked by the host wrapper)
+            // group and position inside it; P < 2^31 (checked by the host wrapper).  Kp is a power of two in every network
+            // of the reference (16 .. 128): a shift and a mask instead of the ~12-instruction division sequence.
+            const unsigned g = kshift >= 0 ? (unsigned)mi >> kshift : (unsigned)mi / (unsigned)Kp;
             r.kk[i] = (int)((unsigned)mi - g * (unsigned)Kp);
                 r.go[i] = ld4(v ? dZp + row_off(g, ldo) + k : zp);           // invalid: dZp = 0 -> dz = 0 whatever arg says
             r.a[i] = ld4i(v ? arg + row_off(g, ldo) + k : reinterpret_cast<const int32_t *>(zp));
@@ -1456,7 +1465,7 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
         return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= K4);
-    LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev()};
+    LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev(), pow2_shift(Kpool)};
     if (prev_Y)
         return dispatch_nt<true>(ld, bm, P, K4, N,
                                  EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s);
@@ -1487,7 +1496,7 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
         return dispatch_tn(dy, LoadPlain{X, ldx, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= round4(M));
-    LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev()};
+    LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev(), pow2_shift(Kpool)};
     if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
     return dispatch_tn(dy, LoadPlain{X, ldx, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
 }
