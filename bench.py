@@ -28,6 +28,9 @@ if ROOT not in sys.path:
 # RCCL between processes needs dmabuf IPC on this host driver (already exported on the GPU boxes; kept here so a bare
 # `torch.distributed.run bench.py` works too).  Must be set before the HIP runtime loads.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# kernel arguments in device memory: the ROCm 7.2 default on gfx950; with 0 every launch of the replayed graph costs more
+# (SSG step 2.96 -> 3.23 ms, MSG 7.34 -> 7.56 ms, measured) -- pinned so a differing site default cannot change the number
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
