@@ -226,13 +226,14 @@ class RefMSGSemSeg(_SegHead):
     """MSG-SemSeg of SURVEY.md §8(d): PointNet2PartSegMsg_one_hot (model/pointnet2.py:106-139)
     without the 16-channel one-hot label, with D extra input features."""
 
-    def __init__(self, num_classes, feature_dims=6, dropout=0.5):
+    def __init__(self, num_classes, feature_dims=6, dropout=0.5, npoint_scale=1):
         super().__init__()
         d = feature_dims
         self.feature_dims = d
-        self.sa1 = RefSetAbstractionMsg(512, [0.1, 0.2, 0.4], [32, 64, 128], d,
+        # npoint_scale: BASELINE.json cfg5 (dense 65 536-point scans) scales the sampled-point counts by 16
+        self.sa1 = RefSetAbstractionMsg(512 * npoint_scale, [0.1, 0.2, 0.4], [32, 64, 128], d,
                                         [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
-        self.sa2 = RefSetAbstractionMsg(128, [0.4, 0.8], [64, 128], 128 + 128 + 64,
+        self.sa2 = RefSetAbstractionMsg(128 * npoint_scale, [0.4, 0.8], [64, 128], 128 + 128 + 64,
                                         [[128, 128, 256], [128, 196, 256]])
         self.sa3 = RefSetAbstraction(None, None, None, 512 + 3, [256, 512, 1024], True)
         self.fp3 = RefFeaturePropagation(1536, [256, 256])
@@ -248,6 +249,113 @@ class RefMSGSemSeg(_SegHead):
         f2 = self.fp3(x2, x3, f2, f3)
         f1 = self.fp2(x1, x2, f1, f2)
         f0 = self.fp1(xyz, x1, torch.cat([xyz, feat], 1), f1)
+        return self.head(f0)
+
+
+class _ClsHead(nn.Module):
+    """fc1/bn1/drop1/fc2/bn2/drop2/fc3 + log_softmax of model/pointnet2.py:29-46, :56-72."""
+
+    def _make_cls_head(self, dropout):
+        self.fc1 = nn.Linear(1024, 512)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.drop1 = nn.Dropout(dropout)
+        self.fc2 = nn.Linear(512, 256)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.drop2 = nn.Dropout(dropout)
+        self.fc3 = nn.Linear(256, 40)
+
+    def cls_head(self, l3):
+        x = l3.view(l3.shape[0], 1024)
+        x = self.drop1(F.relu(self.bn1(self.fc1(x))))
+        x = self.drop2(F.relu(self.bn2(self.fc2(x))))
+        return F.log_softmax(self.fc3(x), -1)
+
+
+class RefClsMsg(_ClsHead):
+    """Restates PointNet2ClsMsg (model/pointnet2.py:7-47): returns (log_probs, l3_points)."""
+
+    def __init__(self, dropout=0.4):
+        super().__init__()
+        self.sa1 = RefSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0,
+                                        [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+        self.sa2 = RefSetAbstractionMsg(128, [0.2, 0.4, 0.8], [32, 64, 128], 320,
+                                        [[64, 64, 128], [128, 128, 256], [128, 128, 256]])
+        self.sa3 = RefSetAbstraction(None, None, None, 640 + 3, [256, 512, 1024], True)
+        self._make_cls_head(dropout)
+
+    def forward(self, xyz):
+        x1, f1 = self.sa1(xyz, None)
+        x2, f2 = self.sa2(x1, f1)
+        _, f3 = self.sa3(x2, f2)
+        return self.cls_head(f3), f3
+
+
+class RefClsSsg(_ClsHead):
+    """Restates PointNet2ClsSsg (model/pointnet2.py:49-73)."""
+
+    def __init__(self, dropout=0.4):
+        super().__init__()
+        self.sa1 = RefSetAbstraction(512, 0.2, 32, 3, [64, 64, 128], False)
+        self.sa2 = RefSetAbstraction(128, 0.4, 64, 128 + 3, [128, 128, 256], False)
+        self.sa3 = RefSetAbstraction(None, None, None, 256 + 3, [256, 512, 1024], True)
+        self._make_cls_head(dropout)
+
+    def forward(self, xyz):
+        x1, f1 = self.sa1(xyz, None)
+        x2, f2 = self.sa2(x1, f1)
+        _, f3 = self.sa3(x2, f2)
+        return self.cls_head(f3)
+
+
+class RefPartSegSsg(_SegHead):
+    """Restates PointNet2PartSegSsg (model/pointnet2.py:75-104): returns (log_probs [B,N,C], feat [B,128,N])."""
+
+    def __init__(self, num_classes, dropout=0.5):
+        super().__init__()
+        self.sa1 = RefSetAbstraction(512, 0.2, 64, 3, [64, 64, 128], False)
+        self.sa2 = RefSetAbstraction(128, 0.4, 64, 128 + 3, [128, 128, 256], False)
+        self.sa3 = RefSetAbstraction(None, None, None, 256 + 3, [256, 512, 1024], True)
+        self.fp3 = RefFeaturePropagation(1280, [256, 256])
+        self.fp2 = RefFeaturePropagation(384, [256, 128])
+        self.fp1 = RefFeaturePropagation(128, [128, 128, 128])
+        self._make_head(num_classes, dropout)
+
+    def forward(self, xyz):
+        x1, f1 = self.sa1(xyz, None)
+        x2, f2 = self.sa2(x1, f1)
+        x3, f3 = self.sa3(x2, f2)
+        f2 = self.fp3(x2, x3, f2, f3)
+        f1 = self.fp2(x1, x2, f1, f2)
+        f0 = self.fp1(xyz, x1, None, f1)
+        feat = F.relu(self.bn1(self.conv1(f0)))                        # :97
+        x = F.log_softmax(self.conv2(self.drop1(feat)), dim=1)
+        return x.permute(0, 2, 1), feat
+
+
+class RefPartSegMsgOneHot(_SegHead):
+    """Restates PointNet2PartSegMsg_one_hot (model/pointnet2.py:106-139)."""
+
+    def __init__(self, num_classes, dropout=0.5):
+        super().__init__()
+        self.sa1 = RefSetAbstractionMsg(512, [0.1, 0.2, 0.4], [32, 64, 128], 0 + 3,
+                                        [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+        self.sa2 = RefSetAbstractionMsg(128, [0.4, 0.8], [64, 128], 128 + 128 + 64,
+                                        [[128, 128, 256], [128, 196, 256]])
+        self.sa3 = RefSetAbstraction(None, None, None, 512 + 3, [256, 512, 1024], True)
+        self.fp3 = RefFeaturePropagation(1536, [256, 256])
+        self.fp2 = RefFeaturePropagation(576, [256, 128])
+        self.fp1 = RefFeaturePropagation(150, [128, 128])
+        self._make_head(num_classes, dropout)
+
+    def forward(self, xyz, norm_plt, cls_label):
+        B, _, N = xyz.shape
+        x1, f1 = self.sa1(xyz, norm_plt)
+        x2, f2 = self.sa2(x1, f1)
+        x3, f3 = self.sa3(x2, f2)
+        f2 = self.fp3(x2, x3, f2, f3)
+        f1 = self.fp2(x1, x2, f1, f2)
+        one_hot = cls_label.view(B, 16, 1).repeat(1, 1, N)                             # :129
+        f0 = self.fp1(xyz, x1, torch.cat([one_hot, xyz, norm_plt], 1), f1)             # :130
         return self.head(f0)
 
 

@@ -106,8 +106,12 @@ def test_network_matches_reference(dev, tag, make):
     lp = net(pts)
     loss = F.nll_loss(lp.reshape(-1, 13), labels.reshape(-1))
     loss.backward()
-    # nine BN-coupled stages deep and B*N = 2048 only: the reference's own 1-vs-8-thread noise here is 7e-5
-    assert np.abs(lp.detach().cpu().numpy() - g[tag + "/log_probs"]).max() <= 2e-4
+    # nine BN-coupled stages deep and B*N = 2048 only: the bound is twice what the REFERENCE moves against itself on
+    # this very input when only its thread count changes (8 vs 1), measured with the reference by
+    # tools/make_golden.py g6n -> g6_noise.npz (ssg 9.1e-5, msg 4.9e-5); the fp64 yardstick for the same case is in
+    # test_parity_fullsize_gpu.py
+    noise = float(golden("g6_noise.npz")[tag + "/log_probs_absdiff"])
+    assert np.abs(lp.detach().cpu().numpy() - g[tag + "/log_probs"]).max() <= 2 * noise
     assert abs(float(loss) - float(g[tag + "/loss"])) <= 2e-6
     grads = dict(net.named_parameters())
     for n, l2, amax in zip(g[tag + "/grad_names"], g[tag + "/grad_l2"], g[tag + "/grad_absmax"]):

@@ -397,6 +397,101 @@ def g6_nets():
     save("g6_nets.npz", **out)
 
 
+# ----------------------------------------------------------------------------- G6n the reference against itself
+def g6_noise():
+    """How far the REFERENCE moves against itself at the G6 size (B=2 x 1024) when only the thread count changes
+    (8 vs 1 threads: another summation order in MKL / the BatchNorm reductions).  tests/test_parity_fullsize_gpu.py
+    quotes these numbers next to the fp64 yardstick instead of asserting a remembered constant."""
+    print("G6n reference self-noise, 8 threads vs 1")
+    out = {}
+    pts_np, labels = syn.kitti_batch(200, 2, 1024)
+    pts = torch.from_numpy(pts_np)
+    for tag, make_ref in [("ssg", lambda: R2.PointNet2SemSeg(13, 6)), ("msg", lambda: RefMSGSemSegFromReference(13, 6))]:
+        runs = []
+        for threads in (8, 1):
+            torch.set_num_threads(threads)
+            torch.manual_seed(1234)
+            ref = make_ref()
+            ref.drop1.p = 0.0
+            ref.train()
+            torch.manual_seed(4321)
+            lp = ref(pts)
+            T.seg_loss(lp, labels).backward()
+            runs.append((lp.detach().numpy().copy(), {k: p.grad.numpy().copy() for k, p in ref.named_parameters()}))
+        torch.set_num_threads(8)
+        (la, ga), (lb, gb) = runs
+        out[tag + "/log_probs_absdiff"] = np.float64(np.abs(la - lb).max())
+        rel = {n: np.abs(ga[n] - gb[n]).max() / max(np.abs(ga[n]).max(), 1e-12) for n in ga
+               if not ("conv" in n and n.endswith("bias") and n != "conv2.bias")}
+        l2 = {n: abs(np.linalg.norm(ga[n].astype(np.float64)) - np.linalg.norm(gb[n].astype(np.float64))) /
+              max(np.linalg.norm(ga[n].astype(np.float64)), 1e-12) for n in rel}
+        out[tag + "/grad_relmax_worst"] = np.float64(max(rel.values()))
+        out[tag + "/grad_l2_worst"] = np.float64(max(l2.values()))
+        print("  %s: |dlog_probs| %.2e, worst grad relmax %.2e, worst grad L2 %.2e" % (
+            tag, out[tag + "/log_probs_absdiff"], out[tag + "/grad_relmax_worst"], out[tag + "/grad_l2_worst"]))
+    save("g6_noise.npz", **out)
+
+
+# ----------------------------------------------------------------------------- G10 the other four zoo nets
+def g10_zoo():
+    """PointNet2ClsMsg / ClsSsg / PartSegSsg / PartSegMsg_one_hot (reference model/pointnet2.py:7-139), train mode,
+    dropout off, B=2 x 1024: pins the oracle restatements of these nets and stores the reference's outputs."""
+    print("G10 zoo nets")
+    out = {}
+    pts_np, _ = syn.kitti_batch(400, 2, 1024)
+    xyz = torch.from_numpy(np.ascontiguousarray(pts_np[:, :3]))
+    nrm = torch.from_numpy(np.ascontiguousarray(pts_np[:, 3:6]))
+    cls = torch.zeros(2, 16)
+    cls[0, 3] = 1.0
+    cls[1, 11] = 1.0
+    nets = [("cls_msg", lambda: R2.PointNet2ClsMsg(), lambda: T.RefClsMsg(dropout=0.0), (xyz,)),
+            ("cls_ssg", lambda: R2.PointNet2ClsSsg(), lambda: T.RefClsSsg(dropout=0.0), (xyz,)),
+            ("partseg_ssg", lambda: R2.PointNet2PartSegSsg(50), lambda: T.RefPartSegSsg(50, dropout=0.0), (xyz,)),
+            ("partseg_msg", lambda: R2.PointNet2PartSegMsg_one_hot(50), lambda: T.RefPartSegMsgOneHot(50, dropout=0.0),
+             (xyz, nrm, cls))]
+    for tag, make_ref, make_orc, ins in nets:
+        torch.manual_seed(77)
+        ref = make_ref()
+        for m in ref.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        torch.manual_seed(77)
+        orc = make_orc()
+        check(state_digest(ref) == state_digest(orc), tag + ": seeded init of oracle net equals reference net")
+        res = {}
+        for which, net in (("ref", ref), ("orc", orc)):
+            net.train()
+            torch.manual_seed(88)
+            y = net(*ins)
+            ys = y if isinstance(y, tuple) else (y,)
+            gw = torch.randn(ys[0].shape, generator=torch.Generator().manual_seed(5))
+            (ys[0] * gw).sum().backward()
+            res[which] = ([t.detach().numpy() for t in ys], {k: p.grad.numpy().copy() for k, p in net.named_parameters()})
+        for i, (a, b) in enumerate(zip(res["ref"][0], res["orc"][0])):
+            d = np.abs(a - b).max()
+            check(a.shape == b.shape and d <= 2e-5, "%s: oracle output %d within 2e-5 of reference (%.2e)" % (tag, i, d))
+        names = sorted(res["ref"][1])
+        worst = 0.0
+        for n in names:
+            a, b = res["ref"][1][n].astype(np.float64), res["orc"][1][n].astype(np.float64)
+            if ("conv" in n and n.endswith("bias") and n != "conv2.bias") or (n.startswith("fc") and n.endswith("bias") and n != "fc3.bias"):
+                continue          # zero gradient under the BatchNorm that follows
+            worst = max(worst, abs(np.linalg.norm(a) - np.linalg.norm(b)) / max(np.linalg.norm(a), 1e-12))
+        check(worst <= 2e-2, "%s: per-tensor gradient L2 norms within 2e-2 (%.2e; flip noise of the tiny batch)" % (tag, worst))
+        out[tag + "/n_out"] = np.int64(len(res["ref"][0]))
+        for i, a in enumerate(res["ref"][0]):
+            out["%s/shape/%d" % (tag, i)] = np.array(a.shape, np.int64)
+            out["%s/out/%d" % (tag, i)] = a if a.size <= 4096 else a.reshape(-1)[::17].copy()
+        out[tag + "/grad_names"] = np.array(names)
+        out[tag + "/grad_l2"] = np.array([np.linalg.norm(res["ref"][1][n].astype(np.float64)) for n in names])
+    out["points"] = pts_np
+    out["cls_label"] = cls.numpy()
+    out["init_seed"] = np.int64(77)
+    out["fwd_seed"] = np.int64(88)
+    out["gw_seed"] = np.int64(5)
+    save("g10_zoo.npz", **out)
+
+
 def g7_checkpoint():
     """Shipped checkpoint (eval mode): stores input + output only; the weights stay in the reference."""
     print("G7 shipped checkpoint, eval mode")
@@ -422,8 +517,8 @@ def g7_checkpoint():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
-    table = dict(g1=g1_fps, g2=g2_ball, g3=g3_sqdist, g4=g4_interp, g5=g5_modules, g6=g6_nets, g7=g7_checkpoint)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6n", "g7", "g10"]
+    table = dict(g1=g1_fps, g2=g2_ball, g3=g3_sqdist, g4=g4_interp, g5=g5_modules, g6=g6_nets, g7=g7_checkpoint, g10=g10_zoo, g6n=g6_noise)
     for w in which:
         table[w]()
     print("all oracle checks passed")
