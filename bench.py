@@ -77,6 +77,18 @@ def algorithmic_work(name, a):
     return 0.0, 0.0
 
 
+def csrc_digest():
+    """sha256 over the kernel sources: stamps profiles/*_pmc_traffic_*.json so a stale file is never quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pointnet12_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "pointnet12_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build_net(workload, dev, npoint_scale=1):
     import torch
     from pointnet12_amd import pointnet2 as M
@@ -111,14 +123,46 @@ def make_step(workload, net, pts, labels, bucket):
     return step
 
 
-def cpu_baseline(workload, batch):
-    """The oracle (port of the reference's CPU path) on a bounded sample of the same workload."""
+def _cpu_info():
+    """(model string, physical cores, logical cpus) of this host."""
+    model, phys, cores_by_pkg = "unknown", set(), {}
+    try:
+        pkg = core = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                pkg = v
+            elif k == "core id":
+                core = v
+            elif not k and pkg is not None:
+                phys.add((pkg, core))
+                pkg = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    n_phys = len(phys) if phys else logical
+    return model, max(1, min(n_phys, logical)), logical
+
+
+def cpu_baseline(workload, batch, budget_s=150.0):
+    """The reference's CPU path, as restated by the oracle with the reference's own operator sequence for the
+    geometry (oracle/aten_geometry.py), on the FULL benchmark batch, timed twice: with 8
+    threads (comparable with the survey container's reference timings) and with all physical cores of this host.
+    1 warm-up + median of 3 steps each (fewer when a step is so slow that the leg would pass `budget_s`)."""
+    import numpy as np
     import torch
     from oracle import torch_ref as T
     from pointnet12_amd import synthetic as syn
-    sample_b = min(batch, 4)
-    pts_np, lab_np = syn.kitti_batch(0, sample_b, 4096)
+    pts_np, lab_np = syn.kitti_batch(0, batch, 4096)
     pts, lab = torch.from_numpy(pts_np), torch.from_numpy(lab_np)
+    T.set_geometry("aten")
     torch.manual_seed(0)
     if workload == "msg":
         net = T.RefMSGSemSeg(13, 6)
@@ -135,17 +179,87 @@ def cpu_baseline(workload, batch):
             f.sum().backward()
         else:
             T.seg_loss(net(pts), lab).backward()
-    torch.manual_seed(1234)
-    step()
-    times = []
-    for _ in range(2):
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    t = sorted(times)[0]
-    return {"value": sample_b * 4096 / t, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle net (oracle/torch_ref.py), B=%d of the %d clouds x 4096 pts, 1 warm-up + best of 2 steps, "
-                      "%.2f s/step; C geometry + torch CPU conv/BN, all host threads" % (sample_b, batch, t)}
+
+    model, n_phys, logical = _cpu_info()
+    saved = torch.get_num_threads()
+    legs = {}
+    try:
+        for threads in sorted({min(8, logical), n_phys}):
+            torch.set_num_threads(threads)
+            torch.manual_seed(1234)
+            t0 = time.perf_counter()
+            step()                                   # warm-up
+            warm = time.perf_counter() - t0
+            left = budget_s / 2 - warm               # each of the two legs gets half of the budget
+            n_timed = int(max(1, min(3, left // max(warm, 1e-3))))
+            times = []
+            for _ in range(n_timed):
+                t0 = time.perf_counter()
+                step()
+                times.append(time.perf_counter() - t0)
+            legs[threads] = (float(np.median(times)), n_timed)
+    finally:
+        torch.set_num_threads(saved)
+        T.set_geometry("c")
+    best = min(legs, key=lambda k: legs[k][0])
+    rate = lambda th: round(batch * 4096 / legs[th][0], 1)
+    t8 = min(8, logical)
+    return {"value": rate(best), "unit": "points/s", "cores": best, "kind": "port",
+            "value_8t": rate(t8), "value_all_cores": rate(n_phys), "physical_cores": n_phys, "logical_cpus": logical,
+            "cpu_model": model, "s_per_step": {str(k): round(v[0], 3) for k, v in legs.items()},
+            "timed_steps": {str(k): v[1] for k, v in legs.items()},
+            "sample": "the whole benchmark batch (B=%d x 4096 pts), oracle net of oracle/torch_ref.py with the reference's "
+                      "ATen operator sequence for FPS / ball query / 3-NN (oracle/aten_geometry.py) and torch-CPU "
+                      "conv/BatchNorm, train mode; 1 warm-up + median of the timed steps, at %s threads" % (
+                          batch, " and ".join(str(k) for k in sorted(legs)))}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run as a CHILD process
+    (this parent never touches the GPU: no re-exec of a process that has initialised HIP), relay rank 0's JSON line
+    and the return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            lines.append(ln.strip())
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if lines:
+        print(lines[-1])
+    sys.exit(rc if rc else (0 if lines else 1))
+
+
+def dry_run(args, dist, torch):
+    """The rank protocol of a real run -- rendezvous, barrier, K timed (empty) steps, MAX over ranks, one JSON line from
+    rank 0 -- on CPU with the gloo backend."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))               # uneven ranks: the reported time must be the slowest one's
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "points/sec fwd+bwd, PointNet2 SemSeg B=16x4096 pts", "value": 0.0, "unit": "points/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "dry_run": True}))
 
 
 def main():
@@ -163,11 +277,19 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute each batch's FPS/ball-query/3-NN inside its own step instead of one step ahead")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU only: exercise the launch / rendezvous / max-over-ranks timing / JSON relay with gloo ranks "
+                         "and no GPU work (tests/test_bench_launch_cpu.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args.gpus)                       # never returns
 
     import numpy as np
     import torch
     import torch.distributed as dist
+    if args.dry_run:
+        return dry_run(args, dist, torch)
     from pointnet12_amd import _lib, parallel
     from pointnet12_amd import synthetic as syn
 
@@ -300,15 +422,22 @@ def main():
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
         # HBM traffic of that kernel family from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes), per launch.
+        # The file carries the digest of the kernel sources it was collected with: a stale file is not quoted.
         fam = {"pn2_conv1x1_wgrad": "gemm_tn_kernel", "pn2_conv1x1_fwd": "gemm_nt_kernel<fwd>",
-               "pn2_conv1x1_dgrad": "gemm_nt_kernel<dgrad>"}.get(top)
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)
-        if fam and os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))["families"].get(fam)
-            if pmc:
+               "pn2_conv1x1_dgrad": "gemm_nt_kernel<dgrad>", "pn2_conv1x1_bwd": "gemm_bwd_fused_kernel"}.get(top)
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)))
+        if fam and cands:
+            pmc_path = cands[-1]
+            doc = json.load(open(pmc_path))
+            pmc = doc.get("families", {}).get(fam)
+            if pmc and doc.get("csrc_sha256") == csrc_digest():
                 roofline["traffic"] = round(pmc["hbm_bytes_per_step"] / pmc["launches_per_step"])
                 roofline["traffic_note"] = "bytes per launch, PMC (profiles/%s); algorithmic bytes per launch %d" % (
                     os.path.basename(pmc_path), round(v[3] / v[1]))
+            elif pmc:
+                roofline["traffic_note"] = "profiles/%s was collected with other kernel sources (digest differs): not quoted" % (
+                    os.path.basename(pmc_path))
         roofline["avg_launch_us"] = round(v[0] / v[1] * 1e3, 2)
         roofline["launches"] = v[1] // prof_steps
         roofline["device_ms_all_kernels_per_step"] = round(sum(x[0] for x in agg.values()) / prof_steps, 3)
@@ -335,11 +464,18 @@ def main():
         model = STEP_MODEL.get(args.workload)
         if model and n_points == 4096 and getattr(args, "npoint_scale", 1) in (1, None):
             per_gpu = value / world
+            executed = sum(k["gflop_per_step"] for k in kernels.values()) * 1e9 if kernels else None
             line["step_roofline"] = {
-                "alg_bytes_per_point": model[0], "flop_per_point": model[1],
+                "alg_bytes_per_point": model[0], "flop_per_point_reference_formulation": model[1],
                 "hbm_GBs": round(per_gpu * model[0] / 1e9, 1), "hbm_frac": round(per_gpu * model[0] / (HBM_PEAK_GBS * 1e9), 4),
-                "mfma_TFs": round(per_gpu * model[1] / 1e12, 2), "mfma_frac": round(per_gpu * model[1] / (F32_MFMA_PEAK_TF * 1e12), 4),
-                "model": "SURVEY.md 8(d): ALG_BYTES = I/O + 5 x pre-BN activations, FLOP = 6 x forward MACs"}
+                # what the matrix cores really did: flops summed over the launches of the instrumented pass (the
+                # factorised first layers skip 94 of the reference formulation's 464.5 GFLOP on MSG)
+                "executed_gflop_per_step": round(executed / 1e9, 2) if executed else None,
+                "mfma_TFs": round(executed / (ms_per_step * 1e-3) / 1e12, 2) if executed else None,
+                "mfma_frac": round(executed / (ms_per_step * 1e-3) / (F32_MFMA_PEAK_TF * 1e12), 4) if executed else None,
+                "mfma_frac_reference_formulation": round(per_gpu * model[1] / (F32_MFMA_PEAK_TF * 1e12), 4),
+                "model": "SURVEY.md 8(d): ALG_BYTES = I/O + 5 x pre-BN activations; mfma_frac prices EXECUTED flops, "
+                         "mfma_frac_reference_formulation the reference's 6 x forward MACs"}
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(line))

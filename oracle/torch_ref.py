@@ -16,6 +16,39 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import geometry as G
+from .aten_geometry import AtenGeometry as A
+
+# "c": index tensors from the scalar C restatement (the parity checker's default).  "aten": the reference's own
+# operator sequence (oracle/aten_geometry.py) -- same indices bit for bit, the reference's cost structure; used by
+# bench.py's cpu_baseline leg so that the timed CPU step is the reference's step, not a faster algorithm.
+_GEOMETRY = "c"
+
+
+def set_geometry(mode):
+    global _GEOMETRY
+    if mode not in ("c", "aten"):
+        raise ValueError(mode)
+    _GEOMETRY = mode
+
+
+def _fps(xyz_r, S, start):
+    if _GEOMETRY == "aten":
+        return A.fps(xyz_r.detach(), S, start)
+    return torch.from_numpy(G.farthest_point_sample(xyz_r.detach().numpy(), S, start.numpy()))
+
+
+def _ball(radius, K, xyz_r, new_xyz):
+    if _GEOMETRY == "aten":
+        return A.ball(radius, K, xyz_r.detach(), new_xyz.detach())
+    return torch.from_numpy(G.query_ball_point(radius, K, xyz_r.detach().numpy(), new_xyz.detach().numpy()))
+
+
+def _rows(table, idx):
+    """table [B,N,C], idx [B,...] -> [B,...,C]; differentiable w.r.t. table."""
+    if _GEOMETRY == "aten":
+        return A.gather(table, idx)
+    B, N, C = table.shape
+    return _take_rows(table.reshape(B * N, C), _flat(idx, N)).view(tuple(idx.shape) + (C,))
 
 
 def _shared_mlp(x, convs, bns, training):
@@ -79,19 +112,16 @@ class RefSetAbstraction(nn.Module):
             S, K = self.npoint, self.nsample
             if start is None:
                 start = draw_start(B, N)
-            fidx = torch.from_numpy(G.farthest_point_sample(xyz_r.detach().numpy(), S, start.numpy()))
-            new_xyz = _take_rows(xyz_r.reshape(B * N, 3), _flat(fidx, N)).view(B, S, 3)
-            gidx = torch.from_numpy(G.query_ball_point(self.radius, K, xyz_r.detach().numpy(),
-                                                       new_xyz.detach().numpy()))
+            fidx = _fps(xyz_r, S, start)
+            new_xyz = _rows(xyz_r, fidx)
+            gidx = _ball(self.radius, K, xyz_r, new_xyz)
             if int(gidx.max()) >= N:
                 raise IndexError("empty ball: index N reaches index_points (pointnet_util.py:127)")
-            flat = _flat(gidx, N)
-            gx = _take_rows(xyz_r.reshape(B * N, 3), flat).view(B, S, K, 3) - new_xyz.view(B, S, 1, 3)
+            gx = _rows(xyz_r, gidx) - new_xyz.view(B, S, 1, 3)
             if pts_r is None:
                 rows = gx
             else:
-                gp = _take_rows(pts_r.reshape(B * N, -1), flat).view(B, S, K, -1)
-                rows = torch.cat([gx, gp], -1)                         # xyz first (:131)
+                rows = torch.cat([gx, _rows(pts_r, gidx)], -1)         # xyz first (:131)
         y = _shared_mlp(rows.view(B, S, K, -1).permute(0, 3, 2, 1), self.mlp_convs, self.mlp_bns,
                         self.training)                                  # [B,C,K,S]  (:194-197)
         return new_xyz.permute(0, 2, 1), y.max(dim=2)[0]               # :199
@@ -122,21 +152,18 @@ class RefSetAbstractionMsg(nn.Module):
         S = self.npoint
         if start is None:
             start = draw_start(B, N)
-        fidx = torch.from_numpy(G.farthest_point_sample(xyz_r.detach().numpy(), S, start.numpy()))
-        new_xyz = _take_rows(xyz_r.reshape(B * N, 3), _flat(fidx, N)).view(B, S, 3)     # :238
+        fidx = _fps(xyz_r, S, start)
+        new_xyz = _rows(xyz_r, fidx)                                                    # :238
         outs = []
         for radius, K, convs, bns in zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks):
-            gidx = torch.from_numpy(G.query_ball_point(radius, K, xyz_r.detach().numpy(),
-                                                       new_xyz.detach().numpy()))
+            gidx = _ball(radius, K, xyz_r, new_xyz)
             if int(gidx.max()) >= N:
                 raise IndexError("empty ball: index N reaches index_points (pointnet_util.py:243)")
-            flat = _flat(gidx, N)
-            gx = _take_rows(xyz_r.reshape(B * N, 3), flat).view(B, S, K, 3) - new_xyz.view(B, S, 1, 3)
+            gx = _rows(xyz_r, gidx) - new_xyz.view(B, S, 1, 3)
             if pts_r is None:
                 rows = gx
             else:
-                gp = _take_rows(pts_r.reshape(B * N, -1), flat).view(B, S, K, -1)
-                rows = torch.cat([gp, gx], -1)                         # features first (:247)
+                rows = torch.cat([_rows(pts_r, gidx), gx], -1)         # features first (:247)
             y = _shared_mlp(rows.permute(0, 3, 2, 1), convs, bns, self.training)      # :251-255
             outs.append(y.max(dim=2)[0])                               # :256
         return new_xyz.permute(0, 2, 1), torch.cat(outs, 1)            # :260
@@ -163,6 +190,8 @@ class RefFeaturePropagation(nn.Module):
         S = x2.shape[1]
         if S == 1:                                                     # :292-293
             interp = p2.expand(B, N, p2.shape[-1])
+        elif _GEOMETRY == "aten":
+            interp, _ = A.three_nn_interp(x1.detach(), x2.detach(), p2)                 # :295-301
         else:
             idx, dist = G.three_nn(x1.detach().numpy(), x2.detach().numpy())           # :295-297
             w = torch.from_numpy(G.three_weights(dist))                                 # :298-300

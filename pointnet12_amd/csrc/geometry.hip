@@ -74,7 +74,8 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
     if (XYZ_LDS || NW > 1) __syncthreads();
     int rot = 0;
 
-    int far = (int)start[b];
+    // an out-of-range start (only the Python `start=` override can produce one) must not index past the cloud
+    int far = (int)(start[b] < 0 ? 0 : (start[b] >= N ? N - 1 : start[b]));
     int64_t *o = out + (size_t)b * npoint;
     for (int it = 0; it < npoint; ++it) {
         if (t == 0) o[it] = far;
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(1024) void fps_large_kernel(const float *__restrict
     const float *p = xyz + (size_t)b * N * 3;
     float *md = work + (size_t)b * N;
     for (int j = t; j < N; j += 1024) md[j] = 1e10f;
-    int far = (int)start[b];
+    // an out-of-range start (only the Python `start=` override can produce one) must not index past the cloud
+    int far = (int)(start[b] < 0 ? 0 : (start[b] >= N ? N - 1 : start[b]));
     int64_t *o = out + (size_t)b * npoint;
     for (int it = 0; it < npoint; ++it) {
         if (t == 0) o[it] = far;
@@ -210,7 +212,8 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
     if (t < 3) red[t] = 0ull;
     __syncthreads();
     int rot = 0;
-    int far = (int)start[b];
+    // an out-of-range start (only the Python `start=` override can produce one) must not index past the cloud
+    int far = (int)(start[b] < 0 ? 0 : (start[b] >= N ? N - 1 : start[b]));
     float cx = p[3 * far], cy = p[3 * far + 1], cz = p[3 * far + 2];
     int64_t *o = out + (size_t)b * npoint;
     FpsSlot *tab = table + (size_t)b * npoint * W;
@@ -256,9 +259,16 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
             const bool act = lane < 4 * W;
             const unsigned long long *src = &row[lane >> 2].w[lane & 3];
             unsigned long long v = 1ull;
-            do {
+            // Bounded: if the W workgroups of a cloud are not all resident (a partitioned device, a CU mask the host
+            // could not see) the missing ones never publish.  After ~1 s of polling the kernel aborts: the launch
+            // fails loudly (hipErrorLaunchFailure at the next synchronisation) instead of hanging the GPU.
+            unsigned spins = 0;
+            for (;;) {
                 if (act) v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while (__ballot(v == 0ull) != 0ull);
+                if (__ballot(v == 0ull) == 0ull) break;
+                if (++spins > (1u << 22)) __builtin_trap();
+                if (spins > 64) __builtin_amdgcn_s_sleep(2);           // a late partner: stop hammering the fabric
+            }
             const unsigned long long best = pn2_wave_max_u64_dpp((act && (lane & 3) == 0) ? v : 0ull);
             const unsigned long long hit = __ballot(act && (lane & 3) == 0 && v == best);
             const int src_lane = __builtin_ctzll(hit);        // lowest lane = lowest w; keys are unique anyway
@@ -403,6 +413,22 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float *__res
 
 }  // namespace
 
+// Workgroups of fps_coop_kernel<PPT> that are certainly co-resident: what the occupancy query admits per CU (1024-thread
+// workgroups: at most 2), times the CUs of THIS device (a CPX partition has 32, not 256), halved as a margin -- the
+// query over-reports by one block per CU for some register footprints (MI355X_MICROARCH.md, Residency) and a queue may
+// run under a CU mask the runtime does not report.  On a full MI355X: 256 * 1 / 2 = 128, the figure measured in round 1.
+template <int PPT>
+static int fps_coop_capacity() {
+    static const int cap = [] {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&fps_coop_kernel<PPT>), 1024, 0) != hipSuccess)
+            per_cu = 0;
+        if (per_cu > 1) per_cu = 1;                       // one 1024-thread workgroup per CU is all the plan ever counts on
+        return pn2_num_cus() * per_cu / 2;
+    }();
+    return cap;
+}
+
 extern "C" {
 
 // Cooperative plan for N > 16384: PPT points per thread and W workgroups per cloud, or W = 0 (single-workgroup
@@ -427,7 +453,8 @@ static void fps_coop_plan(int B, int N, int *ppt, int *W) {
     if (!enabled) return;
     for (int p = 8; p <= 16; p *= 2) {
         const int w = (int)pn2_cdiv(N, 1024 * p);
-        if (w <= 16 && (int64_t)w * B <= 128) { *ppt = p; *W = w; return; }
+        const int cap = p == 8 ? fps_coop_capacity<8>() : fps_coop_capacity<16>();
+        if (w <= 16 && (int64_t)w * B <= cap) { *ppt = p; *W = w; return; }
     }
 }
 

@@ -693,17 +693,6 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     }
 }
 
-inline int pn2_num_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi>
 int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, int n_lo = 0, int n_hi = 0) {
     int64_t tiles_m = pn2_cdiv(P, BM);

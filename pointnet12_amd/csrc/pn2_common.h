@@ -17,6 +17,18 @@ static inline hipStream_t pn2_s(pn2_stream_t s) { return reinterpret_cast<hipStr
 
 static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Compute units of the current device (a CPX partition or a CU-masked queue reports its own count).
+static inline int pn2_num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 // 64-bit max across a wave with xor-shuffles; every lane ends with the result.
 __device__ __forceinline__ unsigned long long pn2_wave_max_u64(unsigned long long v) {
 #pragma unroll

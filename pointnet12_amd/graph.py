@@ -58,6 +58,11 @@ class GraphedStep:
     pre-existing ``.grad`` tensors (parallel.FlatGradBucket does that).  The returned loss tensor is static
     (overwritten by every replay).
 
+    The ``warmup`` eager calls of ``fn`` before the capture are REAL steps: BatchNorm running statistics and
+    ``num_batches_tracked`` advance, and if ``fn`` contains an optimizer step the parameters move.  Capture a step
+    that should start from a pristine state with ``warmup=0`` after warming the allocator up some other way, or
+    snapshot / restore ``state_dict()`` around the constructor.
+
     ``geometry_fn`` (optional): a callable running only the network's geometry on the NEXT batch's static input
     (e.g. ``lambda: net.features(points)``; under a recording GeometryTape the modules skip all feature work).
     The captured graph then has two branches: the main stream runs ``fn`` on the geometry recorded one step

@@ -98,6 +98,11 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib, st = _lib.load(), _lib.stream()
+        if torch.cuda.is_current_stream_capturing() and any(rec["step_dev"] is None for rec in self._flat):
+            # a captured launch would bake the host step count and learning rate in as kernel-argument constants:
+            # every replay would then repeat the SAME bias correction and lr, silently
+            raise _lib.Pn2Error("optim.Adam.step() under stream capture needs device_step=True (step count and lr "
+                                "in device memory); with host-side values every graph replay would reuse this step's")
         for group, rec in zip(self.param_groups, self._flat):
             for p in rec["params"]:
                 if p.grad is None or p.grad.data_ptr() < rec["g"].data_ptr() or \

@@ -261,6 +261,11 @@ def farthest_point_sample(xyz, npoint, start=None):
         raise RuntimeError("farthest_point_sample needs 3 coordinates (pointnet_util.py:79)")
     if start is None:
         start = draw_fps_start(B, N, xyz.device)
+    else:
+        start = torch.as_tensor(start)
+        if not start.is_cuda and (start.numel() != B or int(start.min()) < 0 or int(start.max()) >= N):
+            raise IndexError("farthest_point_sample: start must hold B indices in [0, N)")   # free on host tensors;
+            # device tensors are not read back (that would synchronise): the kernels clamp them into the cloud
     start = start.to(device=xyz.device, dtype=torch.int64).contiguous()
     out = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
     lib = _lib.load()

@@ -1,0 +1,43 @@
+"""CPU: `python bench.py --gpus N` launches its own ranks (it used to exit unless torchrun wrapped it).
+
+--dry-run runs the rank protocol of the real benchmark (rendezvous on 127.0.0.1, barrier, K timed steps, MAX over ranks,
+ONE JSON line from rank 0 relayed by the parent) with gloo ranks and no GPU work."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "4", "--warmup", "1", *extra],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    return p
+
+
+def test_bench_self_launches_two_ranks_and_prints_one_json_line():
+    p = _run("--gpus", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 4 and doc["dry_run"] is True
+    assert doc["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step: the line carries the MAX over ranks
+
+
+def test_bench_single_rank_needs_no_launcher():
+    p = _run()
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads(p.stdout.strip())["n_gpus"] == 1
+
+
+def test_bench_propagates_a_failing_rank():
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "2", "--no-such-flag"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert q.returncode != 0 and not q.stdout.strip()

@@ -163,3 +163,36 @@ def test_adam_restatement_golden():
         opt.step()
         TR.adam_step(p, q.grad.numpy(), m, v, t, lr=3e-3)
         assert np.abs(p - q.detach().numpy()).max() <= 2e-7 * np.abs(p).max()
+
+
+def test_aten_geometry_equals_c_restatement():
+    """oracle/aten_geometry.py (the reference's operator sequence, timed as the CPU baseline) returns the C
+    restatement's indices bit for bit, and the oracle modules give the same outputs in either mode."""
+    from oracle.aten_geometry import AtenGeometry as A
+    from pointnet12_amd import synthetic as syn
+    pts, _ = syn.kitti_batch(33, 2, 1024)
+    xyz = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
+    t = torch.from_numpy(xyz)
+    start = np.array([3, 700])
+    f = A.fps(t, 128, torch.from_numpy(start))
+    assert (f.numpy() == G.farthest_point_sample(xyz, 128, start)).all()
+    new = A.gather(t, f)
+    assert (new.numpy() == G.index_points(xyz, f.numpy())).all()
+    for r, k in ((0.1, 16), (0.4, 64)):
+        assert (A.ball(r, k, t, new).numpy() == G.query_ball_point(r, k, xyz, new.numpy())).all()
+    assert (bits(A.pair_sqdist(new, t).numpy()) == bits(G.square_distance(new.numpy(), xyz))).all()
+    p2 = torch.randn(2, 128, 5, generator=torch.Generator().manual_seed(0))
+    interp, _ = A.three_nn_interp(t, new, p2)
+    oi, od = G.three_nn(xyz, new.numpy())
+    assert np.abs(interp.numpy() - G.three_interpolate(p2.numpy(), oi, G.three_weights(od))).max() <= 2e-6
+    outs = []
+    for mode in ("c", "aten"):
+        T.set_geometry(mode)
+        try:
+            torch.manual_seed(0)
+            net = T.RefSSGSemSeg(13, 6, dropout=0.0).train()
+            torch.manual_seed(1)
+            outs.append(net(torch.from_numpy(pts)).detach())
+        finally:
+            T.set_geometry("c")
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5

@@ -72,3 +72,64 @@ def test_bucket_aliases_grads():
     bucket.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in model.parameters())
     assert bucket.all_reduce() is None          # no process group: no-op
+
+
+# ------------------------------------------------------------------ the path's own network over gloo ranks
+def _oracle_net():
+    from oracle import torch_ref as T
+    torch.manual_seed(3)
+    return T.RefSSGSemSeg(13, 6, dropout=0.0).train()
+
+
+def _oracle_batch():
+    from pointnet12_amd import synthetic as syn
+    pts, labels = syn.kitti_batch(50, 4, 1024)
+    return torch.from_numpy(pts), torch.from_numpy(labels)
+
+
+def _oracle_worker(rank, world, port, out):
+    from oracle import torch_ref as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _oracle_net()
+    if rank != 0:
+        for p in net.parameters():
+            p.data.mul_(0.5)               # broadcast_module must restore rank 0's parameters
+    parallel.broadcast_module(net)
+    bucket = parallel.FlatGradBucket(net)
+    pts, labels = _oracle_batch()
+    lo, hi = parallel.shard_range(pts.shape[0], rank, world)
+    bucket.zero()
+    torch.manual_seed(100 + rank)          # per-rank FPS start draws, reproduced by the single-process run below
+    T.seg_loss(net(pts[lo:hi]), labels[lo:hi]).backward()
+    bucket.all_reduce()
+    out[rank] = (bucket.flat.clone(), net.sa1.mlp_bns[0].running_mean.clone())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_run_of_the_oracle_network_equals_two_bn_groups():
+    """Two gloo ranks, each running the CPU restatement of SSG-SemSeg on its own two clouds (per-replica BatchNorm, as
+    the reference's nn.DataParallel, semseg.py:91) and averaging the flat bucket, against ONE process evaluating the
+    two shards as two BatchNorm groups and averaging the gradients: <= 1e-6 relative."""
+    from oracle import torch_ref as T
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_oracle_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    assert torch.equal(res[0][0], res[1][0])                     # every rank holds the same averaged gradient
+    torch.set_num_threads(2)
+    pts, labels = _oracle_batch()
+    ref = None
+    for r in range(world):
+        net = _oracle_net()
+        torch.manual_seed(100 + r)
+        T.seg_loss(net(pts[2 * r:2 * r + 2]), labels[2 * r:2 * r + 2]).backward()
+        g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        ref = g if ref is None else ref + g
+        if r == 0:
+            assert torch.allclose(res[0][1], net.sa1.mlp_bns[0].running_mean, rtol=1e-6, atol=1e-7)   # per-replica BN
+    ref /= world
+    assert float((res[0][0] - ref).norm()) <= 1e-6 * float(ref.norm())

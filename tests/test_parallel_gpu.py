@@ -1,0 +1,71 @@
+"""GPU: the RCCL leg of the data-parallel path on the one GPU a test box has.
+
+PN2_FORCE_COLLECTIVES=1 makes a single rank go through everything N ranks go through: init_process_group("nccl")
+(= RCCL), broadcast_module, a forward + backward that accumulates straight into FlatGradBucket(direct=True), and the
+flat all-reduce (AVG over one rank = identity, so the gradients must come back unchanged and finite).  Runs in a child
+process: a process group belongs to its process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from pointnet12_amd import parallel, pointnet2 as M, synthetic as syn
+from pointnet12_amd.loss import nll_loss
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+torch.manual_seed(0)
+net = M.PointNet2SemSeg(13, 6).to(dev).train()
+before = [p.detach().clone() for p in net.parameters()]
+parallel.broadcast_module(net)                       # forced: really broadcasts (from rank 0 to rank 0)
+assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+bucket = parallel.FlatGradBucket(net, direct=True)
+pts, lab = syn.kitti_batch(0, 2, 1024)
+pts, lab = torch.from_numpy(pts).to(dev), torch.from_numpy(lab).to(dev)
+bucket.zero()
+torch.manual_seed(1)
+lp = net(pts)
+nll_loss(lp.reshape(-1, 13), lab.reshape(-1)).backward()
+g0 = bucket.flat.clone()
+out = bucket.all_reduce()
+torch.cuda.synchronize()
+assert out is bucket.flat, "the collective was skipped"
+assert bool(torch.isfinite(bucket.flat).all()) and float(g0.abs().max()) > 0
+assert float((bucket.flat - g0).abs().max()) <= 1e-7 * float(g0.abs().max())
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+"""
+
+
+def test_one_rank_rccl_bucket_all_reduce(dev):
+    env = dict(os.environ, PN2_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0 and "RCCL-ONE-RANK-OK" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
+def test_bench_self_launch_one_rank_through_torchrun(dev):
+    """bench.py started by torch.distributed.run with one rank: the same code path the driver's N-rank launch takes
+    (RCCL init, broadcast, barrier-bracketed timing, all-reduce after every step)."""
+    env = dict(os.environ, PN2_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "3", "--warmup", "2", "--workload", "ssg", "--no-cpu-baseline", "--no-roofline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    doc = json.loads(line[0])
+    assert doc["n_gpus"] == 1 and doc["value"] > 1e6 and doc["config"]["parallelism"] == "dp1"
