@@ -56,6 +56,10 @@ def algorithmic_work(name, a):
         P, M, N = a[15], a[16], a[17]
         dense = a[0] is not None
         return 2.0 * P * M * N, 4.0 * (P * M * (2 if dense else 1) + P * N + M * N)
+    if name == "pn2_conv1x1_bwd":            # fused dgrad + wgrad: dZ|pooled, Y [P,Co], prev_Y [P,Ci] read once, dX [P,Ci] written
+        P, Co, Ci = a[19], a[20], a[21]
+        dense = a[0] is not None
+        return 4.0 * P * Co * Ci, 4.0 * (P * Co * (2 if dense else 1) + 2 * P * Ci + 2 * Co * Ci)
     if name == "pn2_bn_relu_max":            # Y ldy aff G K C out ldo arg
         G, K, C = a[3], a[4], a[5]
         return 3.0 * G * K * C, 4.0 * (G * K * C + 2 * G * C)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 3
+#define PN2_ABI_VERSION 4
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -232,6 +232,19 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
                       int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       pn2_stream_t stream);
+
+/* Fused backward of one layer for the narrow, long layers (csrc/mlp_res.hip): dgrad AND wgrad in ONE pass over dZ / Y /
+ * prev_Y -- autograd of model/pointnet_util.py:197,254,312 for conv + BatchNorm + ReLU.  dY is formed once per row
+ * (as in pn2_conv1x1_dgrad), dXout = (dY W) masked by the previous layer's ReLU with its two BatchNorm-backward
+ * reductions added to prev_red, dW (pitch lddw, caller zeroes) += dY^T relu(bn(prev_Y)).  prev_affine == NULL: the
+ * layer input is prev_Y as stored, dXout = dY W unmasked, prev_red must be NULL.  The weight matrix stays in LDS for
+ * the whole launch.  Only for shapes pn2_res_supported() accepts (C_out, C_in multiples of 32, <= 128); training-mode
+ * BatchNorm only (no dbias).  pn2_conv1x1_fwd picks the matching weight-resident forward kernel by itself. */
+int pn2_res_supported(int64_t P, int C_out, int C_in);
+int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool,
+                    const float *Y, int ldy, const float *coef, const float *W, int ldw, const float *prev_Y,
+                    int ld_prev, const float *prev_affine, float *dXout, int ldxo, double *prev_red, float *dW,
+                    int lddw, int64_t P, int C_out, int C_in, pn2_stream_t stream);
 
 /* ---- scatter-adds of the backward pass as segmented reductions (csrc/scatter.hip) ----------------------------
  * pn2_invert_index: idx [B, M] int64 with values in [0, T) -> members int32 [B, M], owners int32 [B, M]: the

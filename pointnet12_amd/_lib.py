@@ -41,6 +41,9 @@ SIGNATURES = {
                                _i64, _i, _i, _vp, _vp]),
     "pn2_conv1x1_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
                                _i64, _i, _i, _vp]),
+    "pn2_res_supported": (_i, [_i64, _i, _i]),
+    "pn2_conv1x1_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
+                             _i64, _i, _i, _vp]),
     "pn2_invert_index": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_three_interp_bwd_seg": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_group_affine_bwd_seg": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i,
@@ -53,7 +56,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DWX_REPLICAS = 32        # PN2_DWX_REPLICAS of include/pn2.h
 
 
@@ -93,7 +96,7 @@ class _Timed:
     def __getattr__(self, name):
         fn = getattr(_raw, name)
         if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes",
-                                                   "pn2_nll_loss_workspace_bytes"):
+                                                   "pn2_nll_loss_workspace_bytes", "pn2_res_supported"):
             return fn
 
         def timed(*args):

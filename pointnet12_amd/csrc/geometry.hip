@@ -422,7 +422,7 @@ static int fps_coop_capacity() {
     static const int cap = [] {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&fps_coop_kernel<PPT>), 1024, 0) != hipSuccess)
-            per_cu = 0;
+            per_cu = 1;                                   // no device to ask (host-only callers): the planning default
         if (per_cu > 1) per_cu = 1;                       // one 1024-thread workgroup per CU is all the plan ever counts on
         return pn2_num_cus() * per_cu / 2;
     }();

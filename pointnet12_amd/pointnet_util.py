@@ -608,6 +608,21 @@ class _SharedMLP(torch.autograd.Function):
             if not training and direct:
                 raise NotImplementedError("direct gradient accumulation with eval-mode BatchNorm: use autograd mode")
             need_dx = l > 0 or ctx.needs_input_grad[0]
+            if need_dx and training and not FUSED_BN_TAILS and lib.pn2_res_supported(P, co, ci):
+                # narrow, long layer: dgrad + wgrad in ONE pass over dZ / Y / Y_prev, weights resident in LDS (mlp_res.hip)
+                dx = _empty_rows(P, ci, dev) if l > 0 else torch.empty(P, ldx, device=dev, dtype=torch.float32)
+                if l == 0:
+                    d_rows = dx
+                c_dz = (None, 0) if pooled else (_p(dZ), dZ.shape[1])
+                c_pool = (_p(dzp), ldo, _p(arg), K) if pooled else (None, 0, None, 0)
+                _check(lib.pn2_conv1x1_bwd(*c_dz, *c_pool, _p(y), ldy, _p(coef), _p(_contig_weight(Ws[l])), ci, _p(x), ldx,
+                                           _p(x_aff), _p(dx), dx.shape[1], _p(red[offs[l - 1]:offs[l]]) if l > 0 else None,
+                                           _p(dW), ci, P, co, ci, st), "pn2_conv1x1_bwd")
+                if not direct:
+                    grads[7 * l] = dW.view_as(Ws[l])
+                if l > 0:
+                    dZ = dx
+                continue
             dx = None
             if need_dx:
                 w_l = _p(_contig_weight(Ws[l]))             # [co, ci] as stored: the dgrad kernel reads it down the columns

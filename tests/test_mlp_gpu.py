@@ -36,6 +36,10 @@ def torch_mlp(rows, convs, bns, pool, training, dtype):
     # the 32-channel stack of sa1 (SSG and MSG scale 1): 32x32 / 64x32 wgrad tiles whose waves split a stage, pooled K = 32;
     # and a few-row stage on the 64x64 wgrad tiles (P <= 65 536)
     (131072, 32, [9, 32, 32, 64]), (65536, 0, [131, 128, 128]),
+    # the weight-resident family (csrc/mlp_res.hip): plain first-layer input (unmasked dX, X as stored), pooled K = 64 with a
+    # 64-row tile inside one group, 96-wide blocks (three co / ci blocks: dW tiles split by row halves), a ragged tail
+    # (P % 64 = 8), and K = 16 < tile rows (four groups per tile)
+    (65536, 0, [128, 128, 64]), (131072, 64, [32, 64, 128]), (40008, 0, [96, 96, 32]), (65536, 16, [64, 96, 128]),
 ])
 def test_shared_mlp_vs_torch(dev, P, pool, chans):
     gen = torch.Generator().manual_seed(P + len(chans))

@@ -107,6 +107,7 @@ def _compare(tag, hip, o32, o64=None):
         r["grad_l2_hip_vs_fp64_median"] = float(np.median(list(eh.values())))
         r["grad_l2_orc32_vs_fp64_median"] = float(np.median(list(eo.values())))
         r["grad_worst_ratio"] = max(eh[n] / max(eo[n], r["grad_l2_orc32_vs_fp64_median"]) for n in names)
+        r["grad_worst_tensors"] = [(n, eh[n], eo[n], float(g_64[n].norm())) for n in sorted(names, key=lambda n: -eh[n])[:4]]
     _report(tag, r)
     return r
 

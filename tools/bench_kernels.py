@@ -82,10 +82,12 @@ def main():
             report("fwd", (P, K, N), timeit(fn, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
             del X, Y
 
-    for which in ("dgrad", "wgrad"):
+    for which in ("dgrad", "wgrad", "bwd"):
         if args.which not in (which, "all"):
             continue
         for P, Cl, Cp, Kp in BWD:
+            if which == "bwd" and not lib.pn2_res_supported(P, Cl, Cp):
+                continue
             Y, Yp = rnd(P, r4(Cl)), rnd(P, r4(Cp))
             coef, affp = affine(Cl), affine(Cp)
             Wt = rnd(Cl, Cp)                    # the Conv weight [C_l, C_{l-1}] as stored; dgrad reads it down the columns
@@ -108,6 +110,16 @@ def main():
                                                p(red), P, Cl, Cp, None, st)
                     assert rc == 0
                 report("dgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
+            elif which == "bwd":
+                dX = torch.empty(P, r4(Cp), device=dev)
+                red = torch.zeros(8 * 2 * Cp, device=dev, dtype=torch.float64)
+                dW = torch.zeros(Cl, Cp, device=dev)
+
+                def fn():
+                    rc = lib.pn2_conv1x1_bwd(*dz, p(Y), r4(Cl), p(coef), p(Wt), Cp, p(Yp), r4(Cp), p(affp), p(dX), r4(Cp), p(red),
+                                             p(dW), Cp, P, Cl, Cp, st)
+                    assert rc == 0
+                report("bwd", (P, Cl, Cp, Kp), timeit(fn, args.reps), 4.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
             else:
                 dW = torch.zeros(Cl, Cp, device=dev)
 
