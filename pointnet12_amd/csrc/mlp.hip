@@ -1092,8 +1092,14 @@ int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float
                     int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin, pn2_stream_t stream) {
     PN2_CHECK_ARG(X && W && bias && Y && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && fin_tail_ok(fin, stats));
     PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= round4(K) && ldw >= K && ldy % 4 == 0 && ldy >= round4(N));
-    if (fin == nullptr && pn2_res_supported(P, N, K) && ldy >= N)        // narrow, long layer: W stays in LDS (mlp_res.hip)
-        return pn2_fwd_res(X, ldx, in_affine, W, ldw, bias, Y, ldy, P, K, N, stats, pn2_s(stream));
+    if (fin == nullptr && pn2_res_supported(P, N, K) && ldy >= N) {      // narrow, long layer: W stays in LDS (mlp_res.hip)
+        const int64_t P_full = P & ~(int64_t)31;                        // whole 32-row slabs there, a ragged tail below
+        const int rc = pn2_fwd_res(X, ldx, in_affine, W, ldw, bias, Y, ldy, P_full, K, N, stats, pn2_s(stream));
+        if (rc != PN2_EUNSUPPORTED) {                                   // (unsupported: W plus eight staging buffers exceed LDS)
+            if (rc != PN2_OK || P_full == P) return rc;
+            X += P_full * ldx; Y += P_full * ldy; P -= P_full;
+        }
+    }
     const int K4 = round4(K);
     EpiFwd epi{Y, ldy, bias, stats, make_fin_tail(fin, P)};
     const BMat bm = make_bmat(W, ldw, K, K);

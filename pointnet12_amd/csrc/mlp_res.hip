@@ -68,37 +68,70 @@ extern __shared__ __attribute__((aligned(16))) float res_lds[];
 
 __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }   // 32x32 C/D layout
 
+// Predicated-off stores go here instead of into a branch: every store is then issued on every path, the code stays
+// straight-line and the compiler can COUNT the outstanding memory operations (s_waitcnt vmcnt(N)) -- gfx9 retires loads
+// and stores through one in-order counter, so a wait it cannot count becomes vmcnt(0) and stalls on the store
+// acknowledgements of the previous tile (1-2 us each).
+__device__ float pn2_dump_page[64];
+// one 256-byte line per wave for the stores of waves that have nothing to write (all waves of all workgroups on ONE line
+// cost 2x the whole kernel: same-line stores serialise chip-wide)
+__device__ float pn2_dump_lines[1024 * 8 * 64];
+
+__device__ __forceinline__ void store_or_dump(float v, float *dst, bool valid, int lane) {
+    __builtin_nontemporal_store(v, valid ? dst : &pn2_dump_page[lane]);
+}
+
 // ----------------------------------------------------------------------------------------------- fused backward
-// dyload: LoadDyDense / LoadDyPooled over this layer's (dZ | pooled dZ, Y, coef).  Yp: the previous layer's pre-BN
-// output [P, Ci] (MASKED: X = relu(bn(Yp)) with aff_p, dX masked by X > 0 and reduced into red_p) or the plain layer
-// input (!MASKED: X = Yp as stored, dX = dY W unmasked, no reductions).
-template <int CO_T, class DyLoad, bool MASKED>
-__global__ __launch_bounds__(512, 2) void bwd_res_kernel(DyLoad dyload, const float *__restrict__ Yp, int ldp,
+// This layer's dY = c0*dZ + q1*(y - mean) + q0 (BatchNorm backward folded into `coef`, see pn2_bn_bwd_coef) with dZ
+// dense [P, Co] or implied by the max-pool (POOLED: dZ[g*Kp + kk, c] = dZp[g, c] if kk == arg[g, c]; Kp a power of two
+// that divides 64 or is a multiple of it, so the groups of a 64-row tile are the same for every tile).
+// Yp: the previous layer's pre-BN output [P, Ci] (MASKED: X = relu(bn(Yp)) with aff_p, dX masked by X > 0 and reduced
+// into red_p) or the plain layer input (!MASKED: X = Yp as stored, dX = dY W unmasked, no reductions).
+// The kernel takes WHOLE 64-row tiles only (P % 64 == 0; the host hands a ragged tail to the streamed kernels): no row
+// predicates anywhere, every address is a per-tile uniform base plus a loop-invariant 32-bit lane offset.
+struct ResDy {
+    const float *dZ;                                   // dense [P, ld]
+    const float *dZp; const int32_t *arg; int ldo; int kshift;   // pooled: [G, ldo], log2(Kp)
+    const float *Y; int ld;                            // Y (and dZ) row pitch
+    const float *coef;
+};
+
+// POOL: 0 dense dZ; 1 pooled with Kp a multiple of 64 (the tile lies in ONE group: one (dZp, arg) quad per thread and
+// tile); 2 pooled with Kp == 32 (two groups per tile).  DEPTH: register sets of prefetched tiles.
+template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH>
+__global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *__restrict__ Yp, int ldp,
                                                          const float *__restrict__ aff_p, const float *__restrict__ W, int ldw,
-                                                         int64_t P, int Ci, float *__restrict__ dX, int ldxo,
+                                                         int64_t tiles, float *__restrict__ dX, int ldxo,
                                                          double *__restrict__ red_p, float *__restrict__ dW, int lddw,
-                                                         ResPlan plan, const float *zp) {
-    constexpr int Co = 32 * CO_T, LDY = Co + 4, QD = Co / 4, IT_D = RES_BM * QD / 512;
-    static_assert(RES_BM * QD % 512 == 0, "dY tile must split evenly over 512 threads");
-    const int LDP = Ci + 4, QP = Ci >> 2, IT_P = QP >> 3;          // 64 * QP / 512 quads of Y_prev per thread (Ci % 32 == 0)
+                                                         ResPlan plan) {
+    constexpr int Co = 32 * CO_T, Ci = 32 * CI_T, LDY = Co + 4, LDP = Ci + 4, QD = Co / 4, QP = Ci / 4;
+    constexpr int IT_D = RES_BM * QD / 512, IT_P = RES_BM * QP / 512;
+    static_assert(RES_BM * QD % 512 == 0 && RES_BM * QP % 512 == 0, "tiles must split evenly over 512 threads");
+    constexpr bool POOLED = POOL != 0;
+    // 512 % QD == 0 (Co = 32, 64, 128): a thread's quads t + 512 i all sit in the same channel quad, RPI rows apart, so
+    // the pooled operands (one row per GROUP) repeat: slot(i) = which of the NZ distinct (dZp, arg) quads quad i uses
+    constexpr int RPI = 512 / QD;
+    static_assert(!POOLED || 512 % QD == 0, "pooled variants need Co in {32, 64, 128}");
+    constexpr int NZ = !POOLED ? IT_D : (POOL == 2 && IT_D > 1 ? 2 : 1);
+    auto slot = [](int i) { return POOL == 2 && IT_D > 1 ? (RPI * i) / 32 : 0; };
     float *Wt = res_lds;                                           // [Ci][LDY]: W transposed, co contiguous
     float *dYs = Wt + Ci * LDY;                                    // [64][LDY]
     float *Yps = dYs + RES_BM * LDY;                               // [64][LDP]
     float *tab = Yps + RES_BM * LDP;                               // coefficient rows c0, q1, q0, mean of this layer: 4 * Co
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
-    const int64_t tiles = (P + RES_BM - 1) / RES_BM;
+    const int G = gridDim.x;
 
     // ---- one-time: W^T, coefficient table
     for (int i = t; i < Co * Ci; i += 512) {
         const int co = i / Ci, ci = i - co * Ci;
         Wt[ci * LDY + co] = W[(int64_t)co * ldw + ci];
     }
-    for (int i = t; i < 4 * Co; i += 512) tab[i] = dyload.tab_src()[i];
+    for (int i = t; i < 4 * Co; i += 512) tab[i] = dy.coef[i];
 
     // ---- this wave's share of every tile (fixed for the whole launch)
     const int dx_rb = plan.dx_rb[wave], dx_cj = plan.dx_cj[wave], n_dw = plan.dw_n[wave];
-    int dw_a[3], dw_b[3], dw_p0[3], dw_p1[3];                      // LDS column offsets of the unit, its row range
+    int dw_a[3], dw_b[3], dw_h0[3], dw_h1[3];                      // LDS column offsets of the unit, its row halves [h0, h1)
     float xmu[3], xsc[3], xbe[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -106,8 +139,9 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(DyLoad dyload, const fl
         const int cb = on ? plan.dw_cb[wave][u] : 0, cj = on ? plan.dw_cj[wave][u] : 0, rows = on ? plan.dw_rows[wave][u] : 0;
         dw_a[u] = cb * 32 + l31;
         dw_b[u] = cj * 32 + l31;
-        dw_p0[u] = on ? (rows == 1 ? 16 : 0) : 0;                  // in units of row PAIRS
-        dw_p1[u] = on ? (rows == 0 ? 16 : 32) : 0;
+        dw_h0[u] = on ? (rows == 1 ? 1 : 0) : 0;
+        dw_h1[u] = on ? (rows == 0 ? 1 : 2) : 0;
+        xmu[u] = xsc[u] = xbe[u] = 0.f;
         if (MASKED) {
             Affine a(aff_p, Ci);
             xmu[u] = a.mean[dw_b[u]]; xsc[u] = a.scale[dw_b[u]]; xbe[u] = a.beta[dw_b[u]];
@@ -127,49 +161,82 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(DyLoad dyload, const fl
         for (int r = 0; r < 16; ++r) accw[u][r] = 0.f;
     double st0 = 0.0, st1 = 0.0;
 
-    // ---- tile loaders: dY quads idx = t + 512 i -> (row, quad); Y_prev quads likewise
-    typename DyLoad::template Raw<1> ra[IT_D];
-    float4 rp[4];
-    auto fetch = [&](int64_t tile) {
-        const int64_t m0 = tile * RES_BM;
-        const bool tv = tile < tiles;
+    // ---- loop-invariant lane offsets (elements): dY quads idx = t + 512 i -> (row, quad); Y_prev quads likewise.
+    // Every global address is a kernel-argument base plus a 32-bit element offset = tile term + lane term.
+    unsigned od[IT_D], og[NZ], kk[IT_D], op[IT_P];
 #pragma unroll
-        for (int i = 0; i < IT_D; ++i) {
-            const int idx = t + 512 * i, row = idx / QD, q = idx - row * QD;
-            dyload.template issue<1>(ra[i], m0 + row, 0, 4 * q, P, tv);
+    for (int i = 0; i < IT_D; ++i) {
+        const int idx = t + 512 * i, row = idx / QD, q = idx - row * QD;
+        od[i] = (unsigned)row * (unsigned)dy.ld + 4u * q;
+        kk[i] = 0;
+        if (POOLED) {                                              // group of the row relative to the tile's first group
+            const unsigned gsub = POOL == 1 ? 0u : (unsigned)row >> 5;
+            og[slot(i)] = gsub * (unsigned)dy.ldo + 4u * q;
+            kk[i] = POOL == 1 ? (unsigned)row : (unsigned)row & 31u;     // + (m0 mod Kp) when Kp > 64
         }
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < IT_P) {
-                const int idx = t + 512 * i, row = idx / QP, q = idx - row * QP;
-                rp[i] = ld4((tv && m0 + row < P) ? Yp + row_off(m0 + row, ldp) + 4 * q : zp);
+    for (int i = 0; i < IT_P; ++i) {
+        const int idx = t + 512 * i, row = idx / QP, q = idx - row * QP;
+        op[i] = (unsigned)row * (unsigned)ldp + 4u * q;
+    }
+
+    // Two register sets: the loads of tile n + 2 are issued as soon as tile n has been written to LDS, so one to two
+    // tiles are always in flight -- with a single set the memory pipe idled from "tile landed" to "next fetch issued"
+    // and a tile cost T_mem + T_compute (measured: matrix pipe 47 % busy, a third of the wave cycles in s_waitcnt).
+    struct Regs { float4 y[IT_D]; float4 z[NZ]; int4 a[POOLED ? NZ : 1]; float4 p[IT_P]; };
+    Regs rs[DEPTH];
+    auto fetch = [&](Regs &R, int64_t tile) {
+        const unsigned tl = (unsigned)(tile < tiles ? tile : tiles - 1);   // past the end: re-read the last tile (never used)
+        const unsigned ty = tl * (unsigned)(RES_BM * dy.ld), tp = tl * (unsigned)(RES_BM * ldp);
+        if (POOLED) {
+            const unsigned g0 = POOL == 1 ? (tl * RES_BM) >> dy.kshift : tl << 1;
+            const unsigned tg = g0 * (unsigned)dy.ldo;
+#pragma unroll
+            for (int i = 0; i < IT_D; ++i) R.y[i] = ld4(dy.Y + (ty + od[i]));
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) {
+                R.z[j] = ld4(dy.dZp + (tg + og[j]));
+                R.a[j] = ld4i(dy.arg + (tg + og[j]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < IT_D; ++i) {
+                R.y[i] = ld4(dy.Y + (ty + od[i]));
+                R.z[i] = ld4(dy.dZ + (ty + od[i]));
             }
         }
+#pragma unroll
+        for (int i = 0; i < IT_P; ++i) R.p[i] = ld4(Yp + (tp + op[i]));
     };
-    int64_t tile = blockIdx.x;
-    fetch(tile);
-    __syncthreads();                                               // Wt and tab are in place
-
-    for (; tile < tiles; tile += gridDim.x) {
-        const int64_t m0 = tile * RES_BM;
+    auto step = [&](Regs &R, int64_t tile) {
         // ---- registers -> LDS (dY formed here, once per row)
+        const unsigned kbase = POOL == 1 ? (unsigned)(tile * RES_BM) & ((1u << dy.kshift) - 1u) : 0u;
 #pragma unroll
         for (int i = 0; i < IT_D; ++i) {
             const int idx = t + 512 * i, row = idx / QD, q = idx - row * QD;
             const DyParams dp = dy_params_tab(tab, Co, 4 * q, true);
-            *reinterpret_cast<float4 *>(&dYs[row * LDY + 4 * q]) = dyload.template finish<1>(ra[i], 0, m0 + row < P, dp);
+            float4 dz = R.z[POOLED ? slot(i) : i];
+            if (POOLED) {
+                const int4 a = R.a[slot(i)];
+                const int k = (int)(kk[i] + kbase);
+                dz.x = a.x == k ? dz.x : 0.f; dz.y = a.y == k ? dz.y : 0.f;
+                dz.z = a.z == k ? dz.z : 0.f; dz.w = a.w == k ? dz.w : 0.f;
+            }
+            *reinterpret_cast<float4 *>(&dYs[row * LDY + 4 * q]) = dy_from(dz, R.y[i], dp);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < IT_P) {
-                const int idx = t + 512 * i, row = idx / QP, q = idx - row * QP;
-                *reinterpret_cast<float4 *>(&Yps[row * LDP + 4 * q]) = rp[i];
-            }
+        for (int i = 0; i < IT_P; ++i) {
+            const int idx = t + 512 * i, row = idx / QP, q = idx - row * QP;
+            *reinterpret_cast<float4 *>(&Yps[row * LDP + 4 * q]) = R.p[i];
         }
-        fetch(tile + gridDim.x);                                   // in flight under this tile's MFMAs
+        fetch(R, tile + DEPTH * (int64_t)G);                      // this set is free again: DEPTH tiles ahead
         __syncthreads();
 
         // ---- dX tile: rows rb*32.., columns cj*32.. ; contraction over Co, both operands 4 k-values per ds_read_b128
+        float outv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) outv[r] = 0.f;
         if (dx_rb >= 0) {
             f32x16 acc;
 #pragma unroll
@@ -185,37 +252,74 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(DyLoad dyload, const fl
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
             }
+            const float *yq = &Yps[(dx_rb * 32 + 4 * lh) * LDP + ecol];
+            float yv[16];
+            if (MASKED) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = yq[((r & 3) + 8 * (r >> 2)) * LDP];      // immediate offsets, one wait
+            }
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = dx_rb * 32 + acc_row(r, lh);
                 float dz = acc[r];
                 if (MASKED) {
-                    const float y = Yps[row * LDP + ecol];
+                    const float y = yv[r];
                     dz = bn_act(y, emu, esc, ebe) > 0.f ? dz : 0.f;
                     s0 += dz;
                     s1 = __builtin_fmaf(dz, (y - emu) * eis, s1);
                 }
-                if (m0 + row < P) __builtin_nontemporal_store(dz, dX + row_off(m0 + row, ldxo) + ecol);
+                outv[r] = dz;
             }
             if (MASKED) { st0 += (double)s0; st1 += (double)s1; }
         }
-        // ---- dW units: contraction over the rows of the tile, one MFMA per row pair
+        // The sixteen stores are issued by EVERY wave (a wave without a dX tile writes zeros to the dump page): the same
+        // count of memory operations on every path, so the wait for a prefetched tile stays an exact s_waitcnt vmcnt(N)
+        // that leaves the younger tile and these stores in flight -- counted against the shorter path it drained them.
+        // Address = base + one 32-bit offset that changes per tile (nothing to hoist into sixteen address registers).
+        {
+            float *sb = dx_rb >= 0 ? dX : pn2_dump_lines;
+            const unsigned xo = dx_rb >= 0 ? (unsigned)tile * (unsigned)(RES_BM * ldxo) + (unsigned)(dx_rb * 32 + 4 * lh) * (unsigned)ldxo + (unsigned)ecol
+                                           : ((blockIdx.x & 1023u) * 8u + (unsigned)wave) * 64u + (unsigned)lane;
+            const unsigned xs = dx_rb >= 0 ? (unsigned)ldxo : 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(outv[r], sb + (xo + (unsigned)((r & 3) + 8 * (r >> 2)) * xs));
+        }
+        // ---- dW units: contraction over the rows of the tile in halves of 16 row pairs (one MFMA per pair): a fixed,
+        // fully unrolled trip count -- with a run-time count the loop stayed rolled and every MFMA waited out its own
+        // two LDS reads
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             if (u < n_dw) {
-                const float *ap = &dYs[lh * LDY + dw_a[u]];
-                const float *bp = &Yps[lh * LDP + dw_b[u]];
-#pragma unroll 8
-                for (int pp = dw_p0[u]; pp < dw_p1[u]; ++pp) {
-                    const float a = ap[2 * pp * LDY];
-                    float b = bp[2 * pp * LDP];
-                    if (MASKED) b = fmaxf(bn_act(b, xmu[u], xsc[u], xbe[u]), 0.f);
-                    accw[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accw[u], 0, 0, 0);
+                for (int h = dw_h0[u]; h < dw_h1[u]; ++h) {
+                    const float *ap = &dYs[(32 * h + lh) * LDY + dw_a[u]];
+                    const float *bp = &Yps[(32 * h + lh) * LDP + dw_b[u]];
+                    float a[16], b[16];
+#pragma unroll
+                    for (int pp = 0; pp < 16; ++pp) { a[pp] = ap[2 * pp * LDY]; b[pp] = bp[2 * pp * LDP]; }
+#pragma unroll
+                    for (int pp = 0; pp < 16; ++pp) {
+                        float bb = b[pp];
+                        if (MASKED) bb = fmaxf(bn_act(bb, xmu[u], xsc[u], xbe[u]), 0.f);
+                        accw[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pp], bb, accw[u], 0, 0, 0);
+                    }
                 }
             }
         }
         __syncthreads();                                           // tile consumed: the next one may land
+    };
+
+    int64_t tile = blockIdx.x;
+    fetch(rs[0], tile);
+    if (DEPTH > 1) fetch(rs[DEPTH - 1], tile + G);
+    __syncthreads();                                               // Wt and tab are in place
+    while (tile < tiles) {
+        step(rs[0], tile);
+        tile += G;
+        if (DEPTH > 1) {
+            if (tile >= tiles) break;
+            step(rs[DEPTH - 1], tile);
+            tile += G;
+        }
     }
 
     // ---- flush: dW partial tiles (256 contiguous bytes per wave-instruction), the dX column's two reductions
@@ -243,36 +347,49 @@ inline size_t bwd_res_lds_bytes(int Co, int Ci) {
     return sizeof(float) * ((size_t)Ci * (Co + 4) + RES_BM * (Co + 4) + RES_BM * (Ci + 4) + 4 * Co);
 }
 
-template <int CO_T, class DyLoad, bool MASKED>
-int launch_bwd_res(DyLoad dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t P, int Ci, float *dX,
-                   int ldxo, double *red_p, float *dW, int lddw, hipStream_t s) {
+template <int CO_T, int CI_T, int POOL, bool MASKED>
+int launch_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
+                   double *red_p, float *dW, int lddw, hipStream_t s) {
     ResPlan plan;
-    if (!make_res_plan(CO_T, Ci / 32, &plan)) return PN2_EINVAL;
-    const size_t lds = bwd_res_lds_bytes(32 * CO_T, Ci);
+    if (!make_res_plan(CO_T, CI_T, &plan)) return PN2_EINVAL;
+    const size_t lds = bwd_res_lds_bytes(32 * CO_T, 32 * CI_T);
     static bool raised = false;
+    // two tiles in flight where a tile's MFMA work is shorter than its memory time (the light pairs, which also have the
+    // registers for it); the heavy pairs cover a tile's loads with the previous tile's MFMAs
+    constexpr int DEPTH = CO_T * CI_T <= 6 ? 2 : 1;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, DyLoad, MASKED>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PN2_ELAUNCH;
         raised = true;
     }
-    const int64_t tiles = pn2_cdiv(P, RES_BM);
     const int64_t cap = pn2_num_cus();                             // one 8-wave workgroup per CU
-    hipLaunchKernelGGL((bwd_res_kernel<CO_T, DyLoad, MASKED>), dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(512), lds, s, dy, Yp,
-                       ldp, aff_p, W, ldw, P, Ci, dX, ldxo, red_p, dW, lddw, plan, zero_page_dev());
+    hipLaunchKernelGGL((bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH>), dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(512), lds, s, dy, Yp,
+                       ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, plan);
     return pn2_launch_status();
 }
 
-template <class DyLoad, bool MASKED>
-int dispatch_bwd_res(int Co, DyLoad dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t P, int Ci,
-                     float *dX, int ldxo, double *red_p, float *dW, int lddw, hipStream_t s) {
-    switch (Co / 32) {
-        case 1: return launch_bwd_res<1, DyLoad, MASKED>(dy, Yp, ldp, aff_p, W, ldw, P, Ci, dX, ldxo, red_p, dW, lddw, s);
-        case 2: return launch_bwd_res<2, DyLoad, MASKED>(dy, Yp, ldp, aff_p, W, ldw, P, Ci, dX, ldxo, red_p, dW, lddw, s);
-        case 3: return launch_bwd_res<3, DyLoad, MASKED>(dy, Yp, ldp, aff_p, W, ldw, P, Ci, dX, ldxo, red_p, dW, lddw, s);
-        case 4: return launch_bwd_res<4, DyLoad, MASKED>(dy, Yp, ldp, aff_p, W, ldw, P, Ci, dX, ldxo, red_p, dW, lddw, s);
+// The (C_out, C_in) pairs the networks of the model zoo actually run on long row counts, per variant -- every instantiation
+// is a 2 000-line kernel; anything else goes to the streamed dgrad + wgrad pair (the entry point does that by itself).
+//   dense, masked  (hidden layers):        32x32, 64x64, 96x64, 128x128
+//   dense, plain   (first layer of FP / head MLPs on [P, 128] inputs): 128x128
+//   pooled, masked (last layer of SA MLPs): 64x32 (K = 32), 128x64 (K = 32 and K % 64 == 0), 128x96 (K % 64 == 0)
+#define PN2_RES_CASE(CO, CI, POOL, MASKED)                                                                                \
+    if (Co == CO && Ci == CI)                                                                                              \
+        return launch_bwd_res<CO / 32, CI / 32, POOL, MASKED>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
+
+int dispatch_bwd_res(int Kpool, bool masked, int Co, int Ci, ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W,
+                     int ldw, int64_t tiles, float *dX, int ldxo, double *red_p, float *dW, int lddw, hipStream_t s) {
+    if (Kpool == 0 && masked) {
+        PN2_RES_CASE(32, 32, 0, true) PN2_RES_CASE(64, 64, 0, true) PN2_RES_CASE(96, 64, 0, true) PN2_RES_CASE(128, 128, 0, true)
+    } else if (Kpool == 0) {
+        PN2_RES_CASE(128, 128, 0, false)
+    } else if (masked && Kpool % 64 == 0) {
+        PN2_RES_CASE(128, 64, 1, true) PN2_RES_CASE(128, 96, 1, true)
+    } else if (masked && Kpool == 32) {
+        PN2_RES_CASE(64, 32, 2, true) PN2_RES_CASE(128, 64, 2, true)
     }
-    return PN2_EINVAL;
+    return PN2_EUNSUPPORTED;
 }
 
 // ----------------------------------------------------------------------------------------------- resident forward
@@ -282,8 +399,7 @@ int dispatch_bwd_res(int Co, DyLoad dy, const float *Yp, int ldp, const float *a
 template <int K_T, int N_T, bool ACT>
 __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ aff,
                                                          const float *__restrict__ W, int ldw, const float *__restrict__ bias,
-                                                         float *__restrict__ Y, int ldy, int64_t P, double *__restrict__ stats,
-                                                         const float *zp) {
+                                                         float *__restrict__ Y, int ldy, int64_t slabs, double *__restrict__ stats) {
     constexpr int K = 32 * K_T, N = 32 * N_T, LDA = K + 4, QK = K / 4, IT = 32 * QK / 64;
     const int NW = blockDim.x >> 6;
     float *Ws = res_lds;                                           // [N][LDA]
@@ -305,16 +421,21 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
 #pragma unroll
     for (int j = 0; j < N_T; ++j) bj[j] = bias[32 * j + l31];
 
-    const int64_t slabs = (P + 31) / 32;
+    // whole 32-row slabs only (the host hands a ragged tail to the streamed kernel): a per-slab uniform base plus
+    // loop-invariant 32-bit lane offsets, no row predicates
+    unsigned ox[IT], ol[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = lane + 64 * i, row = idx / QK, q = idx - row * QK;
+        ox[i] = (unsigned)row * (unsigned)ldx + 4u * q;
+        ol[i] = (unsigned)(row * LDA + 4 * q);
+    }
     const int64_t stride = (int64_t)gridDim.x * NW;
     float4 rx[IT];
     auto fetch = [&](int64_t slab) {
-        const int64_t m0 = slab * 32;
+        const float *xb = X + (slab < slabs ? slab : slabs - 1) * (int64_t)(32 * ldx);
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int idx = lane + 64 * i, row = idx / QK, q = idx - row * QK;
-            rx[i] = ld4((slab < slabs && m0 + row < P) ? X + row_off(m0 + row, ldx) + 4 * q : zp);
-        }
+        for (int i = 0; i < IT; ++i) rx[i] = ld4(xb + ox[i]);
     };
     int64_t slab = (int64_t)blockIdx.x * NW + wave;
     fetch(slab);
@@ -324,22 +445,20 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
     __syncthreads();                                               // W image and table complete (the only barrier before the end)
 
     for (; slab < slabs; slab += stride) {
-        const int64_t m0 = slab * 32;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            const int idx = lane + 64 * i, row = idx / QK, q = idx - row * QK;
             float4 x = rx[i];
             if (ACT) {
-                const float4 mu = *reinterpret_cast<const float4 *>(&atab[4 * q]);
-                const float4 sc = *reinterpret_cast<const float4 *>(&atab[K + 4 * q]);
-                const float4 be = *reinterpret_cast<const float4 *>(&atab[2 * K + 4 * q]);
+                const int q4 = (int)(ol[i] % (unsigned)LDA);
+                const float4 mu = *reinterpret_cast<const float4 *>(&atab[q4]);
+                const float4 sc = *reinterpret_cast<const float4 *>(&atab[K + q4]);
+                const float4 be = *reinterpret_cast<const float4 *>(&atab[2 * K + q4]);
                 x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
                 x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
                 x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
                 x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
-                if (m0 + row >= P) x = kZero4;                       // rows past the end contribute nothing to the statistics
             }
-            *reinterpret_cast<float4 *>(&Ab[row * LDA + 4 * q]) = x;
+            *reinterpret_cast<float4 *>(&Ab[ol[i]]) = x;
         }
         fetch(slab + stride);
 
@@ -362,21 +481,32 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
             }
         }
+        // ---- epilogue, one 32-column block at a time: bias + statistics straight from the accumulators (column on the
+        // lane), then through this wave's staging buffer (free: every MFMA of the slab has read it) so that Y leaves as
+        // 16-byte stores, 128 contiguous bytes per row -- 16 store instructions per slab instead of 64, straight-line:
+        // the next slab's operand wait stays a COUNTED vmcnt (gfx9 retires loads and stores through one in-order
+        // counter; a wait the compiler cannot count becomes vmcnt(0) and stalls on the store acknowledgements)
+        float *yb = Y + slab * (int64_t)(32 * ldy);
+        const unsigned yo = (unsigned)(lane >> 3) * (unsigned)ldy + (unsigned)(lane & 7) * 4u;
 #pragma unroll
         for (int j = 0; j < N_T; ++j) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + acc_row(r, lh);
-                if (m < P) {
-                    const float y = acc[j][r] + bj[j];
-                    __builtin_nontemporal_store(y, Y + row_off(m, ldy) + 32 * j + l31);
-                    s0 += y;
-                    s1 = __builtin_fmaf(y, y, s1);
-                }
+                const float y = acc[j][r] + bj[j];
+                Ab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + l31] = y;
+                s0 += y;
+                s1 = __builtin_fmaf(y, y, s1);
             }
             st[j][0] += (double)s0;
             st[j][1] += (double)s1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = *reinterpret_cast<const float4 *>(&Ab[((lane >> 3) + 8 * i) * 36 + (lane & 7) * 4]);
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(yb + (yo + (unsigned)(8 * i) * (unsigned)ldy + 32u * j)));
+            }
         }
     }
 
@@ -411,7 +541,7 @@ int launch_fwd_res(const float *X, int ldx, const float *aff, const float *W, in
     const size_t fixed = sizeof(float) * ((size_t)N * LDA + 3 * K), per_wave = sizeof(float) * 32 * LDA;
     int nw = (int)((160 * 1024 - fixed) / per_wave);
     if (nw > 8) nw = 8;
-    if (nw < 4) return PN2_EINVAL;
+    if (nw < 8) return PN2_EUNSUPPORTED;                             // fewer than two waves per SIMD cannot fill each other's phases
     size_t lds = fixed + nw * per_wave;
     const size_t red = sizeof(double) * 2 * N * nw;                 // the final fold reuses the image
     if (lds < red) lds = red;
@@ -422,11 +552,11 @@ int launch_fwd_res(const float *X, int ldx, const float *aff, const float *W, in
             return PN2_ELAUNCH;
         raised = true;
     }
-    const int64_t slabs = pn2_cdiv(P, 32);
+    const int64_t slabs = P / 32;                                  // whole slabs; the caller handles P % 32
     int64_t grid = pn2_cdiv(slabs, nw);
     if (grid > pn2_num_cus()) grid = pn2_num_cus();
-    hipLaunchKernelGGL((fwd_res_kernel<K_T, N_T, ACT>), dim3((unsigned)grid), dim3(64 * nw), lds, s, X, ldx, aff, W, ldw, bias, Y, ldy, P,
-                       stats, zero_page_dev());
+    hipLaunchKernelGGL((fwd_res_kernel<K_T, N_T, ACT>), dim3((unsigned)grid), dim3(64 * nw), lds, s, X, ldx, aff, W, ldw, bias, Y, ldy, slabs,
+                       stats);
     return pn2_launch_status();
 }
 
@@ -472,7 +602,7 @@ extern "C" int pn2_res_supported(int64_t P, int C_out, int C_in) {
     return on && P >= res_min_rows() && P < (1LL << 31) && res_shape_ok(C_out, C_in);
 }
 
-// Called by pn2_conv1x1_fwd (mlp.hip) for supported shapes when no fused BatchNorm tail is requested.
+// Called by pn2_conv1x1_fwd (mlp.hip) for supported shapes when no fused BatchNorm tail is requested; P % 32 == 0.
 int pn2_fwd_res(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
                 int64_t P, int K, int N, double *stats, hipStream_t s) {
     if (in_affine) return dispatch_fwd_res<true>(K, N, X, ldx, in_affine, W, ldw, bias, Y, ldy, P, stats, s);
@@ -488,15 +618,27 @@ extern "C" int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int l
     PN2_CHECK_ARG(ldw >= C_in && lddw >= C_in && ldy % 4 == 0 && ldy >= C_out && ld_prev % 4 == 0 && ld_prev >= C_in && ldxo >= C_in);
     PN2_CHECK_ARG(prev_affine != nullptr || prev_red == nullptr);
     hipStream_t s = pn2_s(stream);
-    const float *zp = zero_page_dev();
-    if (dZ) {
-        PN2_CHECK_ARG(ldz % 4 == 0 && ldz >= C_out);
-        LoadDyDense ld{dZ, ldz, Y, ldy, coef, C_out, zp};
-        if (prev_affine)
-            return dispatch_bwd_res<LoadDyDense, true>(C_out, ld, prev_Y, ld_prev, prev_affine, W, ldw, P, C_in, dXout, ldxo, prev_red, dW, lddw, s);
-        return dispatch_bwd_res<LoadDyDense, false>(C_out, ld, prev_Y, ld_prev, nullptr, W, ldw, P, C_in, dXout, ldxo, nullptr, dW, lddw, s);
+    const int kshift = dZ ? 0 : pow2_shift(Kpool);
+    PN2_CHECK_ARG(dZ ? (ldz == ldy) : (kshift >= 0 && ldo % 4 == 0 && ldo >= C_out && prev_affine != nullptr && P % Kpool == 0));
+    int64_t tiles = P / RES_BM, P_full = tiles * RES_BM;
+    int rc = PN2_OK;
+    if (tiles > 0) {
+        ResDy dy{dZ, dZp, arg, ldo, kshift, Y, ldy, coef};
+        rc = dispatch_bwd_res(dZ ? 0 : Kpool, prev_affine != nullptr, C_out, C_in, dy, prev_Y, ld_prev, prev_affine, W, ldw, tiles, dXout, ldxo,
+                              prev_red, dW, lddw, s);
+        if (rc == PN2_EUNSUPPORTED) { rc = PN2_OK; tiles = 0; P_full = 0; }    // no weight-resident kernel for this pair: all rows below
     }
-    PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= C_out && prev_affine != nullptr);
-    LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, C_out, zp, pow2_shift(Kpool)};
-    return dispatch_bwd_res<LoadDyPooled, true>(C_out, ld, prev_Y, ld_prev, prev_affine, W, ldw, P, C_in, dXout, ldxo, prev_red, dW, lddw, s);
+    if (rc != PN2_OK || P_full == P) return rc;
+    // ragged tail (< 64 rows), or a pair without a resident kernel: the streamed kernels, on offset pointers; everything
+    // they produce is accumulated
+    const int64_t tail = P - P_full;
+    const int64_t g_off = dZ ? 0 : (P_full / Kpool) * ldo;                     // P_full is a multiple of Kpool here (Kpool | 64)
+    const float *dZt = dZ ? dZ + P_full * ldz : nullptr;
+    const float *dZpt = dZ ? nullptr : dZp + g_off;
+    const int32_t *argt = dZ ? nullptr : arg + g_off;
+    rc = pn2_conv1x1_dgrad(dZt, ldz, dZpt, ldo, argt, Kpool, Y + P_full * ldy, ldy, coef, W, ldw, prev_affine ? prev_Y + P_full * ld_prev : nullptr,
+                           ld_prev, prev_affine, dXout + P_full * ldxo, ldxo, prev_red, tail, C_out, C_in, nullptr, stream);
+    if (rc != PN2_OK) return rc;
+    return pn2_conv1x1_wgrad(dZt, ldz, dZpt, ldo, argt, Kpool, Y + P_full * ldy, ldy, coef, prev_Y + P_full * ld_prev, ld_prev, prev_affine,
+                             dW, lddw, nullptr, tail, C_out, C_in, stream);
 }

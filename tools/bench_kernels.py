@@ -50,7 +50,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="?", default="all")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="", help="comma list of row counts P to keep (profiling runs)")
     args = ap.parse_args()
+    if args.only:
+        keep = {int(x) for x in args.only.split(",")}
+        FWD[:] = [s_ for s_ in FWD if s_[0] in keep]
+        BWD[:] = [s_ for s_ in BWD if s_[0] in keep]
     lib = _lib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
