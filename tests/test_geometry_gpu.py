@@ -218,3 +218,23 @@ def test_fps_cooperative_under_graph_replay(dev):
         g.replay()
         torch.cuda.synchronize()
         assert (out.cpu().numpy() == G.farthest_point_sample(xyz_np, 200, np.array(s0))).all(), s0
+
+
+@pytest.mark.parametrize("B,M,T", [(3, 5000, 37), (2, 196608, 1024), (2, 40000, 16384), (2, 30000, 20000)])
+def test_invert_index_groups_positions_by_target(dev, B, M, T):
+    """pn2_invert_index (csrc/scatter.hip): positions of every cloud grouped by the value they point at -- the LDS
+    single-pass kernel (T <= 16 384) and the three-pass fallback -- incl. out-of-range entries (dropped, -1 at the end)."""
+    rng = np.random.default_rng(B * M + T)
+    idx = rng.integers(0, T, (B, M))
+    idx[0, ::97] = T + 5                        # out of range: dropped
+    idx[1, 5::131] = -1
+    members, owners = U._inverse_index(torch.from_numpy(idx).to(dev), T)
+    members, owners = members.cpu().numpy(), owners.cpu().numpy()
+    for b in range(B):
+        valid = (idx[b] >= 0) & (idx[b] < T)
+        n = int(valid.sum())
+        assert (members[b, n:] == -1).all()
+        mem, own = members[b, :n], owners[b, :n]
+        assert (np.diff(own) >= 0).all()                         # grouped by target, targets ascending
+        assert (idx[b][mem] == own).all()                        # every member points at its owner
+        assert np.array_equal(np.sort(mem), np.nonzero(valid)[0])    # each valid position exactly once
