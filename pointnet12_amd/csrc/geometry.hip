@@ -307,60 +307,86 @@ int launch_fps(const float *xyz, int B, int N, const int64_t *start, int npoint,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ball query: a workgroup of BQ_WAVES waves takes BQ_WAVES consecutive query centres of one cloud.  The candidates are
-// staged through LDS in tiles of BQ_TILE points as (x, y, z, |p|^2) float4 -- loaded and normed ONCE per workgroup,
-// coalesced, instead of every wave re-reading the cloud from L2 with 12-byte-stride scalar loads and recomputing the
-// norm per pair -- and every wave scans the tile in index order, 64 candidates per ds_read_b128 step: a ballot + prefix
-// popcount gives each in-radius lane its output slot, and the wave stops as soon as nsample slots are filled (the
-// reference sorts a full N-row instead, pointnet_util.py:100-106).  The tile loop ends for the whole workgroup once
-// every wave is done (a KITTI-shaped cloud fills r = 0.1 / K = 32 after ~4 % of the scan).
+// Ball query.  A workgroup of BQ_WAVES waves takes BQ_WAVES * BQ_CPW consecutive query centres of one cloud, every wave
+// BQ_CPW of them at once.  The candidates are staged through LDS in tiles of BQ_TILE points as (x, y, z, |p|^2) float4 --
+// loaded and normed ONCE per workgroup (coalesced, the next tile's raw floats already in flight in registers while the
+// current one is scanned) instead of every wave re-reading the cloud from L2 with 12-byte-stride scalar loads and
+// recomputing the norm per pair.  A wave scans the tile in index order, 64 candidates per ds_read_b128 step, and tests
+// that candidate against its BQ_CPW centres: one LDS read and one loop trip per 256 pairs.  Per centre a ballot + prefix
+// popcount gives each in-radius lane its output slot; a centre stops at nsample slots, the wave when all its centres
+// have, the tile loop when every wave has (the reference sorts a full N-row instead, pointnet_util.py:100-106).
+// On a KITTI-shaped cloud 8..40 % of the balls never fill (far, sparse points): those centres scan the whole cloud,
+// which is what the launch costs -- 3 G pairs at cfg5.
 // ---------------------------------------------------------------------------------------------
-constexpr int BQ_WAVES = 8, BQ_TILE = 2048;
+constexpr int BQ_WAVES = 4, BQ_CPW = 4, BQ_TILE = 1024, BQ_THREADS = BQ_WAVES * 64, BQ_PPT = BQ_TILE / BQ_THREADS;
 
-__global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(const float *__restrict__ xyz,
-                                                                  const float *__restrict__ new_xyz, int N, int S, float r2,
-                                                                  int nsample, int64_t *__restrict__ out) {
+__global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__restrict__ xyz,
+                                                                const float *__restrict__ new_xyz, int N, int S, float r2,
+                                                                int nsample, int64_t *__restrict__ out) {
     __shared__ float4 tile[BQ_TILE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int s = blockIdx.x * BQ_WAVES + wave, b = blockIdx.y;
-    const bool live = s < S;
+    const int s0 = (blockIdx.x * BQ_WAVES + wave) * BQ_CPW, b = blockIdx.y;
     const float *p = xyz + (size_t)b * N * 3;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (live) {
-        const float *q = new_xyz + ((size_t)b * S + s) * 3;
-        qx = q[0]; qy = q[1]; qz = q[2];
+    float qx[BQ_CPW], qy[BQ_CPW], qz[BQ_CPW], nq[BQ_CPW];
+    int cnt[BQ_CPW], first[BQ_CPW];
+#pragma unroll
+    for (int c = 0; c < BQ_CPW; ++c) {
+        const bool live = s0 + c < S;
+        const float *q = new_xyz + ((size_t)b * S + (live ? s0 + c : 0)) * 3;
+        qx[c] = q[0]; qy[c] = q[1]; qz[c] = q[2];
+        nq[c] = sq_norm3(qx[c], qy[c], qz[c]);
+        cnt[c] = live ? 0 : nsample;                     // a centre past the end is "done" from the start
+        first[c] = N;
     }
-    const float nq = sq_norm3(qx, qy, qz);
-    int64_t *row = out + ((size_t)b * S + (live ? s : 0)) * nsample;
-    int cnt = live ? 0 : nsample, first = N;
+    int64_t *rows = out + ((size_t)b * S + s0) * nsample;
+    float raw[BQ_PPT][3];
+    auto fetch = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < BQ_PPT; ++i) {
+            const int j = base + t + i * BQ_THREADS;
+            const float *src = p + 3 * (size_t)(j < N ? j : 0);
+            raw[i][0] = src[0]; raw[i][1] = src[1]; raw[i][2] = src[2];
+        }
+    };
+    fetch(0);
     for (int base = 0; base < N; base += BQ_TILE) {
         const int tn = min(BQ_TILE, N - base);
-        for (int k = t; k < tn; k += BQ_WAVES * 64) {
-            const float x = p[3 * (base + k)], y = p[3 * (base + k) + 1], z = p[3 * (base + k) + 2];
-            tile[k] = make_float4(x, y, z, sq_norm3(x, y, z));
-        }
+#pragma unroll
+        for (int i = 0; i < BQ_PPT; ++i)
+            tile[t + i * BQ_THREADS] = make_float4(raw[i][0], raw[i][1], raw[i][2], sq_norm3(raw[i][0], raw[i][1], raw[i][2]));
         __syncthreads();
-        for (int c = 0; c < tn && cnt < nsample; c += 64) {
-            const int j = c + lane;
-            bool in = false;
-            if (j < tn) {
-                const float4 v = tile[j];
-                const float d = pair_dist(qx, qy, qz, nq, v.x, v.y, v.z, v.w);
-                in = !(d > r2);
-            }
-            const unsigned long long mask = __ballot(in);
-            if (mask) {
-                const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-                if (in && pos < nsample) row[pos] = base + j;
-                if (cnt == 0) first = base + c + __ffsll((long long)mask) - 1;
-                cnt += __popcll(mask);
+        if (base + BQ_TILE < N) fetch(base + BQ_TILE);           // in flight under the scan
+        bool busy = false;
+#pragma unroll
+        for (int c = 0; c < BQ_CPW; ++c) busy |= cnt[c] < nsample;
+        for (int k = 0; k < tn && busy; k += 64) {
+            const int j = k + lane;
+            const float4 v = tile[j < tn ? j : 0];
+            busy = false;
+#pragma unroll
+            for (int c = 0; c < BQ_CPW; ++c) {
+                if (cnt[c] < nsample) {
+                    const float d = pair_dist(qx[c], qy[c], qz[c], nq[c], v.x, v.y, v.z, v.w);
+                    const bool in = j < tn && !(d > r2);
+                    const unsigned long long mask = __ballot(in);
+                    if (mask) {
+                        const int pos = cnt[c] + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (in && pos < nsample) rows[(size_t)c * nsample + pos] = base + j;
+                        if (cnt[c] == 0) first[c] = base + k + __ffsll((long long)mask) - 1;
+                        cnt[c] += __popcll(mask);
+                    }
+                    busy |= cnt[c] < nsample;
+                }
             }
         }
-        if (__syncthreads_or(cnt < nsample) == 0) break;          // also: the tile may be overwritten
+        if (__syncthreads_or(busy) == 0) break;                   // also: the tile may be overwritten
     }
-    if (!live) return;
-    if (cnt > nsample) cnt = nsample;
-    for (int k = cnt + lane; k < nsample; k += 64) row[k] = first;
+#pragma unroll
+    for (int c = 0; c < BQ_CPW; ++c) {
+        if (s0 + c >= S) break;
+        const int have = cnt[c] > nsample ? nsample : cnt[c];
+        for (int k = have + lane; k < nsample; k += 64) rows[(size_t)c * nsample + k] = first[c];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -521,7 +547,7 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
 int pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int nsample,
                    int64_t *out_idx, pn2_stream_t stream) {
     PN2_CHECK_ARG(xyz && new_xyz && out_idx && B > 0 && N > 0 && S > 0 && nsample > 0 && B <= 65535);
-    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)pn2_cdiv(S, BQ_WAVES), B), dim3(BQ_WAVES * 64), 0, pn2_s(stream), xyz,
+    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)pn2_cdiv(S, BQ_WAVES * BQ_CPW), B), dim3(BQ_THREADS), 0, pn2_s(stream), xyz,
                        new_xyz, N, S, r2, nsample, out_idx);
     return pn2_launch_status();
 }
