@@ -359,24 +359,39 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
         bool busy = false;
 #pragma unroll
         for (int c = 0; c < BQ_CPW; ++c) busy |= cnt[c] < nsample;
-        for (int k = 0; k < tn && busy; k += 64) {
-            const int j = k + lane;
-            const float4 v = tile[j < tn ? j : 0];
+        // Branch-free test of one candidate against the wave's centres (a finished centre tests against r2 = -1: never
+        // inside), ONE branch per step for the rare "somebody got a hit" path, two steps in flight: a lone full-scan
+        // wave -- the isolated far point that never fills its ball decides how long the workgroup lives -- is bound
+        // by the latency chain LDS read -> distance -> compare -> branch, not by issue slots.
+        for (int k = 0; k < tn && busy; k += 128) {
+            const int j0 = k + lane, j1 = k + 64 + lane;
+            const float4 v0 = tile[j0 < tn ? j0 : 0], v1 = tile[j1 < tn ? j1 : 0];
+            unsigned long long m0[BQ_CPW], m1[BQ_CPW], any = 0ull;
+#pragma unroll
+            for (int c = 0; c < BQ_CPW; ++c) {
+                const float rc = cnt[c] < nsample ? r2 : -1.0f;
+                const float d0 = pair_dist(qx[c], qy[c], qz[c], nq[c], v0.x, v0.y, v0.z, v0.w);
+                const float d1 = pair_dist(qx[c], qy[c], qz[c], nq[c], v1.x, v1.y, v1.z, v1.w);
+                m0[c] = __ballot(j0 < tn && !(d0 > rc));
+                m1[c] = __ballot(j1 < tn && !(d1 > rc));
+                any |= m0[c] | m1[c];
+            }
+            if (any == 0ull) continue;
             busy = false;
 #pragma unroll
             for (int c = 0; c < BQ_CPW; ++c) {
-                if (cnt[c] < nsample) {
-                    const float d = pair_dist(qx[c], qy[c], qz[c], nq[c], v.x, v.y, v.z, v.w);
-                    const bool in = j < tn && !(d > r2);
-                    const unsigned long long mask = __ballot(in);
-                    if (mask) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned long long mask = h ? m1[c] : m0[c];
+                    if (mask && cnt[c] < nsample) {              // (the second half-step of a centre that just filled up: skipped)
+                        const int j = h ? j1 : j0;
                         const int pos = cnt[c] + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (in && pos < nsample) rows[(size_t)c * nsample + pos] = base + j;
-                        if (cnt[c] == 0) first[c] = base + k + __ffsll((long long)mask) - 1;
+                        if (((mask >> lane) & 1ull) && pos < nsample) rows[(size_t)c * nsample + pos] = base + j;
+                        if (cnt[c] == 0) first[c] = base + k + 64 * h + __ffsll((long long)mask) - 1;
                         cnt[c] += __popcll(mask);
                     }
-                    busy |= cnt[c] < nsample;
                 }
+                busy |= cnt[c] < nsample;
             }
         }
         if (__syncthreads_or(busy) == 0) break;                   // also: the tile may be overwritten

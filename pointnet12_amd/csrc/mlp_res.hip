@@ -98,7 +98,12 @@ struct ResDy {
 
 // POOL: 0 dense dZ; 1 pooled with Kp a multiple of 64 (the tile lies in ONE group: one (dZp, arg) quad per thread and
 // tile); 2 pooled with Kp == 32 (two groups per tile).  DEPTH: register sets of prefetched tiles.
-template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH>
+// DBUF: two dY tiles in LDS.  The waves then form tile n + 1's dY (the VALU-heavy part of a tile: BatchNorm-backward
+// transform, max-pool select, LDS stores) in the SAME barrier interval in which they multiply tile n, waves 0-3 before
+// their MFMAs and waves 4-7 after theirs: the two waves of a SIMD (w and w + 4) sit in opposite phases, so one's
+// transform runs in the shadow of the other's matrix work instead of both queueing for the pipe and then both idling
+// it (single buffer: matrix pipe 43-57 % busy, the rest the lock-stepped transform / epilogue phases).
+template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF>
 __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *__restrict__ Yp, int ldp,
                                                          const float *__restrict__ aff_p, const float *__restrict__ W, int ldw,
                                                          int64_t tiles, float *__restrict__ dX, int ldxo,
@@ -114,9 +119,10 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     static_assert(!POOLED || 512 % QD == 0, "pooled variants need Co in {32, 64, 128}");
     constexpr int NZ = !POOLED ? IT_D : (POOL == 2 && IT_D > 1 ? 2 : 1);
     auto slot = [](int i) { return POOL == 2 && IT_D > 1 ? (RPI * i) / 32 : 0; };
+    static_assert(!DBUF || DEPTH == 1, "the double-buffered form keeps one register set");
     float *Wt = res_lds;                                           // [Ci][LDY]: W transposed, co contiguous
-    float *dYs = Wt + Ci * LDY;                                    // [64][LDY]
-    float *Yps = dYs + RES_BM * LDY;                               // [64][LDP]
+    float *dYs = Wt + Ci * LDY;                                    // [DBUF ? 2 : 1][64][LDY]
+    float *Yps = dYs + (DBUF ? 2 : 1) * RES_BM * LDY;              // [64][LDP]
     float *tab = Yps + RES_BM * LDP;                               // coefficient rows c0, q1, q0, mean of this layer: 4 * Co
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
@@ -186,9 +192,9 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     // and a tile cost T_mem + T_compute (measured: matrix pipe 47 % busy, a third of the wave cycles in s_waitcnt).
     struct Regs { float4 y[IT_D]; float4 z[NZ]; int4 a[POOLED ? NZ : 1]; float4 p[IT_P]; };
     Regs rs[DEPTH];
-    auto fetch = [&](Regs &R, int64_t tile) {
+    auto fetch_dy = [&](Regs &R, int64_t tile) {
         const unsigned tl = (unsigned)(tile < tiles ? tile : tiles - 1);   // past the end: re-read the last tile (never used)
-        const unsigned ty = tl * (unsigned)(RES_BM * dy.ld), tp = tl * (unsigned)(RES_BM * ldp);
+        const unsigned ty = tl * (unsigned)(RES_BM * dy.ld);
         if (POOLED) {
             const unsigned g0 = POOL == 1 ? (tl * RES_BM) >> dy.kshift : tl << 1;
             const unsigned tg = g0 * (unsigned)dy.ldo;
@@ -206,11 +212,14 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
                 R.z[i] = ld4(dy.dZ + (ty + od[i]));
             }
         }
+    };
+    auto fetch_p = [&](Regs &R, int64_t tile) {
+        const unsigned tp = (unsigned)(tile < tiles ? tile : tiles - 1) * (unsigned)(RES_BM * ldp);
 #pragma unroll
         for (int i = 0; i < IT_P; ++i) R.p[i] = ld4(Yp + (tp + op[i]));
     };
-    auto step = [&](Regs &R, int64_t tile) {
-        // ---- registers -> LDS (dY formed here, once per row)
+    // registers -> LDS: dY of one tile, formed here once per row
+    auto finish_dy = [&](Regs &R, float *dst, int64_t tile) {
         const unsigned kbase = POOL == 1 ? (unsigned)(tile * RES_BM) & ((1u << dy.kshift) - 1u) : 0u;
 #pragma unroll
         for (int i = 0; i < IT_D; ++i) {
@@ -223,16 +232,18 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
                 dz.x = a.x == k ? dz.x : 0.f; dz.y = a.y == k ? dz.y : 0.f;
                 dz.z = a.z == k ? dz.z : 0.f; dz.w = a.w == k ? dz.w : 0.f;
             }
-            *reinterpret_cast<float4 *>(&dYs[row * LDY + 4 * q]) = dy_from(dz, R.y[i], dp);
+            *reinterpret_cast<float4 *>(&dst[row * LDY + 4 * q]) = dy_from(dz, R.y[i], dp);
         }
+    };
+    auto write_yp = [&](Regs &R) {
 #pragma unroll
         for (int i = 0; i < IT_P; ++i) {
             const int idx = t + 512 * i, row = idx / QP, q = idx - row * QP;
             *reinterpret_cast<float4 *>(&Yps[row * LDP + 4 * q]) = R.p[i];
         }
-        fetch(R, tile + DEPTH * (int64_t)G);                      // this set is free again: DEPTH tiles ahead
-        __syncthreads();
-
+    };
+    // this wave's share of one tile: dX tile + its sixteen stores, dW units
+    auto compute = [&](const float *dYt, int64_t tile) {
         // ---- dX tile: rows rb*32.., columns cj*32.. ; contraction over Co, both operands 4 k-values per ds_read_b128
         float outv[16];
 #pragma unroll
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float *ap = &dYs[(dx_rb * 32 + l31) * LDY + 4 * lh];
+            const float *ap = &dYt[(dx_rb * 32 + l31) * LDY + 4 * lh];
             const float *bp = &Wt[ecol * LDY + 4 * lh];
 #pragma unroll
             for (int kb = 0; kb < Co / 8; ++kb) {
@@ -272,10 +283,11 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
             }
             if (MASKED) { st0 += (double)s0; st1 += (double)s1; }
         }
-        // The sixteen stores are issued by EVERY wave (a wave without a dX tile writes zeros to the dump page): the same
-        // count of memory operations on every path, so the wait for a prefetched tile stays an exact s_waitcnt vmcnt(N)
-        // that leaves the younger tile and these stores in flight -- counted against the shorter path it drained them.
-        // Address = base + one 32-bit offset that changes per tile (nothing to hoist into sixteen address registers).
+        // The sixteen stores are issued by EVERY wave (a wave without a dX tile writes zeros to a dump line of its own): the
+        // same count of memory operations on every path, so the wait for a prefetched tile stays an exact s_waitcnt
+        // vmcnt(N) that leaves the younger loads and these stores in flight -- counted against the shorter path it
+        // drained them.  Address = base + one 32-bit offset that changes per tile (nothing to hoist into sixteen
+        // address registers).
         {
             float *sb = dx_rb >= 0 ? dX : pn2_dump_lines;
             const unsigned xo = dx_rb >= 0 ? (unsigned)tile * (unsigned)(RES_BM * ldxo) + (unsigned)(dx_rb * 32 + 4 * lh) * (unsigned)ldxo + (unsigned)ecol
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
         for (int u = 0; u < 3; ++u) {
             if (u < n_dw) {
                 for (int h = dw_h0[u]; h < dw_h1[u]; ++h) {
-                    const float *ap = &dYs[(32 * h + lh) * LDY + dw_a[u]];
+                    const float *ap = &dYt[(32 * h + lh) * LDY + dw_a[u]];
                     const float *bp = &Yps[(32 * h + lh) * LDP + dw_b[u]];
                     float a[16], b[16];
 #pragma unroll
@@ -305,20 +317,62 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
                 }
             }
         }
-        __syncthreads();                                           // tile consumed: the next one may land
     };
 
     int64_t tile = blockIdx.x;
-    fetch(rs[0], tile);
-    if (DEPTH > 1) fetch(rs[DEPTH - 1], tile + G);
-    __syncthreads();                                               // Wt and tab are in place
-    while (tile < tiles) {
-        step(rs[0], tile);
-        tile += G;
-        if (DEPTH > 1) {
-            if (tile >= tiles) break;
-            step(rs[DEPTH - 1], tile);
+    if (!DBUF) {
+        auto step = [&](Regs &R, int64_t tl) {
+            finish_dy(R, dYs, tl);
+            write_yp(R);
+            fetch_dy(R, tl + DEPTH * (int64_t)G);                  // this set is free again: DEPTH tiles ahead
+            fetch_p(R, tl + DEPTH * (int64_t)G);
+            __syncthreads();
+            compute(dYs, tl);
+            __syncthreads();                                       // tile consumed: the next one may land
+        };
+        fetch_dy(rs[0], tile);
+        fetch_p(rs[0], tile);
+        if (DEPTH > 1) { fetch_dy(rs[DEPTH - 1], tile + G); fetch_p(rs[DEPTH - 1], tile + G); }
+        __syncthreads();                                           // Wt and tab are in place
+        while (tile < tiles) {
+            step(rs[0], tile);
             tile += G;
+            if (DEPTH > 1) {
+                if (tile >= tiles) break;
+                step(rs[DEPTH - 1], tile);
+                tile += G;
+            }
+        }
+    } else {
+        Regs &R = rs[0];
+        const bool early = (wave & 4) == 0;
+        fetch_dy(R, tile);
+        fetch_p(R, tile);
+        __syncthreads();                                           // Wt and tab are in place
+        if (tile < tiles) {
+            finish_dy(R, dYs, tile);
+            write_yp(R);
+            fetch_dy(R, tile + G);
+            fetch_p(R, tile + G);
+        }
+        __syncthreads();
+        int cur = 0;
+        while (tile < tiles) {
+            const bool more = tile + G < tiles;
+            const float *dYc = dYs + cur * (RES_BM * LDY);
+            float *dYn = dYs + (cur ^ 1) * (RES_BM * LDY);
+            if (early) {
+                if (more) { finish_dy(R, dYn, tile + G); fetch_dy(R, tile + 2 * (int64_t)G); }
+                compute(dYc, tile);
+            } else {
+                compute(dYc, tile);
+                if (more) { finish_dy(R, dYn, tile + G); fetch_dy(R, tile + 2 * (int64_t)G); }
+            }
+            __syncthreads();                                       // tile n consumed by every wave; dY of tile n + 1 complete
+            if (more) { write_yp(R); fetch_p(R, tile + 2 * (int64_t)G); }
+            __syncthreads();                                       // Y_prev of tile n + 1 in place
+            tile += G;
+            cur ^= 1;
         }
     }
 
@@ -343,28 +397,41 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     }
 }
 
-inline size_t bwd_res_lds_bytes(int Co, int Ci) {
-    return sizeof(float) * ((size_t)Ci * (Co + 4) + RES_BM * (Co + 4) + RES_BM * (Ci + 4) + 4 * Co);
+inline size_t bwd_res_lds_bytes(int Co, int Ci, bool dbuf) {
+    return sizeof(float) * ((size_t)Ci * (Co + 4) + (dbuf ? 2 : 1) * RES_BM * (Co + 4) + RES_BM * (Ci + 4) + 4 * Co);
 }
+
+template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF>
+int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
+                        double *red_p, float *dW, int lddw, hipStream_t s);
 
 template <int CO_T, int CI_T, int POOL, bool MASKED>
 int launch_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
                    double *red_p, float *dW, int lddw, hipStream_t s) {
+    // double-buffered dY tile wherever it fits in the 160 KiB of LDS (everything but 128 x 128); else a single buffer, with
+    // two register sets of prefetched tiles on the light pairs (their tile's MFMA work is shorter than its memory time)
+    constexpr bool DBUF = sizeof(float) * ((size_t)32 * CI_T * (32 * CO_T + 4) + 2 * RES_BM * (32 * CO_T + 4) + RES_BM * (32 * CI_T + 4) + 4 * 32 * CO_T) <= 160 * 1024;
+    constexpr int DEPTH = !DBUF && CO_T * CI_T <= 6 ? 2 : 1;
+    static const int dbuf_on = [] { const char *e = getenv("PN2_RES_DBUF"); return e ? atoi(e) : 1; }();
+    if (DBUF && !dbuf_on) return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, (CO_T * CI_T <= 6 ? 2 : 1), false>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
+    return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
+}
+
+template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF>
+int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
+                        double *red_p, float *dW, int lddw, hipStream_t s) {
     ResPlan plan;
     if (!make_res_plan(CO_T, CI_T, &plan)) return PN2_EINVAL;
-    const size_t lds = bwd_res_lds_bytes(32 * CO_T, 32 * CI_T);
+    const size_t lds = bwd_res_lds_bytes(32 * CO_T, 32 * CI_T, DBUF);
     static bool raised = false;
-    // two tiles in flight where a tile's MFMA work is shorter than its memory time (the light pairs, which also have the
-    // registers for it); the heavy pairs cover a tile's loads with the previous tile's MFMAs
-    constexpr int DEPTH = CO_T * CI_T <= 6 ? 2 : 1;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PN2_ELAUNCH;
         raised = true;
     }
     const int64_t cap = pn2_num_cus();                             // one 8-wave workgroup per CU
-    hipLaunchKernelGGL((bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH>), dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(512), lds, s, dy, Yp,
+    hipLaunchKernelGGL((bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>), dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(512), lds, s, dy, Yp,
                        ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, plan);
     return pn2_launch_status();
 }
