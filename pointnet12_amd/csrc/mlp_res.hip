@@ -408,13 +408,17 @@ int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, 
 template <int CO_T, int CI_T, int POOL, bool MASKED>
 int launch_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
                    double *red_p, float *dW, int lddw, hipStream_t s) {
-    // double-buffered dY tile wherever it fits in the 160 KiB of LDS (everything but 128 x 128); else a single buffer, with
-    // two register sets of prefetched tiles on the light pairs (their tile's MFMA work is shorter than its memory time)
-    constexpr bool DBUF = sizeof(float) * ((size_t)32 * CI_T * (32 * CO_T + 4) + 2 * RES_BM * (32 * CO_T + 4) + RES_BM * (32 * CI_T + 4) + 4 * 32 * CO_T) <= 160 * 1024;
-    constexpr int DEPTH = !DBUF && CO_T * CI_T <= 6 ? 2 : 1;
-    static const int dbuf_on = [] { const char *e = getenv("PN2_RES_DBUF"); return e ? atoi(e) : 1; }();
-    if (DBUF && !dbuf_on) return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, (CO_T * CI_T <= 6 ? 2 : 1), false>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
-    return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
+    // Single dY buffer, two register sets of prefetched tiles on the light pairs (their tile's MFMA work is shorter than
+    // its memory time).  The double-buffered form (DBUF: tile n + 1 transformed inside tile n's barrier interval, waves 0-3
+    // and 4-7 in opposite phases) is kept behind -DPN2_RES_DBUF for A/B builds: MEASURED SLOWER on every pair
+    // (128x96 pooled 701 vs 676 us, 96x64 408 vs 385, 64x64 156 vs 136 -- profiles/r02_kernel_microbench.txt): the
+    // transform did not hide under the partner wave's MFMAs, it only delayed this wave's own.
+    constexpr int DEPTH = CO_T * CI_T <= 6 ? 2 : 1;
+#ifdef PN2_RES_DBUF
+    if constexpr (sizeof(float) * ((size_t)32 * CI_T * (32 * CO_T + 4) + 2 * RES_BM * (32 * CO_T + 4) + RES_BM * (32 * CI_T + 4) + 4 * 32 * CO_T) <= 160 * 1024)
+        return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, 1, true>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
+#endif
+    return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, DEPTH, false>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
 }
 
 template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF>

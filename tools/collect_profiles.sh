@@ -27,4 +27,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) 5 > $O/pmc_traffic_msg.json
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o t -- python3 bench.py --workload ssg --no-graph --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_ssg_$c.err
+done
+python3 tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) 5 > $O/pmc_traffic_ssg.json
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+python3 tools/bench_infer.py > $O/infer_single_cloud.jsonl 2> $O/infer.err
+python3 tools/bench_fps.py > $O/fps_probe.txt 2> $O/fps.err
 ls -la $O

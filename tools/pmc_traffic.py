@@ -19,6 +19,8 @@ def family(name):
     fam = m.group(1) if m else name
     if fam == "gemm_nt_kernel":
         fam += "<" + ("fwd" if "EpiFwd" in name else "dgrad") + ">"
+    if fam == "bwd_res_kernel":
+        fam = "gemm_bwd_fused_kernel"
     return fam
 
 
@@ -41,5 +43,10 @@ for fam in sorted(set(fetch) | set(write)):
     if rd + wr > 50e6:
         out[fam] = {"launches_per_step": nf / steps, "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
                     "hbm_bytes_per_step": rd + wr}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                     # noqa: E402  (csrc_digest: stamps the file with the kernel sources it measured)
+total = sum(v["hbm_bytes_per_step"] for v in out.values())
 print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950)",
-                  "steps_in_run": steps, "families": out}, indent=1))
+                  "steps_in_run": steps, "csrc_sha256": bench.csrc_digest(), "hbm_bytes_per_step_listed_families": total,
+                  "families": out}, indent=1))
