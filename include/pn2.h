@@ -246,6 +246,23 @@ int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int ldo, const i
                     int ld_prev, const float *prev_affine, float *dXout, int ldxo, double *prev_red, float *dW,
                     int lddw, int64_t P, int C_out, int C_in, pn2_stream_t stream);
 
+/* Eval-mode fused module (csrc/eval.hip): rows -> L x (linear + ReLU) -> max over the neighbours in ONE launch, BatchNorm
+ * folded into the weights by the caller (W' = diag(gamma / sqrt(var + eps)) W, b' likewise; rows of pitch ldw >=
+ * round8(K), zero padded, 16-byte aligned).  model/pointnet_util.py:127-133 / :243-251 (gather, centre, concat) +
+ * :194-199 / :251-256 / :309-312 (conv + BN + ReLU, max) under .eval() -- the reference's viewer loop pcdvis.py:118-136.
+ * Input: X != NULL: plain rows [P, ldx] with P passed in `B` (FP modules, heads);  X == NULL: grouped rows formed on the
+ * fly from idx [B,S,Knb] (xyz [B,N,3] minus new_xyz [B,S,3], cat with points [B,N,D]; xyz_first as pn2_group;
+ * idx == NULL with S == 1, Knb == N, new_xyz == NULL: group_all, un-centred).  pool: 0 (out [P, ldo], ReLU applied) or
+ * Knb (out [P / Knb, ldo]); Knb must be 16 or a multiple of 32.  L <= 4; activations of a 32-row tile stay in LDS. */
+typedef struct {
+    const float *W;
+    const float *bias;
+    int K, N, ldw;
+} pn2_eval_layer;
+int pn2_fused_eval(const float *X, int ldx, const float *xyz, const float *points, const float *new_xyz,
+                   const int64_t *idx, int B, int N, int S, int Knb, int D, int xyz_first,
+                   const pn2_eval_layer *layers, int L, int pool, float *out, int ldo, pn2_stream_t stream);
+
 /* ---- scatter-adds of the backward pass as segmented reductions (csrc/scatter.hip) ----------------------------
  * pn2_invert_index: idx [B, M] int64 with values in [0, T) -> members int32 [B, M], owners int32 [B, M]: the
  *   positions m of a cloud sorted by the value they point at (a counting sort per cloud; order inside one value is

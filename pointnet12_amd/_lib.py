@@ -44,6 +44,7 @@ SIGNATURES = {
     "pn2_res_supported": (_i, [_i64, _i, _i]),
     "pn2_conv1x1_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                              _i64, _i, _i, _vp]),
+    "pn2_fused_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "pn2_invert_index": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_three_interp_bwd_seg": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_group_affine_bwd_seg": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i,
@@ -70,6 +71,11 @@ class BnCoefTail(ctypes.Structure):
     """pn2_bn_coef_tail of include/pn2.h."""
     _fields_ = [("ticket", _vp), ("gamma", _vp), ("affine", _vp), ("use_batch_stats", _i), ("coef", _vp), ("dgamma", _vp),
                 ("dbeta", _vp), ("accumulate", _i)]
+
+
+class EvalLayer(ctypes.Structure):
+    """pn2_eval_layer of include/pn2.h."""
+    _fields_ = [("W", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("ldw", _i)]
 
 
 class Pn2Error(RuntimeError):

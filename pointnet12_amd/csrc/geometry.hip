@@ -137,6 +137,201 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Farthest-point sampling with exact spatial pruning (2048 < N <= 28 672, one workgroup per cloud).
+//
+// The plain kernel above updates ALL N running distances in every one of the npoint dependent iterations; on one CU
+// that is its whole cost (the iteration is bound by the instruction count of the waves sharing a SIMD: 0.55 us at
+// N = 4096, 2.25 us at 28 672).  But a new sample only lowers the distance of points closer to it than their current
+// distance, i.e. inside a ball whose radius shrinks like 1/sqrt(i).  So the points are first grouped spatially -- a
+// counting sort by Morton cell in LDS, once per launch -- and every WAVE owns one contiguous run of the sorted order
+// (64 * PPT points: a compact region) with its bounding box.  Per iteration a wave whose box is farther from the new
+// sample than its own largest running distance skips the update and re-offers its cached candidate; after the first
+// few dozen samples one to three of the sixteen waves are active.
+//
+// EXACT: a skipped update is one that provably changes nothing.  The reference distance is d = ((dx*dx + dy*dy) + dz*dz)
+// in fp32 (relative error <= 3 ulp-ish, < 4e-7); the box distance lb bounds the true distance from below and is itself
+// computed within 4e-7; a wave is skipped only if lb * (1 - 2e-6) > max(md) >= md[j], hence d_fp32(j) >= md[j] for every
+// point j of the wave and min(md[j], d) == md[j].  The running distances are therefore bit-identical to the plain
+// kernel's, and the argmax key packs (distance bits, ~ORIGINAL index) as before: lowest original index on ties.
+// Two points with equal distance inside one THREAD (duplicates -- 9..23 % of a resampled KITTI cloud) take a slow
+// path that compares their original indices through the LDS permutation.
+// ---------------------------------------------------------------------------------------------
+constexpr int FPS_NC = 4096;                          // Morton cells: 5 + 5 bits of (x, y) interleaved, 2 bits of z
+
+__device__ __forceinline__ int fps_cell(float x, float y, float z, float ox, float oy, float oz, float sx, float sy, float sz) {
+    int ix = (int)((x - ox) * sx), iy = (int)((y - oy) * sy), iz = (int)((z - oz) * sz);
+    ix = ix < 0 ? 0 : (ix > 31 ? 31 : ix);
+    iy = iy < 0 ? 0 : (iy > 31 ? 31 : iy);
+    iz = iz < 0 ? 0 : (iz > 3 ? 3 : iz);
+    unsigned m = 0;
+#pragma unroll
+    for (int bit = 0; bit < 5; ++bit) m |= (((unsigned)ix >> bit) & 1u) << (2 * bit) | (((unsigned)iy >> bit) & 1u) << (2 * bit + 1);
+    return (int)((m << 2) | (unsigned)iz);
+}
+
+template <int THREADS, int PPT>
+__global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__restrict__ xyz, int N,
+                                                             const int64_t *__restrict__ start, int npoint,
+                                                             int64_t *__restrict__ out) {
+    constexpr int NW = THREADS / 64, WCAP = 64 * PPT, CAP = THREADS * PPT;
+    extern __shared__ int fps_p_lds[];
+    int *perm = fps_p_lds;                               // [CAP]: sorted position -> original index (-1: empty)
+    int *hist = perm + CAP;                              // [FPS_NC] counts -> cursors
+    int *wsum = hist + FPS_NC;                           // [NW] + carry
+    float *box = reinterpret_cast<float *>(wsum + 32);   // [6] cloud bounding box, then [NW][6] wave boxes at box + 8
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(box + 8 + 6 * NW + 2);   // [3] rotating meeting words
+
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *p = xyz + (size_t)b * N * 3;
+
+    // ---- cloud bounding box (the cell grid adapts to whatever scale the coordinates have)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = t; j < N; j += THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = p[3 * j + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int m = 32; m >= 1; m >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], m, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], m, 64)); }
+    float *wbox = reinterpret_cast<float *>(perm);       // scratch [NW][6] (perm is not in use yet)
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { wbox[wave * 6 + a] = lo[a]; wbox[wave * 6 + 3 + a] = hi[a]; }
+    }
+    for (int i = t; i < FPS_NC; i += THREADS) hist[i] = 0;
+    if (t < 3) slots[t] = 0ull;
+    __syncthreads();
+    if (t < 6) {
+        float v = wbox[t];
+        for (int w = 1; w < NW; ++w) v = t < 3 ? fminf(v, wbox[w * 6 + t]) : fmaxf(v, wbox[w * 6 + t]);
+        box[t] = v;
+    }
+    __syncthreads();
+    const float ox = box[0], oy = box[1], oz = box[2];
+    const float sx = 32.0f / fmaxf(box[3] - ox, 1e-20f), sy = 32.0f / fmaxf(box[4] - oy, 1e-20f), sz = 4.0f / fmaxf(box[5] - oz, 1e-20f);
+    __syncthreads();                                      // wbox (aliasing perm) is dead
+
+    // ---- counting sort by cell: histogram, exclusive scan, fill through LDS cursors
+    for (int j = t; j < N; j += THREADS)
+        atomicAdd(&hist[fps_cell(p[3 * j], p[3 * j + 1], p[3 * j + 2], ox, oy, oz, sx, sy, sz)], 1);
+    __syncthreads();
+    {
+        constexpr int CPT = FPS_NC / THREADS;             // consecutive cells per thread
+        int c[CPT], sum = 0;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { c[i] = hist[t * CPT + i]; sum += c[i]; }
+        int x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int base = x - sum;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { hist[t * CPT + i] = base; base += c[i]; }
+    }
+    __syncthreads();
+    for (int j = t; j < N; j += THREADS) {
+        const int pos = atomicAdd(&hist[fps_cell(p[3 * j], p[3 * j + 1], p[3 * j + 2], ox, oy, oz, sx, sy, sz)], 1);
+        perm[pos] = j;
+    }
+    for (int i = N + t; i < CAP; i += THREADS) perm[i] = -1;
+    __syncthreads();
+
+    // ---- this thread's points: sorted positions wave * WCAP + i * 64 + lane (the wave owns one contiguous run)
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const int pbase = wave * WCAP + lane;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = perm[pbase + i * 64];
+        if (j >= 0) {
+            px[i] = p[3 * j]; py[i] = p[3 * j + 1]; pz[i] = p[3 * j + 2];
+            md[i] = 1e10f;
+            blo[0] = fminf(blo[0], px[i]); bhi[0] = fmaxf(bhi[0], px[i]);
+            blo[1] = fminf(blo[1], py[i]); bhi[1] = fmaxf(bhi[1], py[i]);
+            blo[2] = fminf(blo[2], pz[i]); bhi[2] = fmaxf(bhi[2], pz[i]);
+        } else {
+            px[i] = py[i] = pz[i] = 0.f;
+            md[i] = -1.f;                                 // never a candidate: distances are >= 0
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int m = 32; m >= 1; m >>= 1) { blo[a] = fminf(blo[a], __shfl_xor(blo[a], m, 64)); bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], m, 64)); }
+    float *mybox = box + 8 + 6 * wave;                    // kept in LDS, read back as six broadcast loads per iteration:
+    if (lane == 0) {                                      // at 24-28 points per thread every register counts
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mybox[a] = blo[a]; mybox[3 + a] = bhi[a]; }
+    }
+    __syncthreads();
+
+    int rot = 0;
+    int far = (int)(start[b] < 0 ? 0 : (start[b] >= N ? N - 1 : start[b]));
+    int64_t *o = out + (size_t)b * npoint;
+    unsigned long long wkey = ~0ull;                      // "unknown": forces the first evaluation
+    float wbest = 1e10f;
+    for (int it = 0; it < npoint; ++it) {
+        if (t == 0) o[it] = far;
+        const int f = __builtin_amdgcn_readfirstlane(far);
+        const float cx = p[3 * f], cy = p[3 * f + 1], cz = p[3 * f + 2];
+        // squared distance from the sample to this wave's box, from below
+        const float ex = fmaxf(fmaxf(mybox[0] - cx, cx - mybox[3]), 0.f), ey = fmaxf(fmaxf(mybox[1] - cy, cy - mybox[4]), 0.f),
+                    ez = fmaxf(fmaxf(mybox[2] - cz, cz - mybox[5]), 0.f);
+        const float lb = (ex * ex + ey * ey) + ez * ez;
+        if (!(lb * 0.999998f > wbest)) {                  // wave-uniform: the sample may reach into this wave's region
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+                const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                const float d = (xx + yy) + zz;
+                md[i] = min_raw(d, md[i]);                // empty slots hold -1 and stay there
+            }
+            float bm = md[0];
+#pragma unroll
+            for (int i = 1; i < PPT; ++i) bm = __builtin_fmaxf(bm, md[i]);
+            int bi = PPT - 1, hits = 0;
+#pragma unroll
+            for (int i = PPT - 1; i >= 0; --i) { const bool h = md[i] == bm; bi = h ? i : bi; hits += h ? 1 : 0; }
+            int bj = bm < 0.f ? 0 : perm[pbase + bi * 64];
+            if (__any(hits > 1 && bm >= 0.f)) {           // equal distances inside one thread: lowest ORIGINAL index wins
+                if (hits > 1 && bm >= 0.f) {
+#pragma unroll
+                    for (int i = 0; i < PPT; ++i)
+                        if (md[i] == bm) { const int j = perm[pbase + i * 64]; bj = j < bj ? j : bj; }
+                }
+            }
+            const unsigned long long key = bm < 0.f ? 0ull : ((unsigned long long)__float_as_uint(bm) << 32) | (0xFFFFFFFFu - (unsigned)bj);
+            wkey = pn2_wave_max_u64_dpp(key);
+            wbest = __uint_as_float((unsigned)(wkey >> 32));      // 0 for an empty wave: skipped from now on
+        }
+        unsigned long long *cur = slots + rot;
+        rot = rot == 2 ? 0 : rot + 1;
+        if (lane == 0) __hip_atomic_fetch_max(cur, wkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t == 0) slots[rot] = 0ull;
+        __syncthreads();
+        far = (int)(0xFFFFFFFFu - (unsigned)(*cur & 0xFFFFFFFFull));
+    }
+}
+
+template <int THREADS, int PPT>
+int launch_fps_pruned(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, hipStream_t s) {
+    const size_t lds = sizeof(int) * ((size_t)THREADS * PPT + FPS_NC + 32 + 8 + 6 * (THREADS / 64) + 2) + 64;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_pruned_kernel<THREADS, PPT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return PN2_ELAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((fps_pruned_kernel<THREADS, PPT>), dim3(B), dim3(THREADS), lds, s, xyz, N, start, npoint, out);
+    return pn2_launch_status();
+}
+
 // Any N: the running distance lives in caller scratch (global), the cloud is re-read from
 // L2 every iteration.  Used beyond the register-resident range (N > 16384).
 __global__ __launch_bounds__(1024) void fps_large_kernel(const float *__restrict__ xyz, int N,
@@ -535,6 +730,19 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
     if (N <= 512) return launch_fps<64, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 1024) return launch_fps<128, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 2048) return launch_fps<256, 8>(xyz, B, N, start, npoint, out_idx, s);
+    // spatially pruned kernel (exact, see fps_pruned_kernel) where a cloud spans at least eight waves and enough samples are
+    // drawn to pay for the one-time sort; PN2_FPS_PRUNE=0 keeps the plain kernels (A/B runs)
+    static const int prune = [] { const char *e = getenv("PN2_FPS_PRUNE"); return e ? atoi(e) : 1; }();
+    if (prune && N > 2048 && N <= 28672 && npoint >= 64) {
+        if (N <= 4096) return launch_fps_pruned<512, 8>(xyz, B, N, start, npoint, out_idx, s);
+        if (N <= 8192) return launch_fps_pruned<1024, 8>(xyz, B, N, start, npoint, out_idx, s);
+        if (N <= 16384) return launch_fps_pruned<1024, 16>(xyz, B, N, start, npoint, out_idx, s);
+        if (N <= 20480) return launch_fps_pruned<1024, 20>(xyz, B, N, start, npoint, out_idx, s);
+        if (N <= 22528) return launch_fps_pruned<1024, 22>(xyz, B, N, start, npoint, out_idx, s);
+        if (N <= 24576) return launch_fps_pruned<1024, 24>(xyz, B, N, start, npoint, out_idx, s);
+        if (N <= 26624) return launch_fps_pruned<1024, 26>(xyz, B, N, start, npoint, out_idx, s);   // (26: no spills; 28 keeps 33
+        return launch_fps_pruned<1024, 28>(xyz, B, N, start, npoint, out_idx, s);                   //  coordinate words in scratch)
+    }
     if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, start, npoint, out_idx, s);

@@ -770,7 +770,78 @@ def shared_mlp(rows, c_in, convs, bns, pool, training):
     rows = _gpu_f32(rows, "rows")
     if rows.dim() != 2 or rows.shape[1] != _r4(c_in):
         raise RuntimeError("rows must be [P, round4(c_in)] with zero pad columns")
+    if not training and _fused_eval_ok(c_in, convs, pool) and (pool == 0 or rows.shape[0] % pool == 0):
+        return fused_eval_rows(rows, c_in, convs, bns, pool)
     return _SharedMLP.apply(rows, c_in, pool, training, cfg, None, *flat)
+
+
+# ------------------------------------------------------------------------------------- eval-mode fused module
+# Under .eval() BatchNorm is a fixed affine map: it folds into the conv in front of it and a whole module becomes ONE
+# launch (csrc/eval.hip: gather -> L x (GEMM + ReLU) -> max, activations in LDS).  Taken when no gradient is wanted
+# (torch.no_grad() / inference_mode: the reference's viewer loop, pcdvis.py:118-136); PN2_FUSED_EVAL=0 keeps the
+# layer-by-layer kernels (A/B runs, and the path eval-mode autograd uses).
+FUSED_EVAL = os.environ.get("PN2_FUSED_EVAL", "1") == "1"
+_fold_cache = {}
+
+
+def _folded_layers(convs, bns):
+    """(ctypes array of pn2_eval_layer, tensors kept alive) with W' = diag(gamma / sqrt(var + eps)) W and
+    b' = (b - mean) * gamma / sqrt(var + eps) + beta, computed in fp64, rows padded to round8(C_in); cached per weight version."""
+    key = tuple(id(m) for m in convs) + tuple(id(m) for m in bns)
+    ver = tuple(int(t._version) for conv, bn in zip(convs, bns)
+                for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    hit = _fold_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    keep, arr = [], (_lib.EvalLayer * len(convs))()
+    for l, (conv, bn) in enumerate(zip(convs, bns)):
+        co = conv.weight.shape[0]
+        ci = conv.weight.numel() // co
+        scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        w = conv.weight.detach().double().reshape(co, ci) * scale[:, None]
+        b = (conv.bias.detach().double() - bn.running_mean.detach().double()) * scale + bn.bias.detach().double()
+        ldw = (ci + 7) & ~7
+        wp = torch.zeros(co, ldw, device=w.device, dtype=torch.float32)
+        wp[:, :ci] = w.float()
+        bp = b.float().contiguous()
+        keep += [wp, bp]
+        arr[l].W, arr[l].bias, arr[l].K, arr[l].N, arr[l].ldw = wp.data_ptr(), bp.data_ptr(), ci, co, ldw
+    _fold_cache[key] = (ver, arr, keep)
+    return arr, keep
+
+
+def _fused_eval_ok(c_in, convs, pool):
+    if not FUSED_EVAL or torch.is_grad_enabled() or len(convs) > 4:
+        return False
+    if pool not in (0, 16) and pool % 32:
+        return False
+    widths = [c_in] + [c.weight.shape[0] for c in convs[:-1]]
+    return max((w + 7) & ~7 for w in widths) + 4 <= 160 * 1024 // (2 * 32 * 4)
+
+
+def fused_eval_rows(rows, c_in, convs, bns, pool):
+    """Plain rows [P, ld] -> [P / pool, C_L] (pool > 0) or [P, C_L] through pn2_fused_eval."""
+    arr, _keep = _folded_layers(convs, bns)
+    P = rows.shape[0]
+    cl = convs[-1].weight.shape[0]
+    out = torch.empty(P // pool if pool else P, _r4(cl), device=rows.device, dtype=torch.float32)
+    _check(_lib.load().pn2_fused_eval(_p(rows), rows.shape[1], None, None, None, None, P, 0, 0, pool or 1, 0, 1,
+                                      ctypes.cast(arr, ctypes.c_void_p), len(convs), pool, _p(out), out.shape[1], _lib.stream()),
+           "pn2_fused_eval")
+    return out[:, :cl] if out.shape[1] != cl else out
+
+
+def fused_eval_grouped(xyz, points, new_xyz, idx, S, K, xyz_first, convs, bns):
+    """Gather + centre + concat + MLP + max over the K neighbours -> [B*S, C_L]; idx None: group_all."""
+    arr, _keep = _folded_layers(convs, bns)
+    B, N, _ = xyz.shape
+    D = 0 if points is None else points.shape[2]
+    cl = convs[-1].weight.shape[0]
+    out = torch.empty(B * S, _r4(cl), device=xyz.device, dtype=torch.float32)
+    _check(_lib.load().pn2_fused_eval(None, 0, _p(xyz), _p(points), _p(new_xyz), _p(idx), B, N, S, K, D, int(xyz_first),
+                                      ctypes.cast(arr, ctypes.c_void_p), len(convs), K, _p(out), out.shape[1], _lib.stream()),
+           "pn2_fused_eval")
+    return out[:, :cl] if out.shape[1] != cl else out
 
 
 FACTORISE_MIN_FEATURES = 32      # below this the grouped rows are narrower than the gathered layer-1 output
@@ -797,6 +868,8 @@ def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training, inv=
     """
     B, S, K = idx.shape
     D = 0 if points is None else points.shape[2]
+    if not training and _fused_eval_ok(3 + D, convs, K):
+        return fused_eval_grouped(xyz, points, new_xyz, idx.contiguous(), S, K, xyz_first, convs, bns)
     if _factorised(D, len(convs), training):
         flat, cfg = _flat_params(convs, bns)
         return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx, xyz_first, inv), *flat)
@@ -866,6 +939,9 @@ class PointNetSetAbstraction(nn.Module):
         B, N, _ = xyz.shape
         if self.group_all:
             new_xyz = torch.zeros(B, 1, 3, device=xyz.device)
+            if not _recording() and not self.training and _fused_eval_ok(3 + (0 if pts is None else pts.shape[2]), self.mlp_convs, N):
+                out = fused_eval_grouped(xyz, pts, None, None, 1, N, True, self.mlp_convs, self.mlp_bns)
+                return new_xyz.permute(0, 2, 1), out.view(B, 1, -1).permute(0, 2, 1)
             rows = None if _recording() else _Group.apply(xyz, pts, None, None, 1, N, True)
             S, K = 1, N
         else:

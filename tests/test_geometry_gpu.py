@@ -238,3 +238,32 @@ def test_invert_index_groups_positions_by_target(dev, B, M, T):
         assert (np.diff(own) >= 0).all()                         # grouped by target, targets ascending
         assert (idx[b][mem] == own).all()                        # every member points at its owner
         assert np.array_equal(np.sort(mem), np.nonzero(valid)[0])    # each valid position exactly once
+
+
+@pytest.mark.parametrize("N,S", [(2049, 100), (5000, 700), (8192, 300), (12000, 200), (16384, 128), (20000, 200), (22000, 100),
+                                 (24576, 100), (25000, 300), (26624, 70), (28672, 100)])
+@pytest.mark.parametrize("kind", ["kitti", "uniform", "dups", "flat"])
+def test_fps_spatially_pruned_kernel_vs_oracle(dev, N, S, kind):
+    """fps_pruned_kernel (2048 < N <= 28 672, npoint >= 64): points sorted by Morton cell, a wave whose bounding box is farther
+    from the new sample than its largest running distance skips the update.  The skip must be EXACT: bit-equal indices against
+    the oracle on KITTI-shaped clouds (9-23 % duplicate points: equal distances inside one thread take the slow tie path),
+    a uniform cube (no spatial structure to prune on early), a cloud of 50 distinct points repeated (exhaustion: every
+    distance 0, then index 0 forever) and a degenerate flat cloud (zero extent in z, all x equal)."""
+    rng = np.random.default_rng(N + S)
+    B = 2
+    if kind == "kitti":
+        pts, _ = syn.kitti_batch(300 + N % 53, B, N)
+        xyz = np.ascontiguousarray(pts[:, :3].transpose(0, 2, 1))
+    elif kind == "uniform":
+        xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    elif kind == "dups":
+        base = rng.uniform(-1, 1, (B, 50, 3)).astype(np.float32)
+        xyz = np.stack([base[b][rng.integers(0, 50, N)] for b in range(B)])
+    else:
+        xyz = np.zeros((B, N, 3), np.float32)
+        xyz[:, :, 1] = rng.uniform(-3, 5, (B, N))
+        xyz[:, :, 0] = 0.25
+    start = rng.integers(0, N, B)
+    ref = G.farthest_point_sample(xyz, S, start)
+    mine = U.farthest_point_sample(cu(xyz, dev), S, cu(start, dev)).cpu().numpy()
+    assert (mine == ref).all(), (np.argwhere(mine != ref)[:3], kind)

@@ -457,3 +457,88 @@ def test_full_size_batch_permutation_equivariance(dev):
         # conv biases in front of a BatchNorm have a mathematically zero gradient: what is there is rounding noise,
         # measured against the typical gradient norm instead of its own
         assert float((a - b).norm()) <= 2e-2 * float(a.norm()) + 1e-4 * typical, a.shape
+
+
+def _randomise_bn(mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in mod.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+
+
+@pytest.mark.parametrize("tag", ["sa32", "sa16", "sa64", "msg", "all128", "fp", "fp_s1"])
+def test_fused_eval_module_vs_oracle(dev, tag):
+    """pn2_fused_eval (csrc/eval.hip): under .eval() + no_grad a module is ONE launch -- gather, centre, concat, BatchNorm
+    folded into the weights, ReLU, max over the neighbours -- against the oracle module in eval mode (<= 1e-5), and
+    against this package's own layer-by-layer eval kernels."""
+    from oracle import torch_ref as T
+    from pointnet12_amd import synthetic as syn
+    pts = torch.from_numpy(syn.kitti_batch(800, 2, 1024)[0])
+    xyz, feat = pts[:, :3].contiguous(), pts[:, 3:].contiguous()
+    torch.manual_seed(3)
+    if tag.startswith("sa"):
+        K = int(tag[2:])
+        orc, mod = T.RefSetAbstraction(128, 0.3, K, 9, [32, 48, 64], False), U.PointNetSetAbstraction(128, 0.3, K, 9, [32, 48, 64], False)
+        args = (xyz, feat)
+    elif tag == "msg":
+        cfg = (64, [0.2, 0.4, 0.8], [16, 32, 128], 6, [[16, 32], [32, 48, 64], [32, 196]])
+        orc, mod = T.RefSetAbstractionMsg(*cfg), U.PointNetSetAbstractionMsg(*cfg)
+        args = (xyz, feat)
+    elif tag == "all128":
+        orc, mod = T.RefSetAbstraction(None, None, None, 9, [64, 256, 520], True), U.PointNetSetAbstraction(None, None, None, 9, [64, 256, 520], True)
+        args = (xyz[:, :, :128].contiguous(), feat[:, :, :128].contiguous())
+    else:
+        S = 1 if tag == "fp_s1" else 128
+        orc, mod = T.RefFeaturePropagation(6 + 24, [40, 16]), U.PointNetFeaturePropagation(6 + 24, [40, 16])
+        p2 = torch.randn(2, 24, S, generator=torch.Generator().manual_seed(8))
+        x2 = xyz[:, :, :S].contiguous() if S > 1 else torch.zeros(2, 3, 1)
+        args = (xyz, x2, feat, p2)
+    _randomise_bn(orc, 5)
+    mod.load_state_dict(orc.state_dict())
+    mod.to(dev).eval()
+    orc.eval()
+    with torch.no_grad():
+        torch.manual_seed(9)
+        a = orc(*args)
+        torch.manual_seed(9)
+        b = mod(*[t.to(dev) for t in args])
+        calls = []
+        with U._lib.call_profile() as prof:
+            torch.manual_seed(9)
+            mod(*[t.to(dev) for t in args])
+            calls = [c[0] for c in prof]
+        U.FUSED_EVAL = False
+        try:
+            torch.manual_seed(9)
+            c = mod(*[t.to(dev) for t in args])
+        finally:
+            U.FUSED_EVAL = True
+    a, b, c = (x[-1] if isinstance(x, tuple) else x for x in (a, b, c))
+    assert "pn2_fused_eval" in calls and "pn2_conv1x1_fwd" not in calls, calls
+    assert tuple(a.shape) == tuple(b.shape)
+    assert float((a - b.cpu()).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+    assert float((c - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_eval_network_fused_vs_oracle(dev):
+    """PointNet2SemSeg(19, 1) in eval mode on one 8192-point cloud (the viewer-loop shape, pcdvis.py:118-136), fused eval
+    path, against the oracle net in eval mode."""
+    from oracle import torch_ref as T
+    from pointnet12_amd import synthetic as syn
+    torch.manual_seed(2)
+    orc = T.RefSSGSemSeg(19, 1)
+    _randomise_bn(orc, 7)
+    net = M.PointNet2SemSeg(19, 1)
+    net.load_state_dict(orc.state_dict())
+    net.to(dev).eval()
+    orc.eval()
+    pts = torch.from_numpy(syn.kitti_batch(55, 1, 8192, channels=4)[0])
+    with torch.no_grad():
+        torch.manual_seed(4)
+        a = orc(pts)
+        torch.manual_seed(4)
+        b = net(pts.to(dev))
+    assert float((a - b.cpu()).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
