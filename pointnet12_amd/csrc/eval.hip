@@ -107,7 +107,7 @@ __global__ __launch_bounds__(EV_THREADS) void fused_eval_kernel(EvalInput in, Ev
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    dstb[row * LP + col] = col < N ? fmaxf(acc[r] + bc, 0.f) : 0.f;
+                    if (col < ((N + 7) & ~7)) dstb[row * LP + col] = col < N ? fmaxf(acc[r] + bc, 0.f) : 0.f;   // (a row holds round8(N) columns)
                 }
             } else if (pool == 0) {                                // FP / head: rows out
 #pragma unroll

@@ -209,7 +209,9 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
     }
     __syncthreads();
     const float ox = box[0], oy = box[1], oz = box[2];
-    const float sx = 32.0f / fmaxf(box[3] - ox, 1e-20f), sy = 32.0f / fmaxf(box[4] - oy, 1e-20f), sz = 4.0f / fmaxf(box[5] - oz, 1e-20f);
+    // (an axis without extent -- a flat cloud -- gets scale 0: everything in cell 0 of that axis, never 0 * inf)
+    const float sx = box[3] > ox ? 32.0f / (box[3] - ox) : 0.f, sy = box[4] > oy ? 32.0f / (box[4] - oy) : 0.f,
+                sz = box[5] > oz ? 4.0f / (box[5] - oz) : 0.f;
     __syncthreads();                                      // wbox (aliasing perm) is dead
 
     // ---- counting sort by cell: histogram, exclusive scan, fill through LDS cursors
@@ -273,8 +275,15 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
     int rot = 0;
     int far = (int)(start[b] < 0 ? 0 : (start[b] >= N ? N - 1 : start[b]));
     int64_t *o = out + (size_t)b * npoint;
-    unsigned long long wkey = ~0ull;                      // "unknown": forces the first evaluation
-    float wbest = 1e10f;
+    // The candidate a wave offers while it is being skipped must be the one the plain kernel would compute from the same
+    // running distances: initially every point sits at 1e10, i.e. (1e10, lowest original index of the wave); an empty
+    // wave offers nothing, ever.
+    int minidx = 0x7FFFFFFF;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) { const int j = perm[pbase + i * 64]; minidx = (j >= 0 && j < minidx) ? j : minidx; }
+    for (int m = 32; m >= 1; m >>= 1) { const int o2 = __shfl_xor(minidx, m, 64); minidx = o2 < minidx ? o2 : minidx; }
+    unsigned long long wkey = minidx == 0x7FFFFFFF ? 0ull : ((unsigned long long)__float_as_uint(1e10f) << 32) | (0xFFFFFFFFu - (unsigned)minidx);
+    float wbest = minidx == 0x7FFFFFFF ? 0.f : 1e10f;
     for (int it = 0; it < npoint; ++it) {
         if (t == 0) o[it] = far;
         const int f = __builtin_amdgcn_readfirstlane(far);
@@ -733,7 +742,10 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
     // spatially pruned kernel (exact, see fps_pruned_kernel) where a cloud spans at least eight waves and enough samples are
     // drawn to pay for the one-time sort; PN2_FPS_PRUNE=0 keeps the plain kernels (A/B runs)
     static const int prune = [] { const char *e = getenv("PN2_FPS_PRUNE"); return e ? atoi(e) : 1; }();
-    if (prune && N > 2048 && N <= 28672 && npoint >= 64) {
+    // (measured, us per iteration plain -> pruned: N = 4096 0.55 -> 0.85, 8192 0.85 -> 0.92 -- the plain kernel keeps the
+    // cloud in LDS and the winner's coordinates are one broadcast read away, the pruned one fetches them from L2 --
+    // 16 384 1.39 -> 1.07, 20 000 1.62 -> 1.23, 25 000 2.19 -> 1.81.  PN2_FPS_PRUNE=2 forces it from N > 2048 on: tests.)
+    if (prune && N > (prune > 1 ? 2048 : 8192) && N <= 28672 && npoint >= 64) {
         if (N <= 4096) return launch_fps_pruned<512, 8>(xyz, B, N, start, npoint, out_idx, s);
         if (N <= 8192) return launch_fps_pruned<1024, 8>(xyz, B, N, start, npoint, out_idx, s);
         if (N <= 16384) return launch_fps_pruned<1024, 16>(xyz, B, N, start, npoint, out_idx, s);

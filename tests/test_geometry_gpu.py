@@ -1,6 +1,8 @@
 """GPU: HIP geometry kernels (through the C ABI) against golden vectors and the oracle -- bit exact."""
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -240,15 +242,7 @@ def test_invert_index_groups_positions_by_target(dev, B, M, T):
         assert np.array_equal(np.sort(mem), np.nonzero(valid)[0])    # each valid position exactly once
 
 
-@pytest.mark.parametrize("N,S", [(2049, 100), (5000, 700), (8192, 300), (12000, 200), (16384, 128), (20000, 200), (22000, 100),
-                                 (24576, 100), (25000, 300), (26624, 70), (28672, 100)])
-@pytest.mark.parametrize("kind", ["kitti", "uniform", "dups", "flat"])
-def test_fps_spatially_pruned_kernel_vs_oracle(dev, N, S, kind):
-    """fps_pruned_kernel (2048 < N <= 28 672, npoint >= 64): points sorted by Morton cell, a wave whose bounding box is farther
-    from the new sample than its largest running distance skips the update.  The skip must be EXACT: bit-equal indices against
-    the oracle on KITTI-shaped clouds (9-23 % duplicate points: equal distances inside one thread take the slow tie path),
-    a uniform cube (no spatial structure to prune on early), a cloud of 50 distinct points repeated (exhaustion: every
-    distance 0, then index 0 forever) and a degenerate flat cloud (zero extent in z, all x equal)."""
+def _pruned_case(N, S, kind):
     rng = np.random.default_rng(N + S)
     B = 2
     if kind == "kitti":
@@ -263,7 +257,45 @@ def test_fps_spatially_pruned_kernel_vs_oracle(dev, N, S, kind):
         xyz = np.zeros((B, N, 3), np.float32)
         xyz[:, :, 1] = rng.uniform(-3, 5, (B, N))
         xyz[:, :, 0] = 0.25
-    start = rng.integers(0, N, B)
+    return xyz, rng.integers(0, N, B)
+
+
+def test_fps_spatially_pruned_kernel_small_clouds_forced():
+    """The pruned kernel is slower than the plain one up to N = 8192 and not dispatched there; PN2_FPS_PRUNE=2 (read once
+    per process: a child process) forces it, so its 512-thread / 8-points-per-thread instantiations and clouds with EMPTY
+    waves (N far below the capacity) are checked against the oracle too."""
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\n"
+            "import test_geometry_gpu as T\n"
+            "from oracle import geometry as G\n"
+            "from pointnet12_amd import pointnet_util as U\n"
+            "dev = torch.device('cuda:0')\n"
+            "for N, S in [(2049, 100), (5000, 700), (8192, 300), (12000, 200)]:\n"
+            "    for kind in ('kitti', 'uniform', 'dups', 'flat'):\n"
+            "        xyz, start = T._pruned_case(N, S, kind)\n"
+            "        ref = G.farthest_point_sample(xyz, S, start)\n"
+            "        mine = U.farthest_point_sample(T.cu(xyz, dev), S, T.cu(start, dev)).cpu().numpy()\n"
+            "        assert (mine == ref).all(), (N, S, kind, np.argwhere(mine != ref)[:3])\n"
+            "print('PRUNED-SMALL-OK')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, PN2_FPS_PRUNE="2"))
+    assert p.returncode == 0 and "PRUNED-SMALL-OK" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+@pytest.mark.parametrize("N,S", [(8193, 300), (12000, 200), (16384, 128), (20000, 200), (22000, 100),
+                                 (24576, 100), (25000, 300), (26624, 70), (28672, 100)])
+@pytest.mark.parametrize("kind", ["kitti", "uniform", "dups", "flat"])
+def test_fps_spatially_pruned_kernel_vs_oracle(dev, N, S, kind):
+    """fps_pruned_kernel (2048 < N <= 28 672, npoint >= 64): points sorted by Morton cell, a wave whose bounding box is farther
+    from the new sample than its largest running distance skips the update.  The skip must be EXACT: bit-equal indices against
+    the oracle on KITTI-shaped clouds (9-23 % duplicate points: equal distances inside one thread take the slow tie path),
+    a uniform cube (no spatial structure to prune on early), a cloud of 50 distinct points repeated (exhaustion: every
+    distance 0, then index 0 forever) and a degenerate flat cloud (zero extent in z, all x equal)."""
+    xyz, start = _pruned_case(N, S, kind)
     ref = G.farthest_point_sample(xyz, S, start)
     mine = U.farthest_point_sample(cu(xyz, dev), S, cu(start, dev)).cpu().numpy()
     assert (mine == ref).all(), (np.argwhere(mine != ref)[:3], kind)
