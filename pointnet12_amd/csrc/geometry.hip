@@ -170,7 +170,7 @@ __device__ __forceinline__ int fps_cell(float x, float y, float z, float ox, flo
     return (int)((m << 2) | (unsigned)iz);
 }
 
-template <int THREADS, int PPT>
+template <int THREADS, int PPT, bool XYZ_LDS>
 __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__restrict__ xyz, int N,
                                                              const int64_t *__restrict__ start, int npoint,
                                                              int64_t *__restrict__ out) {
@@ -181,6 +181,8 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
     int *wsum = hist + FPS_NC;                           // [NW] + carry
     float *box = reinterpret_cast<float *>(wsum + 32);   // [6] cloud bounding box, then [NW][6] wave boxes at box + 8
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(box + 8 + 6 * NW + 2);   // [3] rotating meeting words
+    float4 *cloud = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(slots + 4) + 15) & ~(uintptr_t)15);   // XYZ_LDS: [N] by ORIGINAL index -- the winner's coordinates are
+                                                             // one broadcast ds_read_b128 away instead of an L2 round trip
 
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float *p = xyz + (size_t)b * N * 3;
@@ -238,8 +240,10 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
     }
     __syncthreads();
     for (int j = t; j < N; j += THREADS) {
-        const int pos = atomicAdd(&hist[fps_cell(p[3 * j], p[3 * j + 1], p[3 * j + 2], ox, oy, oz, sx, sy, sz)], 1);
+        const float x = p[3 * j], y = p[3 * j + 1], z = p[3 * j + 2];
+        const int pos = atomicAdd(&hist[fps_cell(x, y, z, ox, oy, oz, sx, sy, sz)], 1);
         perm[pos] = j;
+        if (XYZ_LDS) cloud[j] = make_float4(x, y, z, 0.f);
     }
     for (int i = N + t; i < CAP; i += THREADS) perm[i] = -1;
     __syncthreads();
@@ -286,8 +290,14 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
     float wbest = minidx == 0x7FFFFFFF ? 0.f : 1e10f;
     for (int it = 0; it < npoint; ++it) {
         if (t == 0) o[it] = far;
-        const int f = __builtin_amdgcn_readfirstlane(far);
-        const float cx = p[3 * f], cy = p[3 * f + 1], cz = p[3 * f + 2];
+        float cx, cy, cz;
+        if (XYZ_LDS) {
+            const float4 c = cloud[far];
+            cx = c.x; cy = c.y; cz = c.z;
+        } else {
+            const int f = __builtin_amdgcn_readfirstlane(far);
+            cx = p[3 * f]; cy = p[3 * f + 1]; cz = p[3 * f + 2];
+        }
         // squared distance from the sample to this wave's box, from below
         const float ex = fmaxf(fmaxf(mybox[0] - cx, cx - mybox[3]), 0.f), ey = fmaxf(fmaxf(mybox[1] - cy, cy - mybox[4]), 0.f),
                     ez = fmaxf(fmaxf(mybox[2] - cz, cz - mybox[5]), 0.f);
@@ -329,15 +339,21 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
 
 template <int THREADS, int PPT>
 int launch_fps_pruned(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, hipStream_t s) {
-    const size_t lds = sizeof(int) * ((size_t)THREADS * PPT + FPS_NC + 32 + 8 + 6 * (THREADS / 64) + 2) + 64;
+    const size_t fixed = sizeof(int) * ((size_t)THREADS * PPT + FPS_NC + 32 + 8 + 6 * (THREADS / 64) + 2) + 64;
+    const bool in_lds = fixed + (size_t)N * 16 <= 160 * 1024;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_pruned_kernel<THREADS, PPT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_pruned_kernel<THREADS, PPT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_pruned_kernel<THREADS, PPT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return PN2_ELAUNCH;
         raised = true;
     }
-    hipLaunchKernelGGL((fps_pruned_kernel<THREADS, PPT>), dim3(B), dim3(THREADS), lds, s, xyz, N, start, npoint, out);
+    if (in_lds)
+        hipLaunchKernelGGL((fps_pruned_kernel<THREADS, PPT, true>), dim3(B), dim3(THREADS), fixed + (size_t)N * 16, s, xyz, N, start, npoint, out);
+    else
+        hipLaunchKernelGGL((fps_pruned_kernel<THREADS, PPT, false>), dim3(B), dim3(THREADS), fixed, s, xyz, N, start, npoint, out);
     return pn2_launch_status();
 }
 
