@@ -24,47 +24,70 @@ namespace {
 constexpr int RES_BM = 64;
 
 // ----------------------------------------------------------------------------------------------- backward plan
-// Per wave: at most one dX tile (row block rb, column block cj) and up to three dW units (co block cb, ci block cj,
-// rows: 0 = rows 0..31 of the tile, 1 = rows 32..63, 2 = all 64).
+// Per wave: at most one dX tile (row block rb, column block cj: C_out / 2 MFMAs) and one dW COLUMN UNIT: all C_out rows
+// of dW for the input-channel block dw_cj, contracted over the row quarters [dw_q0, dw_q1) of the 64-row tile (a quarter =
+// 16 rows = 8 MFMAs per 32 x 32 tile; dW is accumulated with atomics anyway, so splitting its contraction over waves is
+// free).  A column unit covers ALL C_out rows because its tiles are INTERLEAVED, tile e = rows {4 i + e} (C_out = 128;
+// {2 i + e} for 64): one ds_read_b128 of dY[p][4 i .. 4 i + 3] then feeds four MFMAs that share one X operand -- with
+// contiguous 32-row tiles every MFMA of the dW loops waited on two LDS reads of its own (in-kernel stamps: 184 cycles
+// per MFMA in the dW-only waves, which set the length of the compute phase).
+// In quarter-units (8 * C_out/32 MFMAs) a dX tile costs 2, a dW column 4, a tile 8 * CI_T in all: CI_T per wave.
 struct ResPlan {
     signed char dx_rb[8], dx_cj[8];                 // -1: none
-    signed char dw_n[8];
-    signed char dw_cb[8][3], dw_cj[8][3], dw_rows[8][3];
+    signed char dw_cj[8], dw_q0[8], dw_q1[8];       // dw_q0 == dw_q1: none
 };
 
-inline bool make_res_plan(int CO_T, int CI_T, ResPlan *out) {
+inline bool make_res_plan(int CI_T, ResPlan *out) {
     ResPlan p;
-    int load[8];
-    for (int w = 0; w < 8; ++w) { p.dx_rb[w] = p.dx_cj[w] = -1; p.dw_n[w] = 0; load[w] = 0; }
-    if (2 * CI_T > 8) return false;
-    for (int i = 0; i < 2 * CI_T; ++i) { p.dx_rb[i] = (signed char)(i & 1); p.dx_cj[i] = (signed char)(i >> 1); load[i] = 16 * CO_T; }
-    const int target = 8 * CO_T * CI_T;             // MFMAs per wave and tile if perfectly balanced
-    auto least = [&](int skip) {
-        int best = -1;
-        for (int w = 0; w < 8; ++w)
-            if (w != skip && p.dw_n[w] < 3 && (best < 0 || load[w] < load[best])) best = w;
-        return best;
-    };
-    auto give = [&](int w, int cb, int cj, int rows) {
-        const int u = p.dw_n[w]++;
-        p.dw_cb[w][u] = (signed char)cb; p.dw_cj[w][u] = (signed char)cj; p.dw_rows[w][u] = (signed char)rows;
-        load[w] += rows == 2 ? 32 : 16;
-    };
-    for (int cb = 0; cb < CO_T; ++cb)
-        for (int cj = 0; cj < CI_T; ++cj) {
-            const int w = least(-1);
+    int load[8], next_q[4] = {0, 0, 0, 0};
+    for (int w = 0; w < 8; ++w) { p.dx_rb[w] = p.dx_cj[w] = -1; p.dw_cj[w] = 0; p.dw_q0[w] = p.dw_q1[w] = 0; load[w] = 0; }
+    if (CI_T < 1 || CI_T > 4) return false;
+    for (int i = 0; i < 2 * CI_T; ++i) { p.dx_rb[i] = (signed char)(i & 1); p.dx_cj[i] = (signed char)(i >> 1); load[i] = 2; }
+    const int target = CI_T > 2 ? CI_T : 2;          // (CI_T = 1: the two dX tiles alone are 2 units each)
+    // waves without a dX tile first (they take the long runs of one column), then the rest, each wave ONE column
+    for (int pass = 0; pass < 2; ++pass)
+        for (int w = 7; w >= 0; --w) {
+            if ((pass == 0) != (p.dx_rb[w] < 0) || p.dw_q0[w] != p.dw_q1[w]) continue;
+            int cj = -1;
+            for (int c = 0; c < CI_T; ++c)
+                if (next_q[c] < 4 && (cj < 0 || next_q[c] < next_q[cj])) cj = c;      // the column with most quarters left
+            if (cj < 0) break;
+            int take = target - load[w];
+            if (take < 1) continue;
+            if (take > 4 - next_q[cj]) take = 4 - next_q[cj];
+            p.dw_cj[w] = (signed char)cj; p.dw_q0[w] = (signed char)next_q[cj]; p.dw_q1[w] = (signed char)(next_q[cj] + take);
+            next_q[cj] += take;
+            load[w] += take;
+        }
+    // leftovers (imbalanced shapes): hand them to waves that still have no column, least loaded first
+    for (int c = 0; c < CI_T; ++c)
+        while (next_q[c] < 4) {
+            int w = -1;
+            for (int v = 0; v < 8; ++v)
+                if (p.dw_q0[v] == p.dw_q1[v] && (w < 0 || load[v] < load[w])) w = v;
             if (w < 0) return false;
-            if (load[w] + 32 <= target) { give(w, cb, cj, 2); continue; }
-            const int w2 = least(w);
-            if (w2 < 0) { give(w, cb, cj, 2); continue; }
-            give(w, cb, cj, 0);
-            give(w2, cb, cj, 1);
+            p.dw_cj[w] = (signed char)c; p.dw_q0[w] = (signed char)next_q[c]; p.dw_q1[w] = 4;
+            load[w] += 4 - next_q[c];
+            next_q[c] = 4;
         }
     *out = p;
     return true;
 }
 
 extern __shared__ __attribute__((aligned(16))) float res_lds[];
+
+#ifdef PN2_STAMP
+// Diagnostic build only (make STAMP=1): per-phase shader-cycle sums of every wave of the first 64 workgroups of the last
+// resident-kernel launch, read back with pn2_debug_stamps_res().  Never compiled into the shipped library.
+__device__ unsigned long long pn2_res_stamp_buf[64 * 8 * 8];
+#define RSTAMP_DECL unsigned long long rst_t = clock64(), rst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RSTAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = clock64(); rst_acc[i] += n_ - rst_t; rst_t = n_; __builtin_amdgcn_sched_barrier(0); }
+#define RSTAMP_FLUSH(wv) if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) { for (int i_ = 0; i_ < 8; ++i_) pn2_res_stamp_buf[(blockIdx.x * 8 + (wv)) * 8 + i_] = rst_acc[i_]; }
+#else
+#define RSTAMP_DECL
+#define RSTAMP(i)
+#define RSTAMP_FLUSH(wv)
+#endif
 
 __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }   // 32x32 C/D layout
 
@@ -136,22 +159,13 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     for (int i = t; i < 4 * Co; i += 512) tab[i] = dy.coef[i];
 
     // ---- this wave's share of every tile (fixed for the whole launch)
-    const int dx_rb = plan.dx_rb[wave], dx_cj = plan.dx_cj[wave], n_dw = plan.dw_n[wave];
-    int dw_a[3], dw_b[3], dw_h0[3], dw_h1[3];                      // LDS column offsets of the unit, its row halves [h0, h1)
-    float xmu[3], xsc[3], xbe[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const bool on = u < n_dw;
-        const int cb = on ? plan.dw_cb[wave][u] : 0, cj = on ? plan.dw_cj[wave][u] : 0, rows = on ? plan.dw_rows[wave][u] : 0;
-        dw_a[u] = cb * 32 + l31;
-        dw_b[u] = cj * 32 + l31;
-        dw_h0[u] = on ? (rows == 1 ? 1 : 0) : 0;
-        dw_h1[u] = on ? (rows == 0 ? 1 : 2) : 0;
-        xmu[u] = xsc[u] = xbe[u] = 0.f;
-        if (MASKED) {
-            Affine a(aff_p, Ci);
-            xmu[u] = a.mean[dw_b[u]]; xsc[u] = a.scale[dw_b[u]]; xbe[u] = a.beta[dw_b[u]];
-        }
+    const int dx_rb = plan.dx_rb[wave], dx_cj = plan.dx_cj[wave];
+    const int dw_cj = plan.dw_cj[wave], dw_q0 = plan.dw_q0[wave], dw_q1 = plan.dw_q1[wave];
+    const int dw_b = dw_cj * 32 + l31;                             // this lane's input channel in the dW column unit
+    float xmu = 0.f, xsc = 0.f, xbe = 0.f;
+    if (MASKED) {
+        Affine a(aff_p, Ci);
+        xmu = a.mean[dw_b]; xsc = a.scale[dw_b]; xbe = a.beta[dw_b];
     }
     float emu = 0.f, esc = 0.f, ebe = 0.f, eis = 0.f;             // epilogue constants of the dX tile's column
     const int ecol = (dx_cj < 0 ? 0 : dx_cj) * 32 + l31;
@@ -160,9 +174,9 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
         emu = a.mean[ecol]; esc = a.scale[ecol]; ebe = a.beta[ecol]; eis = a.invstd[ecol];
     }
 
-    f32x16 accw[3];
+    f32x16 accw[CO_T];                                             // tile e of the column unit: dW rows {CO_T * i + e}
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < CO_T; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accw[u][r] = 0.f;
     double st0 = 0.0, st1 = 0.0;
@@ -296,39 +310,52 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
 #pragma unroll
             for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(outv[r], sb + (xo + (unsigned)((r & 3) + 8 * (r >> 2)) * xs));
         }
-        // ---- dW units: contraction over the rows of the tile in halves of 16 row pairs (one MFMA per pair): a fixed,
-        // fully unrolled trip count -- with a run-time count the loop stayed rolled and every MFMA waited out its own
-        // two LDS reads
+        // ---- dW column unit: row quarters [q0, q1) of the tile, 8 row pairs each; per pair ONE wide read of dY[p][CO_T i ..]
+        // (the interleaved tiles' A operands) and one of Y_prev[p][ci], then CO_T MFMAs
+        for (int q = dw_q0; q < dw_q1; ++q) {
+            const float *ap = &dYt[(16 * q + lh) * LDY + CO_T * l31];
+            const float *bp = &Yps[(16 * q + lh) * LDP + dw_b];
+            float a[8][CO_T], bb[8];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            if (u < n_dw) {
-                for (int h = dw_h0[u]; h < dw_h1[u]; ++h) {
-                    const float *ap = &dYt[(32 * h + lh) * LDY + dw_a[u]];
-                    const float *bp = &Yps[(32 * h + lh) * LDP + dw_b[u]];
-                    float a[16], b[16];
+            for (int pp = 0; pp < 8; ++pp) {
+                if (CO_T == 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(ap + 2 * pp * LDY);
+                    a[pp][0] = v.x; a[pp][1] = v.y; a[pp][2 % CO_T] = v.z; a[pp][3 % CO_T] = v.w;
+                } else if (CO_T == 2) {
+                    const float2 v = *reinterpret_cast<const float2 *>(ap + 2 * pp * LDY);
+                    a[pp][0] = v.x; a[pp][1 % CO_T] = v.y;
+                } else {
 #pragma unroll
-                    for (int pp = 0; pp < 16; ++pp) { a[pp] = ap[2 * pp * LDY]; b[pp] = bp[2 * pp * LDP]; }
-#pragma unroll
-                    for (int pp = 0; pp < 16; ++pp) {
-                        float bb = b[pp];
-                        if (MASKED) bb = fmaxf(bn_act(bb, xmu[u], xsc[u], xbe[u]), 0.f);
-                        accw[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pp], bb, accw[u], 0, 0, 0);
-                    }
+                    for (int e = 0; e < CO_T; ++e) a[pp][e] = ap[2 * pp * LDY + e];
                 }
+                bb[pp] = bp[2 * pp * LDP];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                float x = bb[pp];
+                if (MASKED) x = fmaxf(bn_act(x, xmu, xsc, xbe), 0.f);
+#pragma unroll
+                for (int e = 0; e < CO_T; ++e) accw[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pp][e], x, accw[e], 0, 0, 0);
             }
         }
     };
 
     int64_t tile = blockIdx.x;
+    RSTAMP_DECL
     if (!DBUF) {
         auto step = [&](Regs &R, int64_t tl) {
             finish_dy(R, dYs, tl);
             write_yp(R);
+            RSTAMP(0)
             fetch_dy(R, tl + DEPTH * (int64_t)G);                  // this set is free again: DEPTH tiles ahead
             fetch_p(R, tl + DEPTH * (int64_t)G);
+            RSTAMP(1)
             __syncthreads();
+            RSTAMP(2)
             compute(dYs, tl);
+            RSTAMP(3)
             __syncthreads();                                       // tile consumed: the next one may land
+            RSTAMP(4)
         };
         fetch_dy(rs[0], tile);
         fetch_p(rs[0], tile);
@@ -376,15 +403,15 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
         }
     }
 
-    // ---- flush: dW partial tiles (256 contiguous bytes per wave-instruction), the dX column's two reductions
+    RSTAMP_FLUSH(wave)
+    // ---- flush: dW partial tiles (tile e holds the rows {CO_T i + e}: 128 contiguous bytes per half-wave), the dX column's
+    // two reductions
+    if (dw_q0 < dw_q1) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        if (u < n_dw) {
-            const int cb32 = dw_a[u] - l31;
+        for (int e = 0; e < CO_T; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                atomicAdd(dW + (int64_t)(cb32 + acc_row(r, lh)) * lddw + dw_b[u], accw[u][r]);
-        }
+                atomicAdd(dW + (int64_t)(CO_T * acc_row(r, lh) + e) * lddw + dw_b, accw[e][r]);
     }
     if (MASKED && red_p != nullptr && dx_rb >= 0) {
         st0 += __shfl_xor(st0, 32, 64);
@@ -425,7 +452,7 @@ template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF>
 int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
                         double *red_p, float *dW, int lddw, hipStream_t s) {
     ResPlan plan;
-    if (!make_res_plan(CO_T, CI_T, &plan)) return PN2_EINVAL;
+    if (!make_res_plan(CI_T, &plan)) return PN2_EINVAL;
     const size_t lds = bwd_res_lds_bytes(32 * CO_T, 32 * CI_T, DBUF);
     static bool raised = false;
     if (!raised) {
@@ -515,7 +542,9 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
     for (int j = 0; j < N_T; ++j) st[j][0] = st[j][1] = 0.0;
     __syncthreads();                                               // W image and table complete (the only barrier before the end)
 
+    RSTAMP_DECL
     for (; slab < slabs; slab += stride) {
+        RSTAMP(4)
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             float4 x = rx[i];
@@ -531,7 +560,9 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
             }
             *reinterpret_cast<float4 *>(&Ab[ol[i]]) = x;
         }
+        RSTAMP(0)
         fetch(slab + stride);
+        RSTAMP(1)
 
         f32x16 acc[N_T];
 #pragma unroll
@@ -552,6 +583,7 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
             }
         }
+        RSTAMP(2)
         // ---- epilogue, one 32-column block at a time: bias + statistics straight from the accumulators (column on the
         // lane), then through this wave's staging buffer (free: every MFMA of the slab has read it) so that Y leaves as
         // 16-byte stores, 128 contiguous bytes per row -- 16 store instructions per slab instead of 64, straight-line:
@@ -581,6 +613,8 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
         }
     }
 
+    RSTAMP(3)
+    RSTAMP_FLUSH(wave)
     if (stats != nullptr) {                                        // fold the waves in LDS (the W image is dead), one atomic per channel
         __syncthreads();
         double *red = reinterpret_cast<double *>(res_lds);        // [NW][N][2]
@@ -667,6 +701,13 @@ inline int res_min_rows() {
 static bool res_shape_ok(int C_out, int C_in) {
     return C_out % 32 == 0 && C_in % 32 == 0 && C_out >= 32 && C_out <= 128 && C_in >= 32 && C_in <= 128;
 }
+
+#ifdef PN2_STAMP
+extern "C" int pn2_debug_stamps_res(unsigned long long *host_out, int n) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pn2_res_stamp_buf), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int pn2_res_supported(int64_t P, int C_out, int C_in) {
     static const int on = [] { const char *e = getenv("PN2_RES"); return e ? atoi(e) : 1; }();

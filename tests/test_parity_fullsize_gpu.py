@@ -171,16 +171,13 @@ def test_cfg5_single_cloud_vs_oracle(dev):
     for kind, scale in (("ssg", 1), ("msg", 16)):
         net, orc = _nets(kind, dev, npoint_scale=scale)
         o32 = _run_oracle(orc, pts, labels, torch.float32)
-        o64 = _run_oracle(orc, pts, labels, torch.float64) if kind == "ssg" else None
+        o64 = _run_oracle(orc, pts, labels, torch.float64)
         hip = _run_hip(net, pts, labels, dev)
         r = _compare("cfg5_%s_B1x65536" % kind, hip, o32, o64)
         assert r["hip_vs_orc32_max"] <= REL_CAP * max(1.0, r["log_probs_absmax"]), r
-        if o64 is not None:
-            assert r["hip_vs_fp64_rms"] <= FACTOR * r["orc32_vs_fp64_rms"], r
-            assert r["hip_vs_fp64_max"] <= FACTOR * r["orc32_vs_fp64_max"], r
-        else:
-            assert r["hip_vs_orc32_rms"] <= 2e-5, r
-            assert r["grad_norm_hip_vs_orc32_worst"] <= 2e-2, r
+        assert r["hip_vs_fp64_rms"] <= FACTOR * r["orc32_vs_fp64_rms"], r
+        assert r["hip_vs_fp64_max"] <= FACTOR * r["orc32_vs_fp64_max"], r
+        assert r["grad_l2_hip_vs_fp64_median"] <= GRAD_FACTOR * r["grad_l2_orc32_vs_fp64_median"], r
         del net, orc, hip, o32, o64
         torch.cuda.empty_cache()
 
