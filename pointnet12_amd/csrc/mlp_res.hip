@@ -405,7 +405,8 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
 
     RSTAMP_FLUSH(wave)
     // ---- flush: dW partial tiles (tile e holds the rows {CO_T i + e}: 128 contiguous bytes per half-wave), the dX column's
-    // two reductions
+    // two reductions.  (Summing the waves' partials in LDS first and adding one block per workgroup was measured SLOWER:
+    // 128x128 at 65 536 rows 84 -> 106 us.)
     if (dw_q0 < dw_q1) {
 #pragma unroll
         for (int e = 0; e < CO_T; ++e)
@@ -476,12 +477,16 @@ int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, 
     if (Co == CO && Ci == CI)                                                                                              \
         return launch_bwd_res<CO / 32, CI / 32, POOL, MASKED>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
 
+// Every workgroup ends with C_out x C_in atomic adds (x the waves sharing a column): a launch must give a workgroup enough
+// tiles to pay for them.  128 x 128 (dense: FP stacks, heads, sa2 of MSG at 65 k .. 131 k rows) only ties the streamed pair
+// there (70 vs 71 us, 111 vs 123 us): taken from 262 144 rows on (the dense scans of cfg5).
 int dispatch_bwd_res(int Kpool, bool masked, int Co, int Ci, ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W,
                      int ldw, int64_t tiles, float *dX, int ldxo, double *red_p, float *dW, int lddw, hipStream_t s) {
     if (Kpool == 0 && masked) {
-        PN2_RES_CASE(32, 32, 0, true) PN2_RES_CASE(64, 64, 0, true) PN2_RES_CASE(96, 64, 0, true) PN2_RES_CASE(128, 128, 0, true)
+        PN2_RES_CASE(32, 32, 0, true) PN2_RES_CASE(64, 64, 0, true) PN2_RES_CASE(96, 64, 0, true)
+        if (tiles >= 4096) { PN2_RES_CASE(128, 128, 0, true) }
     } else if (Kpool == 0) {
-        PN2_RES_CASE(128, 128, 0, false)
+        if (tiles >= 4096) { PN2_RES_CASE(128, 128, 0, false) }
     } else if (masked && Kpool % 64 == 0) {
         PN2_RES_CASE(128, 64, 1, true) PN2_RES_CASE(128, 96, 1, true)
     } else if (masked && Kpool == 32) {
