@@ -427,19 +427,20 @@ def main():
         # HBM traffic of that kernel family from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes), per launch.
         # The file carries the digest of the kernel sources it was collected with: a stale file is not quoted.
-        fam = {"pn2_conv1x1_wgrad": "gemm_tn_kernel", "pn2_conv1x1_fwd": "gemm_nt_kernel<fwd>",
-               "pn2_conv1x1_dgrad": "gemm_nt_kernel<dgrad>", "pn2_conv1x1_bwd": "gemm_bwd_fused_kernel"}.get(top)
+        fams = {"pn2_conv1x1_wgrad": ["gemm_tn_kernel", "wgrad_skinny_kernel"], "pn2_conv1x1_fwd": ["gemm_nt_kernel<fwd>", "fwd_res_kernel"],
+                "pn2_conv1x1_dgrad": ["gemm_nt_kernel<dgrad>"], "pn2_conv1x1_bwd": ["gemm_bwd_fused_kernel"]}.get(top)
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)))
-        if fam and cands:
+        if fams and cands:
             pmc_path = cands[-1]
             doc = json.load(open(pmc_path))
-            pmc = doc.get("families", {}).get(fam)
-            if pmc and doc.get("csrc_sha256") == csrc_digest():
-                roofline["traffic"] = round(pmc["hbm_bytes_per_step"] / pmc["launches_per_step"])
-                roofline["traffic_note"] = "bytes per launch, PMC (profiles/%s); algorithmic bytes per launch %d" % (
-                    os.path.basename(pmc_path), round(v[3] / v[1]))
-            elif pmc:
+            hit = [doc.get("families", {}).get(f) for f in fams]
+            hit = [h for h in hit if h]
+            if hit and doc.get("csrc_sha256") == csrc_digest():
+                roofline["traffic"] = round(sum(h["hbm_bytes_per_step"] for h in hit) / sum(h["launches_per_step"] for h in hit))
+                roofline["traffic_note"] = "HBM bytes per launch, PMC (profiles/%s, kernel families %s); algorithmic bytes per launch %d" % (
+                    os.path.basename(pmc_path), " + ".join(fams), round(v[3] / v[1]))
+            elif hit:
                 roofline["traffic_note"] = "profiles/%s was collected with other kernel sources (digest differs): not quoted" % (
                     os.path.basename(pmc_path))
         roofline["avg_launch_us"] = round(v[0] / v[1] * 1e3, 2)

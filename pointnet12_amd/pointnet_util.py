@@ -140,7 +140,10 @@ class _GatherRows(torch.autograd.Function):
         err = torch.zeros(1, device=points.device, dtype=torch.int32) if checked else None
         _check(_lib.load().pn2_gather_rows(_p(points), _p(idx), B, N, C, M, _p(out), _p(err), _lib.stream()),
                "pn2_gather_rows")
-        if checked and int(err.item()) != 0:
+        # the reference's advanced indexing raises on the host; here that costs one device->host read, which a stream
+        # capture cannot contain: under capture the check is skipped (the kernel clamps nothing -- callers that capture
+        # pass indices they produced themselves: FPS / ball query / 3-NN outputs are in range by construction)
+        if checked and not torch.cuda.is_current_stream_capturing() and int(err.item()) != 0:
             raise IndexError("index out of range in index_points")     # as the reference's advanced indexing
         ctx.save_for_backward(idx)
         ctx.shape = (B, N, C, M)
