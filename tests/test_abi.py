@@ -45,3 +45,36 @@ def test_cpu_tensors_are_refused():
     from pointnet12_amd import pointnet_util as U
     with pytest.raises(_lib.Pn2Error):
         U.farthest_point_sample(torch.zeros(1, 8, 3), 2)
+
+
+def test_host_build_exports_the_geometry_symbols_and_matches_golden():
+    """the same pn2_* symbols in a host (CPU) build of the restatement (oracle/pn2_host.c -> libpn2_host.so).
+    Driven through the SAME ctypes signatures as the HIP library (host pointers), it reproduces the reference's golden
+    FPS / ball-query indices and distance bits."""
+    import numpy as np
+    from conftest import golden
+    from oracle import geometry as G
+    G.build()
+    host = ctypes.CDLL(os.path.join(ROOT, "oracle", "libpn2_host.so"))
+    for name in ("pn2_version", "pn2_fps_workspace_bytes", "pn2_fps", "pn2_ball_query", "pn2_square_distance", "pn2_three_nn",
+                 "pn2_gather_rows", "pn2_group", "pn2_three_interp"):
+        fn = getattr(host, name)
+        fn.restype, fn.argtypes = _lib.SIGNATURES[name]
+    assert host.pn2_version() == _lib.ABI_VERSION
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    g = golden("g1_fps.npz")
+    xyz, start, ref = g["kitti1024/xyz"], g["kitti1024/start"], g["kitti1024/idx"]
+    out = np.empty(ref.shape, np.int64)
+    assert host.pn2_fps(p(np.ascontiguousarray(xyz)), xyz.shape[0], xyz.shape[1], p(np.ascontiguousarray(start)), ref.shape[1], p(out),
+                        None, None) == 0
+    assert (out == ref).all()
+    g2 = golden("g2_ball.npz")
+    bx, bn, bref = np.ascontiguousarray(g2["kitti/xyz"]), np.ascontiguousarray(g2["kitti/new_xyz"]), g2["kitti/r0.2_k32"]
+    bout = np.empty(bref.shape, np.int64)
+    assert host.pn2_ball_query(p(bx), p(bn), bx.shape[0], bx.shape[1], bn.shape[1], float(np.float32(0.2 ** 2)), 32, p(bout), None) == 0
+    assert (bout == bref).all()
+    g3 = golden("g3_sqdist.npz")
+    d = np.empty((1, g3["new_xyz"].shape[1], g3["xyz"].shape[1]), np.float32)
+    assert host.pn2_square_distance(p(np.ascontiguousarray(g3["new_xyz"])), p(np.ascontiguousarray(g3["xyz"])), 1, d.shape[1], d.shape[2],
+                                    p(d), None) == 0
+    assert (d.view(np.uint32)[0, ::16, :] == g3["sample_bits"]).all()
