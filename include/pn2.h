@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 4
+#define PN2_ABI_VERSION 5
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -184,6 +184,23 @@ int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float
 int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, const float *beta, float eps,
                     float momentum, int training, float *running_mean, float *running_var,
                     int64_t *num_batches_tracked, float *affine, pn2_stream_t stream);
+
+/* pn2_conv1x1_fwd for the LAST layer of a pooled shared MLP in training mode (model/pointnet_util.py:194-199 / :251-256: the
+ * conv whose BN + ReLU output is max-reduced over the Kpool rows of a group), weight-resident kernel only: besides Y and the
+ * statistics it records, per group and channel, the extreme pre-BN value -- the largest, or the smallest where gamma (this
+ * layer's BatchNorm weight, float[C_out]) is negative -- and the first row attaining it into pool_ws (16-byte aligned
+ * float[2 * (P / Kpool) * C_out]: {value, row as int32} pairs).  BN + ReLU is monotone per channel with the sign of gamma,
+ * so pn2_bn_pool_select turns these into max_k relu(bn(y_k)) exactly once the affine block exists, and the pass over Y of
+ * pn2_bn_relu_max is not needed.  Returns PN2_EUNSUPPORTED (nothing launched) when the shape is outside the resident kernels
+ * (see pn2_res_supported; also needs P % 32 == 0, Kpool == 16 or Kpool % 32 == 0): call pn2_conv1x1_fwd + pn2_bn_relu_max
+ * then. */
+int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
+                         int ldy, int64_t P, int K, int N, double *stats, int Kpool, const float *gamma, float *pool_ws,
+                         pn2_stream_t stream);
+/* out[g,c] = relu(bn(v)) of the recorded extreme value, arg[g,c] = its row (same outputs as pn2_bn_relu_max up to which of
+ * several rows with EQUAL post-BN value is named).  C % 32 == 0, ldo == C. */
+int pn2_bn_pool_select(const float *pool_ws, const float *affine, int64_t G, int C, float *out, int ldo, int32_t *arg,
+                       pn2_stream_t stream);
 
 /* out[g,c] = max_k relu(bn(Y[g*K+k, c])), arg[g,c] = first k attaining it (K = 1: plain
  * BN+ReLU, arg may be NULL).  Y pitch ldy, out / arg pitch ldo: both multiples of 4 and >= round4(C)

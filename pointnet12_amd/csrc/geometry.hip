@@ -768,8 +768,9 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
         if (N <= 20480) return launch_fps_pruned<1024, 20>(xyz, B, N, start, npoint, out_idx, s);
         if (N <= 22528) return launch_fps_pruned<1024, 22>(xyz, B, N, start, npoint, out_idx, s);
         if (N <= 24576) return launch_fps_pruned<1024, 24>(xyz, B, N, start, npoint, out_idx, s);
-        if (N <= 26624) return launch_fps_pruned<1024, 26>(xyz, B, N, start, npoint, out_idx, s);   // (26: no spills; 28 keeps 33
-        return launch_fps_pruned<1024, 28>(xyz, B, N, start, npoint, out_idx, s);                   //  coordinate words in scratch)
+        if (N <= 25600) return launch_fps_pruned<1024, 25>(xyz, B, N, start, npoint, out_idx, s);
+        if (N <= 26624) return launch_fps_pruned<1024, 26>(xyz, B, N, start, npoint, out_idx, s);   // (from 24 points per thread on the
+        return launch_fps_pruned<1024, 28>(xyz, B, N, start, npoint, out_idx, s);                   //  compiler keeps 24-72 words in scratch)
     }
     if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, start, npoint, out_idx, s);

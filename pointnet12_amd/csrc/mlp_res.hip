@@ -499,10 +499,27 @@ int dispatch_bwd_res(int Kpool, bool masked, int Co, int Ci, ResDy dy, const flo
 // Every wave owns 32-row slabs: global -> registers (in flight under the previous slab's MFMAs) -> BN + ReLU -> its private
 // LDS buffer [32][K+4] -> MFMA against the shared W image [N][K+4] -> bias, store, statistics straight from the
 // accumulators.  ACT: X = relu(bn(X_raw)) with the affine block `aff` (hidden layers) or X as stored.
-template <int K_T, int N_T, bool ACT>
+//
+// POOL: the layer feeds a max over groups of Kp consecutive rows (the last layer of a set-abstraction MLP).  BatchNorm + ReLU
+// is monotone in y per channel -- non-decreasing where the folded scale gamma * invstd is >= 0, non-increasing where it is
+// negative, and its sign is the sign of gamma, a PARAMETER known before the statistics are -- so
+// max_k relu(bn(y_k)) = relu(bn(max_k y_k)) resp. relu(bn(min_k y_k)) EXACTLY.  The statistics the affine map needs are only
+// complete when this launch ends: the epilogue therefore records, per group and channel, the extreme y (the largest, or the
+// smallest where gamma < 0: the largest of y with its sign bit flipped) with the first row attaining it, and
+// pn2_bn_pool_select applies BN + ReLU to it once the affine block exists.  The pass that re-read all of Y to pool it
+// (pn2_bn_relu_max: 0.54 GB at 1 M x 128) disappears.  A wave then owns whole groups: Kp / 32 consecutive slabs (Kp = 16: two
+// groups per slab), the running extremum stays in its registers.
+struct ResPool {
+    float2 *rec;              // [G][ldp] records {extreme y, its row (int bits)}
+    const float *gamma;       // BatchNorm weight of this layer: its sign picks maximum or minimum
+    int ldp, U;               // U = slabs per group (Kp / 32; 1 for Kp = 16: two groups per slab)
+};
+
+template <int K_T, int N_T, bool ACT, int POOL>      // POOL: 0 none, 1 groups of whole slabs (Kp % 32 == 0), 2 Kp == 16
 __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ aff,
                                                          const float *__restrict__ W, int ldw, const float *__restrict__ bias,
-                                                         float *__restrict__ Y, int ldy, int64_t slabs, double *__restrict__ stats) {
+                                                         float *__restrict__ Y, int ldy, int64_t slabs, double *__restrict__ stats,
+                                                         ResPool pool) {
     constexpr int K = 32 * K_T, N = 32 * N_T, LDA = K + 4, QK = K / 4, IT = 32 * QK / 64;
     const int NW = blockDim.x >> 6;
     float *Ws = res_lds;                                           // [N][LDA]
@@ -526,35 +543,56 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
 
     // whole 32-row slabs only (the host hands a ragged tail to the streamed kernel): a per-slab uniform base plus
     // loop-invariant 32-bit lane offsets, no row predicates
-    unsigned ox[IT], ol[IT];
+    // (the pooling variants are short of registers at 96+ input channels: they recompute the offsets per use -- a division by a
+    // constant and a multiply-add each -- instead of holding 2 * IT of them)
+    constexpr bool OFFS_LIVE = POOL == 0;
+    unsigned ox[OFFS_LIVE ? IT : 1], ol[OFFS_LIVE ? IT : 1];
+    int lane_op = lane;           // made opaque once per slab where the offsets are recomputed: loop-invariant code motion would
+                                  // put all 2 * IT of them straight back into registers
+    auto off_x = [&](int i) { const int idx = lane_op + 64 * i, row = idx / QK, q = idx - row * QK; return (unsigned)row * (unsigned)ldx + 4u * q; };
+    auto off_l = [&](int i) { const int idx = lane_op + 64 * i, row = idx / QK, q = idx - row * QK; return (unsigned)(row * LDA + 4 * q); };
+    if (OFFS_LIVE) {
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int idx = lane + 64 * i, row = idx / QK, q = idx - row * QK;
-        ox[i] = (unsigned)row * (unsigned)ldx + 4u * q;
-        ol[i] = (unsigned)(row * LDA + 4 * q);
+        for (int i = 0; i < IT; ++i) { ox[OFFS_LIVE ? i : 0] = off_x(i); ol[OFFS_LIVE ? i : 0] = off_l(i); }
     }
     const int64_t stride = (int64_t)gridDim.x * NW;
     float4 rx[IT];
     auto fetch = [&](int64_t slab) {
         const float *xb = X + (slab < slabs ? slab : slabs - 1) * (int64_t)(32 * ldx);
 #pragma unroll
-        for (int i = 0; i < IT; ++i) rx[i] = ld4(xb + ox[i]);
+        for (int i = 0; i < IT; ++i) rx[i] = ld4(xb + (OFFS_LIVE ? ox[OFFS_LIVE ? i : 0] : off_x(i)));
     };
-    int64_t slab = (int64_t)blockIdx.x * NW + wave;
+    // a wave's work items are units of U consecutive slabs (U = 1 without pooling: plain interleaving)
+    const int U = POOL ? pool.U : 1;
+    int64_t unit = (int64_t)blockIdx.x * NW + wave;
+    int sub = 0;
+    int64_t slab = unit * U;
     fetch(slab);
     double st[N_T][2];
 #pragma unroll
     for (int j = 0; j < N_T; ++j) st[j][0] = st[j][1] = 0.0;
+    float vmx[POOL ? N_T : 1];                                     // POOL: the group's running extremum (sign-flipped where gamma < 0)
+    int kmx[POOL ? N_T : 1], sgn[POOL ? N_T : 1];                  // its row; the per-column sign mask
+    if (POOL) {
+#pragma unroll
+        for (int j = 0; j < N_T; ++j) sgn[POOL ? j : 0] = pool.gamma[32 * j + l31] < 0.f ? (int)0x80000000 : 0;
+    }
     __syncthreads();                                               // W image and table complete (the only barrier before the end)
 
     RSTAMP_DECL
-    for (; slab < slabs; slab += stride) {
+    while (slab < slabs) {
         RSTAMP(4)
+        if (!OFFS_LIVE) asm volatile("" : "+v"(lane_op));
+        int64_t next_unit = unit;
+        int next_sub = sub + 1;
+        if (next_sub == U) { next_sub = 0; next_unit += stride; }
+        const int64_t next_slab = next_unit * U + next_sub;
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             float4 x = rx[i];
+            const unsigned oli = OFFS_LIVE ? ol[OFFS_LIVE ? i : 0] : off_l(i);
             if (ACT) {
-                const int q4 = (int)(ol[i] % (unsigned)LDA);
+                const int q4 = (int)(oli % (unsigned)LDA);
                 const float4 mu = *reinterpret_cast<const float4 *>(&atab[q4]);
                 const float4 sc = *reinterpret_cast<const float4 *>(&atab[K + q4]);
                 const float4 be = *reinterpret_cast<const float4 *>(&atab[2 * K + q4]);
@@ -563,10 +601,10 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
                 x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
                 x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
             }
-            *reinterpret_cast<float4 *>(&Ab[ol[i]]) = x;
+            *reinterpret_cast<float4 *>(&Ab[oli]) = x;
         }
         RSTAMP(0)
-        fetch(slab + stride);
+        fetch(next_slab);
         RSTAMP(1)
 
         f32x16 acc[N_T];
@@ -599,15 +637,57 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
 #pragma unroll
         for (int j = 0; j < N_T; ++j) {
             float s0 = 0.f, s1 = 0.f;
+            // this slab's extremum over the lane's rows: (value, accumulator register), ascending register = ascending row,
+            // strict comparisons keep the first; registers 0..7 are rows 0..15, 8..15 rows 16..31 (two groups when Kp = 16)
+            float ma = -INFINITY, mb = -INFINITY;
+            int mai = 0, mbi = 8;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float y = acc[j][r] + bj[j];
                 Ab[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + l31] = y;
                 s0 += y;
                 s1 = __builtin_fmaf(y, y, s1);
+                if (POOL) {
+                    const float yp = __int_as_float(__float_as_int(y) ^ sgn[POOL ? j : 0]);
+                    if (POOL == 1 || r < 8) { mai = yp > ma ? r : mai; ma = fmaxf(ma, yp); }
+                    else { mbi = yp > mb ? r : mbi; mb = fmaxf(mb, yp); }
+                }
             }
             st[j][0] += (double)s0;
             st[j][1] += (double)s1;
+            if (POOL) {
+                auto rowof = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lh; };          // row of the slab
+                auto meet = [&](float &v, int &k) {                                            // the two half-waves hold disjoint rows
+                    const float ov = __shfl_xor(v, 32, 64);
+                    const int ok = __shfl_xor(k, 32, 64);
+                    const bool take = ov > v || (ov == v && ok < k);
+                    v = take ? ov : v; k = take ? ok : k;
+                };
+                // The records leave through UNCONDITIONAL 8-byte stores, the same number every slab, from a wave-uniform base
+                // plus a lane offset (a slab that does not finish a group aims at this wave's dump line; the second half-wave
+                // holds a copy after the meeting and writes it too): stores under a branch would make the next slab's operand
+                // wait uncountable, i.e. vmcnt(0) behind every store acknowledgement.
+                float2 *dump = reinterpret_cast<float2 *>(pn2_dump_lines + ((blockIdx.x & 1023) * 8 + (wave & 7)) * 64);
+                const int sg = sgn[POOL ? j : 0];
+                if (POOL == 2) {                                    // Kp = 16: groups 2 * slab and 2 * slab + 1 are complete
+                    int ka = rowof(mai), kb = rowof(mbi) - 16;
+                    meet(ma, ka); meet(mb, kb);
+                    float2 *base = pool.rec + (2 * slab) * (int64_t)pool.ldp;
+                    base[32 * j + l31] = make_float2(__int_as_float(__float_as_int(ma) ^ sg), __int_as_float(ka));
+                    base[pool.ldp + 32 * j + l31] = make_float2(__int_as_float(__float_as_int(mb) ^ sg), __int_as_float(kb));
+                } else {
+                    // into the group's running extremum (earlier slabs first: ties keep them)
+                    const int mk = 32 * sub + rowof(mai);
+                    const bool t1 = sub == 0 || ma > vmx[j];
+                    vmx[j] = t1 ? ma : vmx[j]; kmx[j] = t1 ? mk : kmx[j];
+                    float v1 = vmx[j];
+                    int k1 = kmx[j];
+                    const bool last = sub == U - 1;                 // wave-uniform
+                    if (last) meet(v1, k1);
+                    float2 *base = last ? pool.rec + unit * (int64_t)pool.ldp : dump;
+                    base[last ? 32 * j + l31 : l31] = make_float2(__int_as_float(__float_as_int(v1) ^ sg), __int_as_float(k1));
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 v = *reinterpret_cast<const float4 *>(&Ab[((lane >> 3) + 8 * i) * 36 + (lane & 7) * 4]);
@@ -615,7 +695,9 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
                 const v4f vv = {v.x, v.y, v.z, v.w};
                 __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(yb + (yo + (unsigned)(8 * i) * (unsigned)ldy + 32u * j)));
             }
+            if (POOL) __builtin_amdgcn_sched_barrier(0);           // one column block at a time: the scans' temporaries do not pile up
         }
+        unit = next_unit; sub = next_sub; slab = next_slab;
     }
 
     RSTAMP(3)
@@ -644,9 +726,9 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
     }
 }
 
-template <int K_T, int N_T, bool ACT>
+template <int K_T, int N_T, bool ACT, int POOL>
 int launch_fwd_res(const float *X, int ldx, const float *aff, const float *W, int ldw, const float *bias, float *Y, int ldy,
-                   int64_t P, double *stats, hipStream_t s) {
+                   int64_t P, double *stats, const ResPool &pool, hipStream_t s) {
     constexpr int K = 32 * K_T, N = 32 * N_T, LDA = K + 4;
     const size_t fixed = sizeof(float) * ((size_t)N * LDA + 3 * K), per_wave = sizeof(float) * 32 * LDA;
     int nw = (int)((160 * 1024 - fixed) / per_wave);
@@ -657,39 +739,39 @@ int launch_fwd_res(const float *X, int ldx, const float *aff, const float *W, in
     if (lds < red) lds = red;
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_res_kernel<K_T, N_T, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_res_kernel<K_T, N_T, ACT, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return PN2_ELAUNCH;
         raised = true;
     }
     const int64_t slabs = P / 32;                                  // whole slabs; the caller handles P % 32
-    int64_t grid = pn2_cdiv(slabs, nw);
+    int64_t grid = pn2_cdiv(slabs / (POOL ? pool.U : 1), nw);
     if (grid > pn2_num_cus()) grid = pn2_num_cus();
-    hipLaunchKernelGGL((fwd_res_kernel<K_T, N_T, ACT>), dim3((unsigned)grid), dim3(64 * nw), lds, s, X, ldx, aff, W, ldw, bias, Y, ldy, slabs,
-                       stats);
+    hipLaunchKernelGGL((fwd_res_kernel<K_T, N_T, ACT, POOL>), dim3((unsigned)grid), dim3(64 * nw), lds, s, X, ldx, aff, W, ldw, bias, Y, ldy,
+                       slabs, stats, pool);
     return pn2_launch_status();
 }
 
-template <int K_T, bool ACT>
+template <int K_T, bool ACT, int POOL>
 int dispatch_fwd_res_n(int N, const float *X, int ldx, const float *aff, const float *W, int ldw, const float *bias, float *Y, int ldy,
-                       int64_t P, double *stats, hipStream_t s) {
+                       int64_t P, double *stats, const ResPool &pool, hipStream_t s) {
     switch (N / 32) {
-        case 1: return launch_fwd_res<K_T, 1, ACT>(X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, s);
-        case 2: return launch_fwd_res<K_T, 2, ACT>(X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, s);
-        case 3: return launch_fwd_res<K_T, 3, ACT>(X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, s);
-        case 4: return launch_fwd_res<K_T, 4, ACT>(X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, s);
+        case 1: return launch_fwd_res<K_T, 1, ACT, POOL>(X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, pool, s);
+        case 2: return launch_fwd_res<K_T, 2, ACT, POOL>(X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, pool, s);
+        case 3: return launch_fwd_res<K_T, 3, ACT, POOL>(X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, pool, s);
+        case 4: return launch_fwd_res<K_T, 4, ACT, POOL>(X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, pool, s);
     }
     return PN2_EINVAL;
 }
 
-template <bool ACT>
+template <bool ACT, int POOL>
 int dispatch_fwd_res(int K, int N, const float *X, int ldx, const float *aff, const float *W, int ldw, const float *bias, float *Y,
-                     int ldy, int64_t P, double *stats, hipStream_t s) {
+                     int ldy, int64_t P, double *stats, const ResPool &pool, hipStream_t s) {
     switch (K / 32) {
-        case 1: return dispatch_fwd_res_n<1, ACT>(N, X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, s);
-        case 2: return dispatch_fwd_res_n<2, ACT>(N, X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, s);
-        case 3: return dispatch_fwd_res_n<3, ACT>(N, X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, s);
-        case 4: return dispatch_fwd_res_n<4, ACT>(N, X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, s);
+        case 1: return dispatch_fwd_res_n<1, ACT, POOL>(N, X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, pool, s);
+        case 2: return dispatch_fwd_res_n<2, ACT, POOL>(N, X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, pool, s);
+        case 3: return dispatch_fwd_res_n<3, ACT, POOL>(N, X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, pool, s);
+        case 4: return dispatch_fwd_res_n<4, ACT, POOL>(N, X, ldx, aff, W, ldw, bias, Y, ldy, P, stats, pool, s);
     }
     return PN2_EINVAL;
 }
@@ -722,8 +804,57 @@ extern "C" int pn2_res_supported(int64_t P, int C_out, int C_in) {
 // Called by pn2_conv1x1_fwd (mlp.hip) for supported shapes when no fused BatchNorm tail is requested; P % 32 == 0.
 int pn2_fwd_res(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
                 int64_t P, int K, int N, double *stats, hipStream_t s) {
-    if (in_affine) return dispatch_fwd_res<true>(K, N, X, ldx, in_affine, W, ldw, bias, Y, ldy, P, stats, s);
-    return dispatch_fwd_res<false>(K, N, X, ldx, nullptr, W, ldw, bias, Y, ldy, P, stats, s);
+    const ResPool none{};
+    if (in_affine) return dispatch_fwd_res<true, 0>(K, N, X, ldx, in_affine, W, ldw, bias, Y, ldy, P, stats, none, s);
+    return dispatch_fwd_res<false, 0>(K, N, X, ldx, nullptr, W, ldw, bias, Y, ldy, P, stats, none, s);
+}
+
+namespace {
+// out[g,c] = relu(bn(v)) with v the recorded maximum where the folded scale is >= 0 and the minimum where it is negative; arg
+// = the row that attained it.  Pad columns (c >= C) get the zero pad of the affine block like pn2_bn_relu_max writes them.
+__global__ __launch_bounds__(256) void bn_pool_select_kernel(const float2 *__restrict__ rec, int ldp, const float *__restrict__ aff, int lda,
+                                                             int64_t G, int C, float *__restrict__ out, int ldo, int32_t *__restrict__ arg) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int qpr = C >> 2;
+    if (i >= G * qpr) return;
+    const int64_t g = i / qpr;
+    const int c = (int)(i - g * qpr) * 4;
+    Affine a(aff, lda);
+    const float4 mu = ld4(a.mean + c), sc = ld4(a.scale + c), be = ld4(a.beta + c);
+    const float4 r01 = ld4(reinterpret_cast<const float *>(rec + g * ldp + c)), r23 = ld4(reinterpret_cast<const float *>(rec + g * ldp + c + 2));
+    float4 o;
+    o.x = fmaxf(bn_act(r01.x, mu.x, sc.x, be.x), 0.f);
+    o.y = fmaxf(bn_act(r01.z, mu.y, sc.y, be.y), 0.f);
+    o.z = fmaxf(bn_act(r23.x, mu.z, sc.z, be.z), 0.f);
+    o.w = fmaxf(bn_act(r23.z, mu.w, sc.w, be.w), 0.f);
+    *reinterpret_cast<float4 *>(out + g * ldo + c) = o;
+    *reinterpret_cast<int4 *>(arg + g * ldo + c) = make_int4(__float_as_int(r01.y), __float_as_int(r01.w), __float_as_int(r23.y), __float_as_int(r23.w));
+}
+}  // namespace
+
+extern "C" int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
+                                    int ldy, int64_t P, int K, int N, double *stats, int Kpool, const float *gamma, float *pool_ws,
+                                    pn2_stream_t stream) {
+    PN2_CHECK_ARG(X && in_affine && W && bias && Y && stats && gamma && pool_ws && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && Kpool > 0);
+    PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= K && ldw >= K && ldy % 4 == 0 && ldy >= N);
+    if (!pn2_res_supported(P, N, K) || P % 32 != 0 || P % Kpool != 0 || !(Kpool == 16 || Kpool % 32 == 0)) return PN2_EUNSUPPORTED;
+    PN2_CHECK_ARG((reinterpret_cast<uintptr_t>(pool_ws) & 15) == 0);
+    ResPool pool;
+    pool.rec = reinterpret_cast<float2 *>(pool_ws);
+    pool.gamma = gamma;
+    pool.ldp = N; pool.U = Kpool == 16 ? 1 : Kpool / 32;
+    if (Kpool == 16) return dispatch_fwd_res<true, 2>(K, N, X, ldx, in_affine, W, ldw, bias, Y, ldy, P, stats, pool, pn2_s(stream));
+    return dispatch_fwd_res<true, 1>(K, N, X, ldx, in_affine, W, ldw, bias, Y, ldy, P, stats, pool, pn2_s(stream));
+}
+
+extern "C" int pn2_bn_pool_select(const float *pool_ws, const float *affine, int64_t G, int C, float *out, int ldo, int32_t *arg,
+                                  pn2_stream_t stream) {
+    PN2_CHECK_ARG(pool_ws && affine && out && arg && G > 0 && C > 0 && C % 32 == 0 && ldo == C &&
+                  (reinterpret_cast<uintptr_t>(pool_ws) & 15) == 0);
+    const int64_t n = G * (C >> 2);
+    hipLaunchKernelGGL(bn_pool_select_kernel, dim3((unsigned)pn2_cdiv(n, 256)), dim3(256), 0, pn2_s(stream),
+                       reinterpret_cast<const float2 *>(pool_ws), C, affine, C, G, C, out, ldo, arg);
+    return pn2_launch_status();
 }
 
 extern "C" int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y,

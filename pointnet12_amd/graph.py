@@ -12,9 +12,13 @@ during capture every draw site receives a slice of one device buffer; before eac
 same ``randint(0, N, (B,))`` sequence, in the same order, into a pinned staging buffer and enqueues one H2D
 copy ahead of the graph.
 """
+import os
+
 import torch
 
 from . import pointnet_util as U
+
+_GEO_FIRST = os.environ.get("PN2_GEO_FIRST", "1") == "1"      # capture order of the two branches (the executor's launch order follows it)
 
 
 class FpsStartFeed:
@@ -132,14 +136,22 @@ class GraphedStep:
                 with torch.cuda.graph(graph, pool=pool):
                     main = torch.cuda.current_stream(device)
                     geo_stream.wait_stream(main)
-                    with torch.cuda.stream(geo_stream):            # branch 2: next batch's geometry
-                        U.set_geometry_tape(write)
-                        with torch.no_grad():
-                            geometry_fn()
+
+                    def geometry_branch():                         # branch 2: next batch's geometry
+                        with torch.cuda.stream(geo_stream):
+                            U.set_geometry_tape(write)
+                            with torch.no_grad():
+                                geometry_fn()
+
+                    if _GEO_FIRST:
+                        geometry_branch()
                     read.rewind("replay")                          # branch 1: this batch on the recorded geometry
                     U.set_geometry_tape(read)
                     loss = fn()
                     U.set_geometry_tape(None)
+                    if not _GEO_FIRST:
+                        geometry_branch()
+                        U.set_geometry_tape(None)
                     main.wait_stream(geo_stream)
             finally:
                 U.set_capture_scope(None)

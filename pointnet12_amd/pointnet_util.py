@@ -411,6 +411,8 @@ _DIRECT_GRADS = False
 # B=16 9.257 vs 9.245 ms, B=1 2.29 vs 2.33 ms; SSG 3.833 vs 3.827 ms) -- the last workgroup's ticket + device-scope
 # reads cost the same ~5 us as the dependent launch they replace -- so the stand-alone launches stay the default.
 FUSED_BN_TAILS = os.environ.get("PN2_FUSED_BN_TAILS", "0") == "1"
+# the last layer of a pooled MLP records the per-group extrema in its GEMM epilogue (pn2_conv1x1_fwd_pool); 0: A/B runs
+POOL_IN_EPILOGUE = os.environ.get("PN2_POOL_EPILOGUE", "1") == "1"
 _REPL = 8                         # PN2_STAT_REPLICAS of include/pn2.h
 _MALL_CHUNK_BYTES = 1 << 62       # row-chunked dgrad+wgrad pairing is OFF: measured 10.9 -> 13.1 ms/step at 96 MiB chunks
                                   # (per-launch fixed costs beat the Infinity-Cache hits); kept as a tuning knob
@@ -472,6 +474,7 @@ class _SharedMLP(torch.autograd.Function):
         tickets = zero_bytes.data_ptr() + 8 * n_stats + 4 * n_aff      # one uint32 per fused BatchNorm tail
         aff_off = 0
         x, ldx, x_aff, off = rows, rows.shape[-1], None, 0
+        pool_ws = None
         for l in range(L):
             w, b, gamma, beta, rmean, rvar, nbt = flat[7 * l:7 * l + 7]
             co, ci = chans[l + 1], chans[l]
@@ -497,6 +500,19 @@ class _SharedMLP(torch.autograd.Function):
                                            None, None, st), "pn2_conv1x1_fwd")
                 _check(lib.pn2_group_affine_fwd(_p(zf), zf.shape[1], _p(g_xyz), _p(g_new), _p(g_idx), wx_ptr, ci, gB, gN, gS,
                                                 gK, co, _p(y), y.shape[1], _p(st_l), fin, st), "pn2_group_affine_fwd")
+            elif (l == L - 1 and pool and training and fin is None and x_aff is not None and POOL_IN_EPILOGUE and P % 32 == 0 and
+                  (pool == 16 or pool % 32 == 0) and lib.pn2_res_supported(P, co, ci)):
+                # last layer of a pooled MLP: the weight-resident kernel also records the per-group extrema of y, so the
+                # pooled output needs no second pass over Y (unsupported shapes: the plain launch + pn2_bn_relu_max below)
+                pool_ws = torch.empty(2 * (P // pool) * co, device=dev, dtype=torch.float32)
+                rc = lib.pn2_conv1x1_fwd_pool(_p(x), ldx, _p(x_aff), _p(_contig_weight(w)), ci, _p(b), _p(y), y.shape[1], P, ci, co,
+                                              _p(st_l), pool, _p(gamma), _p(pool_ws), st)
+                if rc == _lib.PN2_EUNSUPPORTED:
+                    pool_ws = None
+                    _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(_contig_weight(w)), ci, _p(b), _p(y), y.shape[1], P, ci,
+                                               co, _p(st_l), fin, st), "pn2_conv1x1_fwd")
+                else:
+                    _check(rc, "pn2_conv1x1_fwd_pool")
             else:
                 _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(_contig_weight(w)), ci, _p(b), _p(y), y.shape[1], P, ci,
                                            co, _p(st_l), fin, st), "pn2_conv1x1_fwd")
@@ -512,8 +528,11 @@ class _SharedMLP(torch.autograd.Function):
         G = P // K
         out = _empty_rows(G, cl, dev)
         arg = torch.empty(G, out.shape[1], device=dev, dtype=torch.int32) if pool else None
-        _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), out.shape[1], _p(arg), st),
-               "pn2_bn_relu_max")
+        if pool_ws is not None:
+            _check(lib.pn2_bn_pool_select(_p(pool_ws), _p(affs[-1]), G, cl, _p(out), out.shape[1], _p(arg), st), "pn2_bn_pool_select")
+        else:
+            _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), out.shape[1], _p(arg), st),
+                   "pn2_bn_relu_max")
         ctx.meta = (chans, pool, bool(training), P)
         ctx.geom = None if geom is None else (g_xyz, g_new, g_idx, bool(g_first), g_inv)   # index/coordinate tensors: no cycle
         ctx.params = flat                       # leaf parameters / buffers (no grad_fn): no cycle either

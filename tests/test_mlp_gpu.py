@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from pointnet12_amd import _lib
 from pointnet12_amd import pointnet_util as U
 
 pytestmark = pytest.mark.gpu
@@ -189,3 +190,52 @@ def test_plain_conv1x1_bias_and_weight_gradients(dev, P, ci, co):
         a = a.double().reshape(r.shape)
         tol = 2e-6 * float(r.abs().max()) * max(1.0, (ci if name in ("y",) else co if name == "dx" else P) ** 0.5 / 8)
         assert float((a - r).abs().max()) <= tol, (name, float((a - r).abs().max()), tol)
+
+
+@pytest.mark.parametrize("P,pool,chans", [(65536, 16, [64, 96, 128]), (65536, 32, [32, 32, 64]), (131072, 64, [32, 64, 128]),
+                                          (65536, 128, [64, 64, 96]), (32768 + 64, 64, [32, 64, 64])])
+def test_pool_in_gemm_epilogue_equals_the_pooling_pass(dev, P, pool, chans):
+    """pn2_conv1x1_fwd_pool + pn2_bn_pool_select (extrema of y recorded by the weight-resident GEMM's epilogue, BN + ReLU applied to
+    the maximum where the folded scale is >= 0 and to the minimum where it is negative) against pn2_bn_relu_max over Y: the
+    pooled output must be BIT-equal (monotonicity), the argmax equal wherever it is unique -- with negative and zero BatchNorm
+    weights, and groups padded by repeating their first row (the ball query's padding: equal rows, first one wins)."""
+    gen = torch.Generator().manual_seed(P + pool)
+    c_in = chans[0]
+    rows = torch.randn(P, c_in, generator=gen) * 2 + 0.5
+    rows = rows.view(P // pool, pool, c_in)
+    rows[::3, pool // 2:] = rows[::3, :1]                       # every third group: second half = copies of its first row
+    rows[1::7, 1:] = rows[1::7, :1]                             # some groups: one distinct row only
+    rows = rows.reshape(P, c_in).contiguous()
+    convs = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])])
+    bns = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]])
+    for bn in bns:
+        bn.weight.data.uniform_(-1.5, 1.5, generator=gen)       # half of the channels: negative scale -> the minimum is pooled
+        bn.weight.data[::5] = 0.0                               # scale 0: constant output
+        bn.bias.data.uniform_(-0.5, 0.5, generator=gen)
+    convs.to(dev), bns.to(dev)
+    res = {}
+    for flag in (True, False):
+        U.POOL_IN_EPILOGUE = flag
+        try:
+            for p in list(convs.parameters()) + list(bns.parameters()):
+                p.grad = None
+            for bn in bns:
+                bn.reset_running_stats()
+            x = rows.to(dev).requires_grad_(True)
+            with _lib.call_profile() as calls:
+                out = U.shared_mlp(x, c_in, convs, bns, pool, True)
+            gw = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+            (out * gw).sum().backward()
+            res[flag] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in convs.parameters()],
+                         [c[0] for c in calls])
+        finally:
+            U.POOL_IN_EPILOGUE = True
+    names_on, names_off = res[True][3], res[False][3]
+    assert "pn2_conv1x1_fwd_pool" in names_on and "pn2_bn_pool_select" in names_on and "pn2_bn_relu_max" not in names_on
+    assert "pn2_bn_relu_max" in names_off and "pn2_conv1x1_fwd_pool" not in names_off
+    assert torch.equal(res[True][0], res[False][0])             # bit-equal pooled output
+    # gradients: identical routing except between rows with EQUAL post-BN value (clamped to 0 by the ReLU -- no gradient --
+    # or collapsed by rounding): same yardstick as the flip slack above
+    for a, b in zip([res[True][1]] + res[True][2], [res[False][1]] + res[False][2]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale, float((a - b).abs().max()) / scale

@@ -85,6 +85,17 @@ def main():
                 rc = lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), None, st)
                 assert rc == 0
             report("fwd", (P, K, N), timeit(fn, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
+            for Kp in (16, 32, 64):              # the same GEMM with the pooling extrema recorded in its epilogue
+                if aff is None or not lib.pn2_res_supported(P, N, K) or N % 32 or K % 32:
+                    continue
+                ws = torch.empty(4 * (P // Kp) * N, device=dev)
+                if lib.pn2_conv1x1_fwd_pool(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), Kp, p(bias), p(ws), st) != 0:
+                    continue                     # W plus eight staging buffers exceed LDS
+
+                def fnp():
+                    rc = lib.pn2_conv1x1_fwd_pool(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), Kp, p(bias), p(ws), st)
+                    assert rc == 0
+                report("fwdpool%d" % Kp, (P, K, N), timeit(fnp, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
             del X, Y
 
     for which in ("dgrad", "wgrad", "bwd"):
