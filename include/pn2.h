@@ -88,6 +88,12 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
  * for an empty ball (the reference's tensor at :107). */
 int pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int nsample,
                    int64_t *out_idx, pn2_stream_t stream);
+/* The same query with caller scratch (`work`: pn2_ball_query_workspace_bytes(B, N, S) bytes, 4-byte aligned; 0 bytes / NULL:
+ * identical to pn2_ball_query): on large clouds the centres are first put in spatial (Morton-cell) order so that the sixteen
+ * centres a workgroup scans for have similar neighbour densities -- same out_idx, bit for bit. */
+int64_t pn2_ball_query_workspace_bytes(int B, int N, int S);
+int pn2_ball_query_ws(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int nsample, int64_t *out_idx,
+                      void *work, pn2_stream_t stream);
 
 /* square_distance, model/pointnet_util.py:19-40. src [B,S,3], dst [B,N,3] -> out [B,S,N]. */
 int pn2_square_distance(const float *src, const float *dst, int B, int S, int N, float *out, pn2_stream_t stream);

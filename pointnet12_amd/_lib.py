@@ -20,6 +20,8 @@ SIGNATURES = {
     "pn2_fps_workspace_bytes": (_i64, [_i, _i, _i]),
     "pn2_fps": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "pn2_ball_query_workspace_bytes": (_i64, [_i, _i, _i]),
+    "pn2_ball_query_ws": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "pn2_square_distance": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pn2_three_nn": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -105,7 +107,7 @@ class _Timed:
     def __getattr__(self, name):
         fn = getattr(_raw, name)
         if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes",
-                                                   "pn2_nll_loss_workspace_bytes", "pn2_res_supported"):
+                                                   "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_ball_query_workspace_bytes"):
             return fn
 
         def timed(*args):

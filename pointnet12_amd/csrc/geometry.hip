@@ -526,6 +526,63 @@ int launch_fps(const float *xyz, int B, int N, const int64_t *start, int npoint,
     return pn2_launch_status();
 }
 
+// Spatial (Morton-cell) ordering of the query centres of one cloud for ball_query_kernel: bounding box, 4096-cell histogram,
+// scan and fill in LDS -- one workgroup per cloud, any S (the order array lives in global memory).
+__global__ __launch_bounds__(1024) void bq_order_kernel(const float *__restrict__ new_xyz, int S, int *__restrict__ order) {
+    __shared__ int hist[FPS_NC];
+    __shared__ int wsum[16];
+    __shared__ float wbox[16][6];
+    __shared__ float box[6];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *q = new_xyz + (size_t)b * S * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = t; j < S; j += 1024) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = q[3 * j + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int m = 32; m >= 1; m >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], m, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], m, 64)); }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { wbox[wave][a] = lo[a]; wbox[wave][3 + a] = hi[a]; }
+    }
+    for (int i = t; i < FPS_NC; i += 1024) hist[i] = 0;
+    __syncthreads();
+    if (t < 6) {
+        float v = wbox[0][t];
+        for (int w = 1; w < 16; ++w) v = t < 3 ? fminf(v, wbox[w][t]) : fmaxf(v, wbox[w][t]);
+        box[t] = v;
+    }
+    __syncthreads();
+    const float ox = box[0], oy = box[1], oz = box[2];
+    const float sx = box[3] > ox ? 32.0f / (box[3] - ox) : 0.f, sy = box[4] > oy ? 32.0f / (box[4] - oy) : 0.f,
+                sz = box[5] > oz ? 4.0f / (box[5] - oz) : 0.f;
+    for (int j = t; j < S; j += 1024) atomicAdd(&hist[fps_cell(q[3 * j], q[3 * j + 1], q[3 * j + 2], ox, oy, oz, sx, sy, sz)], 1);
+    __syncthreads();
+    {
+        constexpr int CPT = FPS_NC / 1024;
+        int c[CPT], sum = 0;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { c[i] = hist[t * CPT + i]; sum += c[i]; }
+        int x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int base = x - sum;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { hist[t * CPT + i] = base; base += c[i]; }
+    }
+    __syncthreads();
+    int *o = order + (size_t)b * S;
+    for (int j = t; j < S; j += 1024) o[atomicAdd(&hist[fps_cell(q[3 * j], q[3 * j + 1], q[3 * j + 2], ox, oy, oz, sx, sy, sz)], 1)] = j;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Ball query.  A workgroup of BQ_WAVES waves takes BQ_WAVES * BQ_CPW consecutive query centres of one cloud, every wave
 // BQ_CPW of them at once.  The candidates are staged through LDS in tiles of BQ_TILE points as (x, y, z, |p|^2) float4 --
@@ -540,25 +597,34 @@ int launch_fps(const float *xyz, int B, int N, const int64_t *start, int npoint,
 // ---------------------------------------------------------------------------------------------
 constexpr int BQ_WAVES = 4, BQ_CPW = 4, BQ_TILE = 1024, BQ_THREADS = BQ_WAVES * 64, BQ_PPT = BQ_TILE / BQ_THREADS;
 
+//
+// `order` (optional, [B][S] int32): a spatial ordering of the centres (bq_order_kernel).  A workgroup lives as long as the
+// slowest of its BQ_WAVES * BQ_CPW centres scans; taken in sampling order (FPS output: scattered all over the cloud) almost
+// every workgroup holds one sparse-region centre that runs to the end of the cloud.  Taken in Morton order the sixteen centres
+// of a workgroup are neighbours with similar neighbour density: dense groups stop after a few tiles, and the full scans are
+// confined to the workgroups of the sparse regions.  The results are the same rows, written to the centres' own positions.
 __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__restrict__ xyz,
                                                                 const float *__restrict__ new_xyz, int N, int S, float r2,
-                                                                int nsample, int64_t *__restrict__ out) {
+                                                                int nsample, const int *__restrict__ order,
+                                                                int64_t *__restrict__ out) {
     __shared__ float4 tile[BQ_TILE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int s0 = (blockIdx.x * BQ_WAVES + wave) * BQ_CPW, b = blockIdx.y;
     const float *p = xyz + (size_t)b * N * 3;
     float qx[BQ_CPW], qy[BQ_CPW], qz[BQ_CPW], nq[BQ_CPW];
     int cnt[BQ_CPW], first[BQ_CPW];
+    int64_t *rows[BQ_CPW];
 #pragma unroll
     for (int c = 0; c < BQ_CPW; ++c) {
         const bool live = s0 + c < S;
-        const float *q = new_xyz + ((size_t)b * S + (live ? s0 + c : 0)) * 3;
+        const int sid = !live ? 0 : (order ? order[(size_t)b * S + s0 + c] : s0 + c);
+        const float *q = new_xyz + ((size_t)b * S + sid) * 3;
         qx[c] = q[0]; qy[c] = q[1]; qz[c] = q[2];
         nq[c] = sq_norm3(qx[c], qy[c], qz[c]);
         cnt[c] = live ? 0 : nsample;                     // a centre past the end is "done" from the start
         first[c] = N;
+        rows[c] = out + ((size_t)b * S + sid) * nsample;
     }
-    int64_t *rows = out + ((size_t)b * S + s0) * nsample;
     float raw[BQ_PPT][3];
     auto fetch = [&](int base) {
 #pragma unroll
@@ -606,7 +672,7 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
                     if (mask && cnt[c] < nsample) {              // (the second half-step of a centre that just filled up: skipped)
                         const int j = h ? j1 : j0;
                         const int pos = cnt[c] + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (((mask >> lane) & 1ull) && pos < nsample) rows[(size_t)c * nsample + pos] = base + j;
+                        if (((mask >> lane) & 1ull) && pos < nsample) rows[c][pos] = base + j;
                         if (cnt[c] == 0) first[c] = base + k + 64 * h + __ffsll((long long)mask) - 1;
                         cnt[c] += __popcll(mask);
                     }
@@ -620,7 +686,7 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
     for (int c = 0; c < BQ_CPW; ++c) {
         if (s0 + c >= S) break;
         const int have = cnt[c] > nsample ? nsample : cnt[c];
-        for (int k = have + lane; k < nsample; k += 64) rows[(size_t)c * nsample + k] = first[c];
+        for (int k = have + lane; k < nsample; k += 64) rows[c][k] = first[c];
     }
 }
 
@@ -796,12 +862,33 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
     return pn2_launch_status();
 }
 
+// The centres are put in spatial order first where that pays: large clouds (a full scan is long) with enough centres for the
+// ordering to form homogeneous workgroups.  PN2_BQ_ORDER=0: never (A/B runs).
+static bool bq_wants_order(int N, int S) {
+    static const int on = [] { const char *e = getenv("PN2_BQ_ORDER"); return e ? atoi(e) : 1; }();
+    return on && N >= 8192 && S >= 1024;
+}
+
+int64_t pn2_ball_query_workspace_bytes(int B, int N, int S) {
+    return (B > 0 && bq_wants_order(N, S)) ? (int64_t)B * S * (int64_t)sizeof(int) : 0;
+}
+
+int pn2_ball_query_ws(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int nsample, int64_t *out_idx,
+                      void *work, pn2_stream_t stream) {
+    PN2_CHECK_ARG(xyz && new_xyz && out_idx && B > 0 && N > 0 && S > 0 && nsample > 0 && B <= 65535);
+    int *order = nullptr;
+    if (work != nullptr && bq_wants_order(N, S)) {
+        order = static_cast<int *>(work);
+        hipLaunchKernelGGL(bq_order_kernel, dim3(B), dim3(1024), 0, pn2_s(stream), new_xyz, S, order);
+    }
+    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)pn2_cdiv(S, BQ_WAVES * BQ_CPW), B), dim3(BQ_THREADS), 0, pn2_s(stream), xyz,
+                       new_xyz, N, S, r2, nsample, order, out_idx);
+    return pn2_launch_status();
+}
+
 int pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int nsample,
                    int64_t *out_idx, pn2_stream_t stream) {
-    PN2_CHECK_ARG(xyz && new_xyz && out_idx && B > 0 && N > 0 && S > 0 && nsample > 0 && B <= 65535);
-    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)pn2_cdiv(S, BQ_WAVES * BQ_CPW), B), dim3(BQ_THREADS), 0, pn2_s(stream), xyz,
-                       new_xyz, N, S, r2, nsample, out_idx);
-    return pn2_launch_status();
+    return pn2_ball_query_ws(xyz, new_xyz, B, N, S, r2, nsample, out_idx, nullptr, stream);
 }
 
 int pn2_square_distance(const float *src, const float *dst, int B, int S, int N, float *out, pn2_stream_t stream) {

@@ -289,8 +289,10 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
         raise RuntimeError("nsample (%d) > N (%d): the reference's mask assignment fails here too" % (nsample, N))
     out = torch.empty(B, S, nsample, device=xyz.device, dtype=torch.int64)
     r2 = float(np.float32(radius ** 2))
-    _check(_lib.load().pn2_ball_query(_p(xyz), _p(new_xyz), B, N, S, r2, nsample, _p(out), _lib.stream()),
-           "pn2_ball_query")
+    lib = _lib.load()
+    wb = lib.pn2_ball_query_workspace_bytes(B, N, S)          # > 0: the library wants to take the centres in spatial order
+    work = torch.empty(wb, device=xyz.device, dtype=torch.uint8) if wb else None
+    _check(lib.pn2_ball_query_ws(_p(xyz), _p(new_xyz), B, N, S, r2, nsample, _p(out), _p(work), _lib.stream()), "pn2_ball_query_ws")
     return _taped(lambda: out)
 
 
