@@ -26,7 +26,7 @@ def test_library_exports_every_symbol():
     for name in header_functions():
         assert hasattr(lib, name), name
     lib.pn2_version.restype = ctypes.c_int
-    assert lib.pn2_version() == 4            # host-only call: no GPU needed
+    assert lib.pn2_version() == _lib.ABI_VERSION     # host-only call: no GPU needed
     lib.pn2_error_string.restype = ctypes.c_char_p
     assert lib.pn2_error_string(-1) == b"invalid argument"
 
