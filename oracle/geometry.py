@@ -15,7 +15,8 @@ def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libpn2_oracle.so"])
     host = os.path.join(_HERE, "libpn2_host.so")           # the same restatement behind the pn2_* symbols of include/pn2.h
-    if force or not os.path.exists(host) or os.path.getmtime(host) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "pn2_host.c"))):
+    if force or not os.path.exists(host) or os.path.getmtime(host) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "pn2_host.c")),
+                                                                           os.path.getmtime(os.path.join(_HERE, "..", "include", "pn2.h"))):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libpn2_host.so"])
     return _SO
 

@@ -33,6 +33,14 @@ HOST_API int pn2_ball_query(const float *xyz, const float *new_xyz, int B, int N
     return PN2_OK;
 }
 
+HOST_API int64_t pn2_ball_query_workspace_bytes(int B, int N, int S) { (void)B; (void)N; (void)S; return 0; }
+
+HOST_API int pn2_ball_query_ws(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int nsample, int64_t *out_idx,
+                               void *work, pn2_stream_t stream) {
+    (void)work;
+    return pn2_ball_query(xyz, new_xyz, B, N, S, r2, nsample, out_idx, stream);
+}
+
 HOST_API int pn2_square_distance(const float *src, const float *dst, int B, int S, int N, float *out, pn2_stream_t stream) {
     (void)stream;
     if (!src || !dst || !out || B <= 0 || S <= 0 || N <= 0) return PN2_EINVAL;
