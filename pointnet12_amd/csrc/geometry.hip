@@ -337,23 +337,236 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
     }
 }
 
+// The same kernel with a second level of pruning for 24+ points per thread (N > 22 528), where the one above runs out of
+// registers (24-72 of its words went to scratch) and its per-thread argmax over all PPT points is the iteration: the skip test
+// is per ROW of 64 consecutive sorted points (lane i of a wave holds row i's bounding box and largest running distance and
+// tests it while the other lanes test theirs), only touched rows are updated, four at a time with their four DPP maxima
+// interleaved, and the wave's candidate comes from the row maxima (the original index is looked up in the tied rows only:
+// no per-thread argmax, no tie slow path).  Measured, us per iteration: N = 25 000 1.93 -> 1.68, 28 672 2.26 -> 1.87
+// (16 384: 1.04 -> 1.42, 20 000: 1.20 -> 1.52 -- the dependent DPP chains of a lone active wave cost more than the arithmetic
+// they save there, so the smaller clouds stay with the wave-level kernel; row keys through 64-lane ds_max_u64 instead of DPP:
+// 2.85 at 25 000, a same-address LDS atomic takes ~8 cycles per lane).
+#ifdef PN2_FPS_DBG
+__device__ unsigned long long pn2_fps_dbg[1024 * 16 * 6];   // [iteration][wave][t0, t_test, t_rows, t_tie, t_barrier, groups]
+extern "C" __global__ void pn2_fps_dbg_touch() {}
+#define FPS_DBG(k, v) if (b == 0 && lane == 0 && it < 1024) pn2_fps_dbg[(it * 16 + wave) * 6 + (k)] = (v);
+#else
+#define FPS_DBG(k, v)
+#endif
+template <int THREADS, int PPT, bool XYZ_LDS>
+__global__ __launch_bounds__(THREADS) void fps_rows_kernel(const float *__restrict__ xyz, int N,
+                                                             const int64_t *__restrict__ start, int npoint,
+                                                             int64_t *__restrict__ out) {
+    constexpr int NW = THREADS / 64, WCAP = 64 * PPT, CAP = THREADS * PPT;
+    extern __shared__ int fps_p_lds[];
+    int *perm = fps_p_lds;                               // [CAP]: sorted position -> original index (-1: empty)
+    int *hist = perm + CAP;                              // [FPS_NC] counts -> cursors
+    int *wsum = hist + FPS_NC;                           // [NW] + carry
+    float *box = reinterpret_cast<float *>(wsum + 32);   // [6] cloud bounding box, then [NW][6] wave boxes at box + 8
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(box + 8 + 6 * NW + 2);   // [3] rotating meeting words
+    float4 *cloud = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(slots + 4) + 15) & ~(uintptr_t)15);   // XYZ_LDS: [N] by ORIGINAL index -- the winner's coordinates are
+                                                             // one broadcast ds_read_b128 away instead of an L2 round trip
+
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *p = xyz + (size_t)b * N * 3;
+
+    // ---- cloud bounding box (the cell grid adapts to whatever scale the coordinates have)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = t; j < N; j += THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = p[3 * j + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int m = 32; m >= 1; m >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], m, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], m, 64)); }
+    float *wbox = reinterpret_cast<float *>(perm);       // scratch [NW][6] (perm is not in use yet)
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { wbox[wave * 6 + a] = lo[a]; wbox[wave * 6 + 3 + a] = hi[a]; }
+    }
+    for (int i = t; i < FPS_NC; i += THREADS) hist[i] = 0;
+    if (t < 3) slots[t] = 0ull;
+    __syncthreads();
+    if (t < 6) {
+        float v = wbox[t];
+        for (int w = 1; w < NW; ++w) v = t < 3 ? fminf(v, wbox[w * 6 + t]) : fmaxf(v, wbox[w * 6 + t]);
+        box[t] = v;
+    }
+    __syncthreads();
+    const float ox = box[0], oy = box[1], oz = box[2];
+    // (an axis without extent -- a flat cloud -- gets scale 0: everything in cell 0 of that axis, never 0 * inf)
+    const float sx = box[3] > ox ? 32.0f / (box[3] - ox) : 0.f, sy = box[4] > oy ? 32.0f / (box[4] - oy) : 0.f,
+                sz = box[5] > oz ? 4.0f / (box[5] - oz) : 0.f;
+    __syncthreads();                                      // wbox (aliasing perm) is dead
+
+    // ---- counting sort by cell: histogram, exclusive scan, fill through LDS cursors
+    for (int j = t; j < N; j += THREADS)
+        atomicAdd(&hist[fps_cell(p[3 * j], p[3 * j + 1], p[3 * j + 2], ox, oy, oz, sx, sy, sz)], 1);
+    __syncthreads();
+    {
+        constexpr int CPT = FPS_NC / THREADS;             // consecutive cells per thread
+        int c[CPT], sum = 0;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { c[i] = hist[t * CPT + i]; sum += c[i]; }
+        int x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int base = x - sum;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { hist[t * CPT + i] = base; base += c[i]; }
+    }
+    __syncthreads();
+    for (int j = t; j < N; j += THREADS) {
+        const float x = p[3 * j], y = p[3 * j + 1], z = p[3 * j + 2];
+        const int pos = atomicAdd(&hist[fps_cell(x, y, z, ox, oy, oz, sx, sy, sz)], 1);
+        perm[pos] = j;
+        if (XYZ_LDS) cloud[j] = make_float4(x, y, z, 0.f);
+    }
+    for (int i = N + t; i < CAP; i += THREADS) perm[i] = -1;
+    __syncthreads();
+
+    // ---- this thread's points: sorted positions wave * WCAP + i * 64 + lane.  The wave owns one contiguous run of the sorted
+    // order; ROW i of the wave -- the i-th point of its 64 lanes -- is 64 consecutive sorted positions: a compact cluster with
+    // its own bounding box and its own largest running distance, both held by LANE i of the wave.
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    const int pbase = wave * WCAP + lane;
+    float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};   // lane i: box of row i (empty: never reached)
+    unsigned rmax = 0u;                                   // lane i: bits of the largest running distance of row i (0: empty / exhausted)
+    int minidx = 0x7FFFFFFF;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = perm[pbase + i * 64];
+        float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (j >= 0) {
+            px[i] = p[3 * j]; py[i] = p[3 * j + 1]; pz[i] = p[3 * j + 2];
+            md[i] = 1e10f;
+            blo[0] = bhi[0] = px[i]; blo[1] = bhi[1] = py[i]; blo[2] = bhi[2] = pz[i];
+            minidx = j < minidx ? j : minidx;
+        } else {
+            px[i] = py[i] = pz[i] = 0.f;
+            md[i] = -1.f;                                 // never a candidate: distances are >= 0
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            for (int m = 32; m >= 1; m >>= 1) { blo[a] = fminf(blo[a], __shfl_xor(blo[a], m, 64)); bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], m, 64)); }
+        if (lane == i) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { rlo[a] = blo[a]; rhi[a] = bhi[a]; }
+            rmax = blo[0] <= bhi[0] ? __float_as_uint(1e10f) : 0u;
+        }
+    }
+
+    int rot = 0;
+    int far = (int)(start[b] < 0 ? 0 : (start[b] >= N ? N - 1 : start[b]));
+    int64_t *o = out + (size_t)b * npoint;
+    // The candidate a wave offers while it is being skipped must be the one the plain kernel would compute from the same
+    // running distances: initially every point sits at 1e10, i.e. (1e10, lowest original index of the wave); an empty
+    // wave offers nothing, ever.
+    for (int m = 32; m >= 1; m >>= 1) { const int o2 = __shfl_xor(minidx, m, 64); minidx = o2 < minidx ? o2 : minidx; }
+    unsigned long long wkey = minidx == 0x7FFFFFFF ? 0ull : ((unsigned long long)__float_as_uint(1e10f) << 32) | (0xFFFFFFFFu - (unsigned)minidx);
+    __syncthreads();
+    for (int it = 0; it < npoint; ++it) {
+        FPS_DBG(0, __builtin_readcyclecounter())
+        if (t == 0) o[it] = far;
+        float cx, cy, cz;
+        if (XYZ_LDS) {
+            const float4 c = cloud[far];
+            cx = c.x; cy = c.y; cz = c.z;
+        } else {
+            const int f = __builtin_amdgcn_readfirstlane(far);
+            cx = p[3 * f]; cy = p[3 * f + 1]; cz = p[3 * f + 2];
+        }
+        // every row against the new sample at once (lane i: row i): squared distance to the row's box, from below.  A row
+        // farther away than its largest running distance cannot change (EXACT, see the header).
+        const float ex = fmaxf(fmaxf(rlo[0] - cx, cx - rhi[0]), 0.f), ey = fmaxf(fmaxf(rlo[1] - cy, cy - rhi[1]), 0.f),
+                    ez = fmaxf(fmaxf(rlo[2] - cz, cz - rhi[2]), 0.f);
+        const float lb = (ex * ex + ey * ey) + ez * ez;
+        const unsigned long long touched = __ballot(!(lb * 0.999998f > __uint_as_float(rmax)));   // (empty rows: lb = inf)
+        FPS_DBG(1, __builtin_readcyclecounter())
+#ifdef PN2_FPS_DBG
+        { int ng = 0; for (int i0 = 0; i0 < PPT; i0 += 4) ng += ((touched >> i0) & 15ull) ? 1 : 0; FPS_DBG(5, (unsigned long long)ng | ((unsigned long long)__popcll(touched) << 32)) }
+        FPS_DBG(2, 0ull) FPS_DBG(3, 0ull)
+#endif
+        if (touched != 0ull) {                            // wave-uniform: the sample may reach into some of this wave's rows
+            // rows in groups of four (neighbours in the sorted order: a sample that touches one usually touches the next): the
+            // four row maxima go through one interleaved DPP reduction
+#pragma unroll
+            for (int i0 = 0; i0 < PPT; i0 += 4) {
+                if ((touched >> i0) & 15ull) {            // wave-uniform
+                    unsigned v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u < PPT ? i0 + u : PPT - 1;
+                        if (i0 + u < PPT) {
+                            const float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+                            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                            const float d = (xx + yy) + zz;
+                            md[i] = min_raw(d, md[i]);    // empty slots hold -1 and stay there
+                            v[u] = md[i] < 0.f ? 0u : __float_as_uint(md[i]);
+                        } else {
+                            v[u] = 0u;
+                        }
+                    }
+                    pn2_wave_max_u32_x4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u < PPT) rmax = lane == i0 + u ? (unsigned)__builtin_amdgcn_readlane((int)v[u], 63) : rmax;
+                }
+            }
+            FPS_DBG(2, __builtin_readcyclecounter())
+            // the wave's candidate: the largest row maximum (distances are >= 0: their bit patterns order like unsigned
+            // integers), and among the points that attain it the lowest ORIGINAL index -- looked up only in the rows that tie
+            const unsigned bv = pn2_wave_max_u32(rmax);
+            const unsigned long long tied = __ballot(rmax == bv && lane < PPT);
+            unsigned low = 0u;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                if ((tied >> i) & 1ull) {                 // wave-uniform
+                    const int j = perm[pbase + i * 64];
+                    const unsigned c = (md[i] >= 0.f && __float_as_uint(md[i]) == bv) ? 0xFFFFFFFFu - (unsigned)j : 0u;
+                    const unsigned cm = pn2_wave_max_u32(c);
+                    low = cm > low ? cm : low;
+                }
+            }
+            wkey = low == 0u ? 0ull : ((unsigned long long)bv << 32) | low;      // (no valid point in the wave: nothing to offer)
+            FPS_DBG(3, __builtin_readcyclecounter())
+        }
+        unsigned long long *cur = slots + rot;
+        rot = rot == 2 ? 0 : rot + 1;
+        if (lane == 0) __hip_atomic_fetch_max(cur, wkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t == 0) slots[rot] = 0ull;
+        __syncthreads();
+        far = (int)(0xFFFFFFFFu - (unsigned)(*cur & 0xFFFFFFFFull));
+        FPS_DBG(4, __builtin_readcyclecounter())
+    }
+}
+
 template <int THREADS, int PPT>
 int launch_fps_pruned(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, hipStream_t s) {
+    constexpr bool ROWS = PPT >= 24;                      // two-level pruning where the wave-level kernel spills (see fps_rows_kernel)
     const size_t fixed = sizeof(int) * ((size_t)THREADS * PPT + FPS_NC + 32 + 8 + 6 * (THREADS / 64) + 2) + 64;
     const bool in_lds = fixed + (size_t)N * 16 <= 160 * 1024;
+    typedef void (*kernel_t)(const float *, int, const int64_t *, int, int64_t *);
+    kernel_t k_lds, k_mem;
+    if constexpr (ROWS) { k_lds = &fps_rows_kernel<THREADS, PPT, true>; k_mem = &fps_rows_kernel<THREADS, PPT, false>; }
+    else { k_lds = &fps_pruned_kernel<THREADS, PPT, true>; k_mem = &fps_pruned_kernel<THREADS, PPT, false>; }
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_pruned_kernel<THREADS, PPT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_pruned_kernel<THREADS, PPT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_mem), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PN2_ELAUNCH;
         raised = true;
     }
     if (in_lds)
-        hipLaunchKernelGGL((fps_pruned_kernel<THREADS, PPT, true>), dim3(B), dim3(THREADS), fixed + (size_t)N * 16, s, xyz, N, start, npoint, out);
+        hipLaunchKernelGGL(k_lds, dim3(B), dim3(THREADS), fixed + (size_t)N * 16, s, xyz, N, start, npoint, out);
     else
-        hipLaunchKernelGGL((fps_pruned_kernel<THREADS, PPT, false>), dim3(B), dim3(THREADS), fixed, s, xyz, N, start, npoint, out);
+        hipLaunchKernelGGL(k_mem, dim3(B), dim3(THREADS), fixed, s, xyz, N, start, npoint, out);
     return pn2_launch_status();
 }
 
@@ -835,8 +1048,8 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
         if (N <= 22528) return launch_fps_pruned<1024, 22>(xyz, B, N, start, npoint, out_idx, s);
         if (N <= 24576) return launch_fps_pruned<1024, 24>(xyz, B, N, start, npoint, out_idx, s);
         if (N <= 25600) return launch_fps_pruned<1024, 25>(xyz, B, N, start, npoint, out_idx, s);
-        if (N <= 26624) return launch_fps_pruned<1024, 26>(xyz, B, N, start, npoint, out_idx, s);   // (from 24 points per thread on the
-        return launch_fps_pruned<1024, 28>(xyz, B, N, start, npoint, out_idx, s);                   //  compiler keeps 24-72 words in scratch)
+        if (N <= 26624) return launch_fps_pruned<1024, 26>(xyz, B, N, start, npoint, out_idx, s);   // (24+: the row-level kernel)
+        return launch_fps_pruned<1024, 28>(xyz, B, N, start, npoint, out_idx, s);
     }
     if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, start, npoint, out_idx, s);
@@ -868,6 +1081,12 @@ static bool bq_wants_order(int N, int S) {
     static const int on = [] { const char *e = getenv("PN2_BQ_ORDER"); return e ? atoi(e) : 1; }();
     return on && N >= 8192 && S >= 1024;
 }
+
+#ifdef PN2_FPS_DBG
+int pn2_fps_debug_read(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pn2_fps_dbg), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 
 int64_t pn2_ball_query_workspace_bytes(int B, int N, int S) {
     return (B > 0 && bq_wants_order(N, S)) ? (int64_t)B * S * (int64_t)sizeof(int) : 0;

@@ -80,6 +80,27 @@ __device__ __forceinline__ unsigned pn2_wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Four independent 32-bit wave maxima at once: the DPP steps of the four chains interleaved, so each chain's two wait states
+// are filled by the other three instead of s_nops (a lone chain is latency-bound: ~12 cycles per step for 4 of work).
+// Lane 63 of every value ends with its maximum; the caller reads it (v_readlane).
+__device__ __forceinline__ void pn2_wave_max_u32_x4(unsigned &a, unsigned &b, unsigned &c, unsigned &d) {
+#define PN2_DPP4(ctl)                                                   \
+    "v_max_u32_dpp %0, %0, %0 " ctl "\n\t"                              \
+    "v_max_u32_dpp %1, %1, %1 " ctl "\n\t"                              \
+    "v_max_u32_dpp %2, %2, %2 " ctl "\n\t"                              \
+    "v_max_u32_dpp %3, %3, %3 " ctl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 PN2_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 PN2_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 PN2_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 PN2_DPP4("row_mirror row_mask:0xf bank_mask:0xf")
+                 PN2_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 PN2_DPP4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef PN2_DPP4
+}
+
 // 64-bit max over the wave, result uniform (SGPRs).
 __device__ __forceinline__ unsigned long long pn2_wave_max_u64_dpp(unsigned long long v) {
     const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
