@@ -743,6 +743,7 @@ class _Conv1x1(torch.autograd.Function):
         _check(lib.pn2_conv1x1_fwd(_p(rows), ldx, None, _p(_contig_weight(weight)), ci, _p(bias), _p(y), y.shape[1], P, ci, co,
                                    None, None, st), "pn2_conv1x1_fwd")
         ctx.save_for_backward(rows, weight)
+        ctx.params = (weight, bias)             # leaf parameters (no grad_fn): no reference cycle
         ctx.dims = (P, ci, co, ldx, y.shape[1])
         return y[:, :co] if y.shape[1] != co else y
 
@@ -757,10 +758,14 @@ class _Conv1x1(torch.autograd.Function):
             g[:, :co] = grad
         else:
             g = grad.contiguous()
-        zb = _zeros_small(4 * (co * ci + co), dev).view(torch.float32)
         ident = _ident_coef(co, dev)                       # dY := 1*g + 0*(y - 0) + 0
-        dW = zb[:co * ci].view(co, ci)
-        db = zb[co * ci:]
+        direct = _direct_ok(ctx.params)                    # the kernel's atomics add straight into .grad (see set_direct_grad_accumulation)
+        if direct:
+            dW, db = ctx.params[0].grad.view(co, ci), ctx.params[1].grad
+        else:
+            zb = _zeros_small(4 * (co * ci + co), dev).view(torch.float32)
+            dW = zb[:co * ci].view(co, ci)
+            db = zb[co * ci:]
         _check(lib.pn2_conv1x1_wgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(rows), ldx, None, _p(dW), ci,
                                      _p(db), P, co, ci, st), "pn2_conv1x1_wgrad")
         d_rows = None
@@ -769,6 +774,8 @@ class _Conv1x1(torch.autograd.Function):
             _check(lib.pn2_conv1x1_dgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(_contig_weight(weight)), ci,
                                          None, 0, None,
                                          _p(d_rows), ldx, None, P, co, ci, None, st), "pn2_conv1x1_dgrad")
+        if direct:
+            return d_rows, None, None
         return d_rows, dW.view_as(weight), db
 
 
