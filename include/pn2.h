@@ -127,6 +127,15 @@ int pn2_group(const float *xyz, const float *points, const float *new_xyz, const
 int pn2_group_bwd(const float *grad_rows, const int64_t *idx, int B, int N, int S, int K, int D, int xyz_first,
                   int ld, float *grad_points, pn2_stream_t stream);
 
+/* pn2_group + the FIRST conv of a shared MLP in one launch, for narrow first layers (3 + D <= 12 input channels, C_out 32
+ * or 64, B*S*K a multiple of 64; otherwise PN2_EUNSUPPORTED and nothing is launched): X [B*S*K, ldx] receives the grouped
+ * rows exactly as pn2_group writes them (the backward's weight gradient reads them), Y [B*S*K, ldy] = X W^T + bias with
+ * W [C_out, 3 + D] as stored (pitch ldw), stats (may be NULL) the per-channel sums like pn2_conv1x1_fwd.
+ * model/pointnet_util.py:127-131 + :197, :243-247 + :254. */
+int pn2_group_conv_fwd(const float *xyz, const float *points, const float *new_xyz, const int64_t *idx, int B, int N, int S,
+                       int K, int D, int xyz_first, const float *W, int ldw, const float *bias, float *X, int ldx, float *Y, int ldy,
+                       int C_out, double *stats, pn2_stream_t stream);
+
 /* Factorised first MLP layer of a set-abstraction level (replaces gather + cat + the first 1x1 conv,
  * model/pointnet_util.py:127-131,:197 / :243-247,:254, for that layer only):
  *   Y[p, c] = Zf[b, idx[p], c] + sum_a Wx[c, a] * (xyz[b, idx[p], a] - new_xyz[b, s, a]),  p = (b, s, k)

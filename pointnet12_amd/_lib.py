@@ -34,6 +34,7 @@ SIGNATURES = {
     "pn2_three_interp_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_copy_cols": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
     "pn2_conv1x1_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "pn2_group_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "pn2_conv1x1_fwd_pool": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_bn_pool_select": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp]),
     "pn2_bn_finalize": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -415,6 +415,8 @@ _DIRECT_GRADS = False
 FUSED_BN_TAILS = os.environ.get("PN2_FUSED_BN_TAILS", "0") == "1"
 # the last layer of a pooled MLP records the per-group extrema in its GEMM epilogue (pn2_conv1x1_fwd_pool); 0: A/B runs
 POOL_IN_EPILOGUE = os.environ.get("PN2_POOL_EPILOGUE", "1") == "1"
+# narrow first layers: gather + first conv in one launch (pn2_group_conv_fwd); 0: pn2_group then the GEMM (A/B runs)
+GATHER_CONV = os.environ.get("PN2_GATHER_CONV", "1") == "1"
 _REPL = 8                         # PN2_STAT_REPLICAS of include/pn2.h
 _MALL_CHUNK_BYTES = 1 << 62       # row-chunked dgrad+wgrad pairing is OFF: measured 10.9 -> 13.1 ms/step at 96 MiB chunks
                                   # (per-launch fixed costs beat the Infinity-Cache hits); kept as a tuning knob
@@ -462,7 +464,7 @@ class _SharedMLP(torch.autograd.Function):
         if geom is None:
             P = rows.shape[0]
         else:
-            g_xyz, g_new, g_idx, g_first, g_inv = geom
+            g_xyz, g_new, g_idx, g_first, g_inv = geom[:5]
             gB, gN, gD = rows.shape
             gS, gK = g_idx.shape[1], g_idx.shape[2]
             P = gB * gS * gK
@@ -477,6 +479,8 @@ class _SharedMLP(torch.autograd.Function):
         aff_off = 0
         x, ldx, x_aff, off = rows, rows.shape[-1], None, 0
         pool_ws = None
+        gather = geom is not None and len(geom) > 5 and bool(geom[5])      # (xyz, new_xyz, idx, xyz_first, None, True)
+        gathered = None
         for l in range(L):
             w, b, gamma, beta, rmean, rvar, nbt = flat[7 * l:7 * l + 7]
             co, ci = chans[l + 1], chans[l]
@@ -489,7 +493,13 @@ class _SharedMLP(torch.autograd.Function):
             if training and FUSED_BN_TAILS:     # the producer of the statistics also turns them into the affine block
                 fin = ctypes.byref(_lib.BnFinalizeTail(tickets + 4 * l, _p(gamma), _p(beta), eps, mom, _p(rmean), _p(rvar),
                                                        _p(nbt), _p(aff)))
-            if l == 0 and geom is not None:
+            if l == 0 and gather:
+                # narrow first layer: gather + conv in one launch; the grouped rows are written once, for the backward
+                gathered = _empty_rows(P, ci, dev)
+                _check(lib.pn2_group_conv_fwd(_p(g_xyz), _p(rows), _p(g_new), _p(g_idx), gB, gN, gS, gK, gD, int(g_first),
+                                              _p(_contig_weight(w)), ci, _p(b), _p(gathered), gathered.shape[1], _p(y), y.shape[1], co,
+                                              _p(st_l), st), "pn2_group_conv_fwd")
+            elif l == 0 and geom is not None:
                 # the kernels read the xyz / feature columns straight out of the [co, 3+D] weight (pitch ci): no copies
                 w_ptr = _contig_weight(w).data_ptr()
                 wx_ptr, wf_ptr = (w_ptr, w_ptr + 12) if g_first else (w_ptr + 4 * gD, w_ptr)
@@ -537,6 +547,9 @@ class _SharedMLP(torch.autograd.Function):
                    "pn2_bn_relu_max")
         ctx.meta = (chans, pool, bool(training), P)
         ctx.geom = None if geom is None else (g_xyz, g_new, g_idx, bool(g_first), g_inv)   # index/coordinate tensors: no cycle
+        ctx.gather = (gB, gN, gD) if gather else None
+        if gather:
+            rows = gathered                     # what the backward reads as the first layer's input
         ctx.params = flat                       # leaf parameters / buffers (no grad_fn): no cycle either
         # save_for_backward (not ctx attributes): `out` is this node's own output, and holding it on ctx would close a
         # reference cycle that only the cyclic GC breaks -- gigabytes of saved activations would pile up for several
@@ -620,7 +633,7 @@ class _SharedMLP(torch.autograd.Function):
                                            _p(coef), _p(dgamma), _p(dbeta), int(direct), st), "pn2_bn_bwd_coef")
             if not direct:
                 grads[7 * l + 1], grads[7 * l + 2], grads[7 * l + 3] = dbias, dgamma, dbeta
-            if l == 0 and ctx.geom is not None:
+            if l == 0 and ctx.geom is not None and ctx.gather is None:
                 d_rows, dW0 = _SharedMLP._first_layer_bwd(ctx, rows, Ws[0], dZ, y, coef, co, ctx.needs_input_grad[0],
                                                           w_p.grad if direct else None)
                 grads[0] = dW0
@@ -685,6 +698,13 @@ class _SharedMLP(torch.autograd.Function):
                 grads[7 * l] = dW.view_as(Ws[l])
             if l > 0:
                 dZ = dx
+        if ctx.gather is not None and d_rows is not None:          # gradient of the grouped rows -> the gathered source points
+            gB, gN, gD = ctx.gather
+            g_idx = ctx.geom[2]
+            gp = torch.zeros(gB, gN, gD, device=dev, dtype=torch.float32)
+            _check(lib.pn2_group_bwd(_p(d_rows), _p(g_idx), gB, gN, g_idx.shape[1], g_idx.shape[2], gD, int(ctx.geom[3]),
+                                     d_rows.shape[1], _p(gp), st), "pn2_group_bwd")
+            d_rows = gp
         return (d_rows, None, None, None, None, None) + tuple(grads)
 
     @staticmethod
@@ -904,6 +924,11 @@ def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training, inv=
     if _factorised(D, len(convs), training):
         flat, cfg = _flat_params(convs, bns)
         return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx, xyz_first, inv), *flat)
+    if (GATHER_CONV and not FUSED_BN_TAILS and 1 <= D <= 9 and convs[0].out_channels in (32, 64) and (B * S * K) % 64 == 0 and new_xyz is not None and
+            idx is not None):
+        # narrow first layer (the sa1 stacks): pn2_group and the first conv are one launch (pn2_group_conv_fwd)
+        flat, cfg = _flat_params(convs, bns)
+        return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx.contiguous(), xyz_first, None, True), *flat)
     rows = _Group.apply(xyz, points, new_xyz, idx, S, K, xyz_first)
     return shared_mlp(rows, 3 + D, convs, bns, K, training)
 

@@ -542,3 +542,40 @@ def test_eval_network_fused_vs_oracle(dev):
         torch.manual_seed(4)
         b = net(pts.to(dev))
     assert float((a - b.cpu()).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.parametrize("K,co,D,xyz_first", [(16, 32, 6, False), (32, 64, 6, True), (64, 64, 3, False), (32, 64, 9, False)])
+def test_gather_conv_first_layer_equals_group_then_gemm(dev, K, co, D, xyz_first):
+    """pn2_group_conv_fwd (gather + first conv in one launch, the sa1 stacks) against pn2_group followed by the GEMM: same
+    grouped rows bit for bit, outputs and every gradient (weights, BatchNorm, the gathered features) within the GEMM-vs-fma
+    rounding of the first layer."""
+    import torch.nn as nn
+    from pointnet12_amd import _lib
+    gen = torch.Generator().manual_seed(K + co + D)
+    B, N, S = 2, 2048, 256
+    xyz = torch.rand(B, N, 3, generator=gen).to(dev)
+    pts = torch.randn(B, N, D, generator=gen).to(dev)
+    new_xyz = xyz[:, :S].contiguous()
+    idx = torch.randint(0, N, (B, S, K), generator=gen).to(dev)
+    convs = nn.ModuleList([nn.Conv2d(3 + D, co, 1), nn.Conv2d(co, 64, 1)]).to(dev)
+    bns = nn.ModuleList([nn.BatchNorm2d(co), nn.BatchNorm2d(64)]).to(dev)
+    res = {}
+    for flag in (True, False):
+        U.GATHER_CONV = flag
+        try:
+            for p in list(convs.parameters()) + list(bns.parameters()):
+                p.grad = None
+            f = pts.clone().requires_grad_(True)
+            with _lib.call_profile() as calls:
+                out = U.grouped_mlp(xyz, f, new_xyz, idx, xyz_first, convs, bns, True)
+            gw = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+            (out * gw).sum().backward()
+            res[flag] = (out.detach().clone(), f.grad.clone(), [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())],
+                         [c[0] for c in calls])
+        finally:
+            U.GATHER_CONV = True
+    assert "pn2_group_conv_fwd" in res[True][3] and "pn2_group" not in res[True][3]
+    assert "pn2_group" in res[False][3] and "pn2_group_conv_fwd" not in res[False][3]
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5 * float(res[False][0].abs().max())
+    for a, b in zip([res[True][1]] + res[True][2], [res[False][1]] + res[False][2]):
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6)
