@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 5
+#define PN2_ABI_VERSION 6
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -229,6 +229,11 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
 int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
                         const float *affine, int64_t G, int K, int C, float *dZp, double *red,
                         const pn2_bn_coef_tail *tail, pn2_stream_t stream);
+/* The same with the incoming gradient at a pitch of its own (ld_dout >= C, any alignment): a column slice of a wider gradient
+ * matrix -- what autograd hands a branch of a concatenated output -- is read in place instead of being copied out first. */
+int pn2_pool_bwd_reduce_ld(const float *dOut, int ld_dout, const float *out, int ldo, const int32_t *arg, const float *Y, int ldy,
+                           const float *affine, int64_t G, int K, int C, float *dZp, double *red, const pn2_bn_coef_tail *tail,
+                           pn2_stream_t stream);
 /* Backward, dense (FP) last layer: dZ = dOut * (out > 0) written to dZ [P, ldz] (its pad columns
  * C .. round4(C)-1 are written as zeros); same reductions. */
 int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "pn2_bn_finalize": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "pn2_bn_relu_max": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
     "pn2_pool_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "pn2_pool_bwd_reduce_ld": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_relu_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_bn_bwd_coef": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pn2_conv1x1_dgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp,
@@ -62,7 +63,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PN2_EUNSUPPORTED = -3            # include/pn2.h
 DWX_REPLICAS = 32        # PN2_DWX_REPLICAS of include/pn2.h
 

@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restric
 }
 
 // red[c] += sum_g dZ, red[C+c] += sum_g dZ*yhat at the pooled positions.
-__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__restrict__ dOut, int ldo,
+__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__restrict__ dOut, int ldg, int ldo,
                                                               const float *__restrict__ out,
                                                               const int32_t *__restrict__ arg,
                                                               const float *__restrict__ Y, int ldy,
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
                 const int64_t g = g0 + u * stride;
                 const bool v = g < G && real;
                 o[u] = v ? out[g * ldo + c] : 0.f;
-                dz[u] = v ? dOut[g * ldo + c] : 0.f;
+                dz[u] = v ? dOut[g * ldg + c] : 0.f;
                 a4[u] = v ? arg[g * ldo + c] : 0;
             }
 #pragma unroll
@@ -1152,16 +1152,22 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
     return pn2_launch_status();
 }
 
-int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
-                        const float *affine, int64_t G, int K, int C, float *dZp, double *red, const pn2_bn_coef_tail *tail,
-                        pn2_stream_t stream) {
-    PN2_CHECK_ARG(dOut && out && arg && Y && affine && dZp && red && G > 0 && K > 0 && C > 0 && ldo >= ((C + 3) & ~3) &&
+int pn2_pool_bwd_reduce_ld(const float *dOut, int ld_dout, const float *out, int ldo, const int32_t *arg, const float *Y, int ldy,
+                           const float *affine, int64_t G, int K, int C, float *dZp, double *red, const pn2_bn_coef_tail *tail,
+                           pn2_stream_t stream) {
+    PN2_CHECK_ARG(dOut && out && arg && Y && affine && dZp && red && G > 0 && K > 0 && C > 0 && ldo >= ((C + 3) & ~3) && ld_dout >= C &&
                   coef_tail_ok(tail, red));
     int64_t gy = pn2_cdiv(G, 4 * 4);                    // one trip of four groups per thread where the grid allows
     if (gy > 1024) gy = 1024;                           // (x 8 reduction replicas: same-address queues of <= 128)
     hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((unsigned)pn2_cdiv((C + 3) & ~3, 64), (unsigned)gy), dim3(256), 0, pn2_s(stream), dOut,
-                       ldo, out, arg, Y, ldy, affine, (C + 3) & ~3, G, K, C, dZp, red, make_coef_tail(tail, G * K));
+                       ld_dout, ldo, out, arg, Y, ldy, affine, (C + 3) & ~3, G, K, C, dZp, red, make_coef_tail(tail, G * K));
     return pn2_launch_status();
+}
+
+int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
+                        const float *affine, int64_t G, int K, int C, float *dZp, double *red, const pn2_bn_coef_tail *tail,
+                        pn2_stream_t stream) {
+    return pn2_pool_bwd_reduce_ld(dOut, ldo, out, ldo, arg, Y, ldy, affine, G, K, C, dZp, red, tail, stream);
 }
 
 int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,

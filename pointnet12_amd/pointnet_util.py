@@ -570,11 +570,18 @@ class _SharedMLP(torch.autograd.Function):
         dev = rows.device
         cl = chans[-1]
         ldo = out.shape[1]
-        if ldo != cl:
-            g = torch.zeros_like(out)
-            g[:, :cl] = grad_out
-            grad_out = g
-        grad_out = grad_out.contiguous()
+        # The pooled branch reads the incoming gradient once, scalar-wise, at any pitch: a column slice of a wider matrix (a
+        # branch of a concatenated MSG output) or an un-padded [G, cl] matrix is passed in place -- no copy kernel at the head
+        # of the branch's backward chain.
+        ld_grad = ldo
+        if pool and grad_out.dim() == 2 and grad_out.stride(1) == 1 and grad_out.stride(0) >= cl and grad_out.dtype == torch.float32:
+            ld_grad = grad_out.stride(0)
+        else:
+            if ldo != cl:
+                g = torch.zeros_like(out)
+                g[:, :cl] = grad_out
+                grad_out = g
+            grad_out = grad_out.contiguous()
         n_red = _REPL * 2 * sum(chans[1:])
         direct = _direct_ok([ctx.params[7 * l + j] for l in range(L) for j in (0, 2, 3)])
         sizes = [4 * _r4(chans[l + 1]) + (0 if direct else chans[l + 1] * chans[l] + chans[l + 1]) for l in range(L)]
@@ -614,8 +621,8 @@ class _SharedMLP(torch.autograd.Function):
         dzp = None
         if pool:
             dzp = torch.empty_like(out)          # dOut masked by out > 0: the pooled form of dZ_L the GEMM loaders read
-            _check(lib.pn2_pool_bwd_reduce(_p(grad_out), ldo, _p(out), _p(arg), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]),
-                                           G, K, cl, _p(dzp), _p(red_L), coef_tail(L - 1), st), "pn2_pool_bwd_reduce")
+            _check(lib.pn2_pool_bwd_reduce_ld(_p(grad_out), ld_grad, _p(out), ldo, _p(arg), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]),
+                                              G, K, cl, _p(dzp), _p(red_L), coef_tail(L - 1), st), "pn2_pool_bwd_reduce_ld")
         else:
             dZ = _empty_rows(P, cl, dev)
             _check(lib.pn2_relu_bwd_reduce(_p(grad_out), ldo, _p(out), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), P, cl,
