@@ -278,6 +278,9 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
  * the whole launch.  Only for shapes pn2_res_supported() accepts (C_out, C_in multiples of 32, <= 128); training-mode
  * BatchNorm only (no dbias).  pn2_conv1x1_fwd picks the matching weight-resident forward kernel by itself. */
 int pn2_res_supported(int64_t P, int C_out, int C_in);
+/* 1 if pn2_conv1x1_bwd runs (P, C_out, C_in) with this dZ form (Kpool = 0: dense) and input (masked: BatchNorm + ReLU of the
+ * previous layer) in its fused kernel; 0: it would hand the layer to pn2_conv1x1_dgrad + pn2_conv1x1_wgrad. */
+int pn2_bwd_res_supported(int64_t P, int C_out, int C_in, int Kpool, int masked);
 int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool,
                     const float *Y, int ldy, const float *coef, const float *W, int ldw, const float *prev_Y,
                     int ld_prev, const float *prev_affine, float *dXout, int ldxo, double *prev_red, float *dW,

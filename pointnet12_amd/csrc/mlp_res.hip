@@ -801,6 +801,19 @@ extern "C" int pn2_res_supported(int64_t P, int C_out, int C_in) {
     return on && P >= res_min_rows() && P < (1LL << 31) && res_shape_ok(C_out, C_in);
 }
 
+// Whether pn2_conv1x1_bwd runs this layer in the fused kernel (the instantiation list of dispatch_bwd_res) rather than handing
+// it to the streamed dgrad + wgrad pair.  Kpool = 0: dense dZ; masked: the layer has a BatchNorm + ReLU input (prev_affine).
+extern "C" int pn2_bwd_res_supported(int64_t P, int C_out, int C_in, int Kpool, int masked) {
+    if (!pn2_res_supported(P, C_out, C_in)) return 0;
+    const int64_t tiles = P / RES_BM;
+    const auto is = [&](int co, int ci) { return C_out == co && C_in == ci; };
+    if (Kpool == 0 && masked) return is(32, 32) || is(64, 64) || is(96, 64) || (tiles >= 4096 && is(128, 128));
+    if (Kpool == 0) return tiles >= 4096 && is(128, 128);
+    if (masked && Kpool % 64 == 0) return is(128, 64) || is(128, 96);
+    if (masked && Kpool == 32) return is(64, 32) || is(128, 64);
+    return 0;
+}
+
 // Called by pn2_conv1x1_fwd (mlp.hip) for supported shapes when no fused BatchNorm tail is requested; P % 32 == 0.
 int pn2_fwd_res(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
                 int64_t P, int K, int N, double *stats, hipStream_t s) {

@@ -652,7 +652,8 @@ class _SharedMLP(torch.autograd.Function):
             if not training and direct:
                 raise NotImplementedError("direct gradient accumulation with eval-mode BatchNorm: use autograd mode")
             need_dx = l > 0 or ctx.needs_input_grad[0]
-            if need_dx and training and not FUSED_BN_TAILS and lib.pn2_res_supported(P, co, ci):
+            if (need_dx and training and not FUSED_BN_TAILS and
+                    lib.pn2_bwd_res_supported(P, co, ci, K if pooled else 0, int(x_aff is not None))):
                 # narrow, long layer: dgrad + wgrad in ONE pass over dZ / Y / Y_prev, weights resident in LDS (mlp_res.hip)
                 dx = _empty_rows(P, ci, dev) if l > 0 else torch.empty(P, ldx, device=dev, dtype=torch.float32)
                 if l == 0:
