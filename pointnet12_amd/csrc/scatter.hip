@@ -138,7 +138,16 @@ __global__ __launch_bounds__(1024) void invert_lds_kernel(const int64_t *__restr
     for (int i = total + t; i < M; i += 1024) { mem[i] = -1; own[i] = -1; }     // dropped entries: "no member"
 }
 
-constexpr int kChunk = 16;            // members per lane group
+// Members per lane group: long chunks mean few segments straddle a boundary (those add atomically, the rest is stored), short
+// ones mean more lane groups in flight; 64 where that still leaves eight waves per CU, else 32 (four), else 16.  PN2_SEG_CHUNK: A/B.
+static int seg_chunk(int64_t members, int lanes_per_row) {
+    static const int forced = [] { const char *e = getenv("PN2_SEG_CHUNK"); return e ? atoi(e) : 0; }();
+    if (forced == 16 || forced == 32 || forced == 64) return forced;
+    const int64_t per_cu = (int64_t)pn2_num_cus() * (64 / lanes_per_row);           // lane groups of one wave per CU
+    if (members / 64 >= 8 * per_cu) return 64;                                       // (measured on the MSG / SSG level sizes:
+    if (members / 32 >= 4 * per_cu) return 32;                                       //  tools/bench_seg.py with PN2_SEG_CHUNK)
+    return 16;
+}
 
 __device__ __forceinline__ void row_atomic_add(float *dst, int c, int D, float4 v) {
     atomicAdd(dst + c, v.x);
@@ -147,13 +156,24 @@ __device__ __forceinline__ void row_atomic_add(float *dst, int c, int D, float4 
     if (c + 3 < D) atomicAdd(dst + c + 3, v.w);
 }
 
+// A segment (the members of one owner) that lies entirely inside one chunk has a single writer: its sum is STORED (the
+// buffer is zeroed for the owners without members and for the segments that straddle a chunk boundary, which still add
+// atomically).  With 64-member chunks over ~12-member segments that is 2 atomic rows per chunk instead of 6.
+__device__ __forceinline__ void row_flush(float *dst, int c, int D, float4 v, bool exclusive) {
+    if (!exclusive) { row_atomic_add(dst, c, D, v); return; }
+    dst[c] = v.x;
+    if (c + 1 < D) dst[c + 1] = v.y;
+    if (c + 2 < D) dst[c + 2] = v.z;
+    if (c + 3 < D) dst[c + 3] = v.w;
+}
+
 // 3-NN interpolation backward: dP2[b, s, :] += w[b, n, k] * dRows[b*N + n, col0 + :] for the members m = 3n + k of s.
 // LPR lanes (a power of two) hold one row as float4s; each lane group walks one chunk of the target-sorted members.
 __global__ __launch_bounds__(256) void three_interp_bwd_seg_kernel(const float *__restrict__ grad_out, int ld, int col0,
                                                                    const int *__restrict__ members,
                                                                    const int *__restrict__ owners,
                                                                    const float *__restrict__ w, int N, int S, int D,
-                                                                   int lpr_log2, int chunks_per_cloud, int64_t chunks,
+                                                                   int lpr_log2, int chunk, int chunks_per_cloud, int64_t chunks,
                                                                    float *__restrict__ grad_points2) {
     const int lane = threadIdx.x & 63;
     const int LPR = 1 << lpr_log2;
@@ -162,14 +182,18 @@ __global__ __launch_bounds__(256) void three_interp_bwd_seg_kernel(const float *
     if (q >= chunks) return;
     const int64_t b = q / chunks_per_cloud;
     const int M = N * 3;
-    const int e0 = (int)(q - b * chunks_per_cloud) * kChunk;
-    const int e1 = e0 + kChunk < M ? e0 + kChunk : M;
+    const int e0 = (int)(q - b * chunks_per_cloud) * chunk;
+    const int e1 = e0 + chunk < M ? e0 + chunk : M;
     const int *mem = members + b * M, *own = owners + b * M;
     const float *wb = w + b * (int64_t)M;
     const bool vec = ((ld | col0) & 3) == 0;
+    const int head = own[e0];
+    const bool head_shared = e0 > 0 && own[e0 - 1] == head;       // the chunk starts inside a segment
+    const int tail_next = e1 < M ? own[e1] : -1;                   // the owner the next chunk starts with
     for (int c = sub * 4; c < D; c += LPR * 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int cur = -1;
+        bool first = true;                                         // `cur` is the chunk's first segment
         for (int e = e0; e < e1; e += 4) {
             int m[4], tg[4];
             float wt[4];
@@ -199,7 +223,10 @@ __global__ __launch_bounds__(256) void three_interp_bwd_seg_kernel(const float *
             for (int u = 0; u < 4; ++u) {
                 if (m[u] < 0) continue;
                 if (tg[u] != cur) {
-                    if (cur >= 0) row_atomic_add(grad_points2 + (b * S + cur) * D, c, D, acc);
+                    if (cur >= 0) {
+                        row_flush(grad_points2 + (b * S + cur) * D, c, D, acc, !(first && head_shared));
+                        first = false;
+                    }
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     cur = tg[u];
                 }
@@ -207,7 +234,7 @@ __global__ __launch_bounds__(256) void three_interp_bwd_seg_kernel(const float *
                 acc.z = __builtin_fmaf(g[u].z, wt[u], acc.z); acc.w = __builtin_fmaf(g[u].w, wt[u], acc.w);
             }
         }
-        if (cur >= 0) row_atomic_add(grad_points2 + (b * S + cur) * D, c, D, acc);
+        if (cur >= 0) row_flush(grad_points2 + (b * S + cur) * D, c, D, acc, !(first && head_shared) && cur != tail_next);
     }
 }
 
@@ -221,7 +248,7 @@ __global__ __launch_bounds__(256) void group_affine_bwd_seg_kernel(const float *
                                                                    const float *__restrict__ new_xyz,
                                                                    const int *__restrict__ members,
                                                                    const int *__restrict__ owners, int N, int S, int K,
-                                                                   int C, int lpr_log2, int chunks_per_cloud,
+                                                                   int C, int lpr_log2, int chunk, int chunks_per_cloud,
                                                                    int64_t chunks, float *__restrict__ G, int ldg,
                                                                    float *__restrict__ dWx, int ldwx,
                                                                    float *__restrict__ rep) {
@@ -242,11 +269,14 @@ __global__ __launch_bounds__(256) void group_affine_bwd_seg_kernel(const float *
     for (int64_t q = ((int64_t)blockIdx.x * 4 + (t >> 6)) * GPW + (lane >> lpr_log2); q < chunks; q += qstride) {
         if (!cv) continue;
         const int64_t b = q / chunks_per_cloud;
-        const int e0 = (int)(q - b * chunks_per_cloud) * kChunk;
-        const int e1 = e0 + kChunk < M ? e0 + kChunk : M;
+        const int e0 = (int)(q - b * chunks_per_cloud) * chunk;
+        const int e1 = e0 + chunk < M ? e0 + chunk : M;
         const int *mem = members + b * M, *own = owners + b * M;
+        const bool head_shared = e0 > 0 && own[e0 - 1] == own[e0];
+        const int tail_next = e1 < M ? own[e1] : -1;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int cur = -1;
+        bool first = true;
         for (int e = e0; e < e1; e += 4) {
             int m[4], src[4];
             float4 dz[4], y[4];
@@ -274,7 +304,10 @@ __global__ __launch_bounds__(256) void group_affine_bwd_seg_kernel(const float *
             for (int u = 0; u < 4; ++u) {
                 if (m[u] < 0) continue;
                 if (src[u] != cur) {
-                    if (cur >= 0) row_atomic_add(G + (b * N + cur) * ldg, c, C4, acc);
+                    if (cur >= 0) {
+                        row_flush(G + (b * N + cur) * ldg, c, C4, acc, !(first && head_shared));
+                        first = false;
+                    }
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     cur = src[u];
                 }
@@ -292,7 +325,7 @@ __global__ __launch_bounds__(256) void group_affine_bwd_seg_kernel(const float *
                 }
             }
         }
-        if (cur >= 0) row_atomic_add(G + (b * N + cur) * ldg, c, C4, acc);
+        if (cur >= 0) row_flush(G + (b * N + cur) * ldg, c, C4, acc, !(first && head_shared) && cur != tail_next);
     }
     // fold dWx over the workgroup: threads with the same `sub` own the same four channels
 #pragma unroll
@@ -360,11 +393,12 @@ int pn2_three_interp_bwd_seg(const float *grad_out, int ld, int col0, const int3
                   ld >= col0 + D);
     int lpr_log2 = 0;
     while ((4 << lpr_log2) < D && lpr_log2 < 6) ++lpr_log2;       // lanes per row (float4 each), at most a wave
-    const int cpc = (int)pn2_cdiv((int64_t)N * 3, kChunk);
+    const int chunk = seg_chunk((int64_t)B * N * 3, 1 << lpr_log2);
+    const int cpc = (int)pn2_cdiv((int64_t)N * 3, chunk);
     const int64_t chunks = (int64_t)B * cpc;
     const int64_t waves = pn2_cdiv(chunks, 64 >> lpr_log2);
     hipLaunchKernelGGL(three_interp_bwd_seg_kernel, dim3((unsigned)pn2_cdiv(waves, 4)), dim3(256), 0, pn2_s(stream), grad_out, ld,
-                       col0, members, owners, weight, N, S, D, lpr_log2, cpc, chunks, grad_points2);
+                       col0, members, owners, weight, N, S, D, lpr_log2, chunk, cpc, chunks, grad_points2);
     return pn2_launch_status();
 }
 
@@ -378,12 +412,13 @@ int pn2_group_affine_bwd_seg(const float *dZ, int ldz, const float *Y, int ldy, 
     int lpr_log2 = 0;
     while ((4 << lpr_log2) < C && lpr_log2 < 6) ++lpr_log2;
     const int C4 = (C + 3) & ~3;
-    const int cpc = (int)pn2_cdiv((int64_t)S * K, kChunk);
+    const int chunk = seg_chunk((int64_t)B * S * K, 1 << lpr_log2);
+    const int cpc = (int)pn2_cdiv((int64_t)S * K, chunk);
     const int64_t chunks = (int64_t)B * cpc;
     int64_t blocks = pn2_cdiv(pn2_cdiv(chunks, 64 >> lpr_log2), 4);
     if (blocks > 1024) blocks = 1024;                  // every workgroup ends with 3*C atomics for dWx
     hipLaunchKernelGGL(group_affine_bwd_seg_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), dZ, ldz, Y, ldy, coef,
-                       C4, xyz, new_xyz, members, owners, N, S, K, C, lpr_log2, cpc, chunks, G, ldg, dWx, ldwx, dwx_scratch);
+                       C4, xyz, new_xyz, members, owners, N, S, K, C, lpr_log2, chunk, cpc, chunks, G, ldg, dWx, ldwx, dwx_scratch);
     if (dwx_scratch)
         hipLaunchKernelGGL(dwx_fold_kernel, dim3(1), dim3(256), 0, pn2_s(stream), dwx_scratch, C, C4, dWx, ldwx);
     return pn2_launch_status();
