@@ -1085,6 +1085,12 @@ bool coef_tail_ok(const pn2_bn_coef_tail *t, const double *red) {
 
 int pn2_fwd_res(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
                 int64_t P, int K, int N, double *stats, hipStream_t s);      // mlp_res.hip
+// mlp_wide.hip: register-stationary kernels for the wide layers; *rows_done = the leading rows they covered (whole tiles)
+int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
+                 int64_t P, int K, int N, double *stats, hipStream_t s, int64_t *rows_done);
+int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
+                   const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev, const float *prev_affine,
+                   float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, hipStream_t s, int64_t *rows_done);
 
 extern "C" {
 
@@ -1092,6 +1098,14 @@ int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float
                     int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin, pn2_stream_t stream) {
     PN2_CHECK_ARG(X && W && bias && Y && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && fin_tail_ok(fin, stats));
     PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= round4(K) && ldw >= K && ldy % 4 == 0 && ldy >= round4(N));
+    if (fin == nullptr) {                                               // wide layer: W stays in registers (mlp_wide.hip)
+        int64_t done = 0;
+        const int rc = pn2_wide_fwd(X, ldx, in_affine, W, ldw, bias, Y, ldy, P, K, N, stats, pn2_s(stream), &done);
+        if (rc != PN2_EUNSUPPORTED) {
+            if (rc != PN2_OK || done == P) return rc;
+            X += done * ldx; Y += done * ldy; P -= done;                // ragged tail: the streamed kernel below
+        }
+    }
     if (fin == nullptr && pn2_res_supported(P, N, K) && ldy >= N) {      // narrow, long layer: W stays in LDS (mlp_res.hip)
         const int64_t P_full = P & ~(int64_t)31;                        // whole 32-row slabs there, a ragged tail below
         const int rc = pn2_fwd_res(X, ldx, in_affine, W, ldw, bias, Y, ldy, P_full, K, N, stats, pn2_s(stream));
@@ -1200,6 +1214,18 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     PN2_CHECK_ARG(prev_Y == nullptr || prev_affine != nullptr);
     const int K4 = round4(K), ldc = round4(K);
     hipStream_t s = pn2_s(stream);
+    if (prev_tail == nullptr && prev_Y != nullptr) {                    // wide layer: W stays in registers (mlp_wide.hip)
+        int64_t done = 0;
+        const int rc = pn2_wide_dgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, W, ldw, prev_Y, ld_prev, prev_affine, dXout, ldxo,
+                                      prev_red, P, K, N, s, &done);
+        if (rc != PN2_EUNSUPPORTED) {
+            if (rc != PN2_OK || done == P) return rc;
+            // ragged tail (whole pooling groups: the tile height divides Kpool or is a multiple of it)
+            if (dZ) dZ += done * ldz;
+            else { dZp += (done / Kpool) * ldo; arg += (done / Kpool) * ldo; }
+            Y += done * ldy; prev_Y += done * ld_prev; dXout += done * ldxo; P -= done;
+        }
+    }
     if (dZ) {
         PN2_CHECK_ARG(ldz % 4 == 0 && ldz >= K4);
         LoadDyDense ld{dZ, ldz, Y, ldy, coef, ldc, zero_page_dev()};

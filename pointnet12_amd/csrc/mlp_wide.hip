@@ -1,0 +1,422 @@
+// Register-stationary shared-MLP GEMMs for the WIDE layers (C_in or C_out above 128, or both 128: the sa2 / FP / head stacks
+// of the segmentation networks -- model/pointnet_util.py:197,254,312 at the widths of model/pointnet2.py:109-114,145-153):
+//   pn2_conv1x1_fwd   -> regw_nt_kernel<..., EPI_FWD>     Y  = act(X) W^T + b, BatchNorm statistics
+//   pn2_conv1x1_dgrad -> regw_nt_kernel<..., EPI_MASK>    dX = dY W masked by the previous ReLU, its BatchNorm-backward sums
+//
+// Why a third GEMM family.  The streamed kernels of mlp.hip restage the WEIGHT tile through LDS for every 64-row tile and
+// synchronise their four waves every 16 MFMAs; the weight-resident kernels of mlp_res.hip need W in LDS (<= 128 x 128).  On a
+// tall, skinny product the weights are the operand that never changes, so here they never move at all:
+//   * every wave owns ONE 32-column block of the output for the whole launch and holds its slice of W as the B operand of
+//     v_mfma_f32_32x32x2_f32 in REGISTERS (K/2 per lane: 64 .. 128), loaded once;
+//   * the activations (the only streamed operand) go through LDS in 64-deep chunks shared by all waves of the workgroup:
+//     one barrier per chunk and 64 .. 128 MFMAs per wave between barriers (round 3 measurements, tools/exp/regw_nt.hip: a
+//     barrier interval costs 1 000 - 1 500 cycles of matrix-pipe idle when both waves of a SIMD stage at the same time, so the
+//     staging of chunk c + 1 is spread between the MFMA groups of chunk c and the intervals are long);
+//   * LDS holds nothing but two activation chunks: 70 KB, whatever K and N are.
+// The chip holds ~2.0 GHz under this load (GRBM_GUI_ACTIVE / 8 / time), i.e. ~131 TF is the ceiling these kernels see.
+//
+// Whole BM-row tiles only; the entry points of mlp.hip hand a ragged tail to the streamed kernels.
+#include "mlp_loaders.h"
+
+namespace {
+
+enum { MODE_PLAIN = 0, MODE_BNRELU = 1, MODE_DYDENSE = 2, MODE_DYPOOLED = 3 };
+enum { EPI_FWD = 0, EPI_MASK = 1, EPI_STORE = 2 };
+
+struct RegwArgs {
+    // streamed operand: X (forward) or this layer's pre-BN output Y (dgrad), [P, lda]
+    const float *A; int lda;
+    const float *dZ; int ldz;                                      // MODE_DYDENSE
+    const float *dZp; const int32_t *arg; int ldo; int kshift;     // MODE_DYPOOLED: [G, ldo], Kpool = 1 << kshift
+    const float *tab;                                              // MODE_BNRELU: affine block of the input (rows mean, scale, beta of
+                                                                   // pitch K4); dgrad: coef rows c0, q1, q0, mean of pitch K4
+    const float *W; int ldw;                                       // forward: [N, K] rows; dgrad (BNN): [K, N] rows
+    const float *bias;                                             // EPI_FWD
+    float *Out; int ldout;                                         // Y or dX
+    const float *prevY; int ldp; const float *prev_aff;            // EPI_MASK: previous layer's pre-BN output and affine block (pitch N4)
+    double *red;                                                   // EPI_FWD: stats; EPI_MASK: prev_red (replicated, may be null)
+    int64_t tiles; int K; int N;
+};
+
+extern __shared__ __attribute__((aligned(16))) float wide_lds[];
+
+// K4: row length of the streamed operand in floats (a multiple of 4, >= K).  NCB: 32-column blocks of the output (one per wave
+// column), RS: row splits (waves = NCB * RS), TM: 32-row blocks per wave; workgroup tile BM = 32 * TM * RS rows x 32 * NCB.
+template <int K4, int NCB, int RS, int TM, int KC, int MODE, int EPI, bool BNN, int PKP, bool ADB>
+__global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g) {
+    constexpr int KP = (K4 + 7) & ~7, NT = 64 * NCB * RS, BM = 32 * TM * RS, LDP = KC + 4, NCH = (KP + KC - 1) / KC;
+    constexpr int NTAB = MODE == MODE_PLAIN ? 0 : (MODE == MODE_BNRELU ? 3 : 4);
+    constexpr bool DY = MODE == MODE_DYDENSE || MODE == MODE_DYPOOLED;
+    static_assert(KC % 8 == 0 && K4 % 4 == 0, "chunk / row geometry");
+    // chunk c: k in [c * KC, c * KC + 4 * QT(c)); QV(c) of its QT(c) float4 quads exist in memory, the rest (k >= K4, at most
+    // one quad of the last chunk) are written as zeros
+    auto QT = [](int c) constexpr { return ((KP - c * KC) < KC ? (KP - c * KC) : KC) / 4; };
+    auto QV = [](int c) constexpr { return ((K4 - c * KC) < KC ? (K4 - c * KC) : KC) / 4; };
+    constexpr int A_IT = (BM * (KC / 4) + NT - 1) / NT;            // staging items (float4 of one row) per thread, widest chunk
+    // Pooled dZ (dZ[g * Kp + kk, c] = dZp[g, c] if kk == arg[g, c]): a thread's items all sit in the same channel quad
+    // (NT % (KC / 4) == 0, every chunk full), (NT / (KC / 4)) rows apart, so the (dZp, arg) quads repeat per GROUP:
+    // NZ distinct ones per thread and chunk instead of A_IT.
+    constexpr bool POOLED = MODE == MODE_DYPOOLED;
+    constexpr int RPI = NT / (KC / 4);                              // rows between a thread's consecutive items
+    static_assert(!POOLED || (PKP > 0 && (PKP & (PKP - 1)) == 0 && NT % (KC / 4) == 0 && K4 % KC == 0 && (BM <= PKP || PKP % RPI == 0)),
+                  "pooled loader geometry");
+    constexpr int NZ = !POOLED ? 1 : (BM <= PKP ? 1 : (RPI * (A_IT - 1)) / (PKP > 0 ? PKP : 1) + 1);
+    auto zslot = [](int i) constexpr { return BM <= PKP ? 0 : (RPI * i) / (PKP > 0 ? PKP : 1); };
+
+    float *As0 = wide_lds, *As1 = wide_lds + BM * LDP;
+    float *tab = wide_lds + 2 * BM * LDP;                           // NTAB rows of KP floats
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int cb = wave % NCB, rs = wave / NCB;
+    const int n = cb * 32 + l31;                                    // this lane's output column
+    const int N = g.N, K = g.K;
+
+    // ---- one-time: this lane's slice of W, the B operand of every MFMA it issues: w[4 kb + e] = W(n, k = 8 kb + 4 lh + e)
+    float w[KP / 2];
+    if (BNN) {                                                      // W stored [K, N]: consecutive lanes on consecutive n
+#pragma unroll
+        for (int kb = 0; kb < KP / 8; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * kb + 4 * lh + e;
+                w[kb * 4 + e] = (n < N && k < K) ? g.W[(int64_t)k * g.ldw + n] : 0.f;
+            }
+    } else {
+        // W stored [N, K]: a lane's values lie along a row, 32 lanes on 32 rows.  Read straight from global that is 32 cache
+        // lines per instruction and a 4x over-fetch from L2 (measured: 10+ us of fixed cost per launch).  Instead every wave
+        // copies its 32 rows chunk by chunk into a private LDS region with coalesced reads and picks its operands from there.
+        float *reg = wide_lds + wave * (32 * LDP);                  // NCB * RS * 32 <= 2 * BM rows: inside the chunk buffers
+        const bool vec = (g.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(g.W) & 15) == 0 && (K & 3) == 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            constexpr int dummy = 0; (void)dummy;
+            const int qt = QT(c);
+            if (vec) {
+                for (int idx = lane; idx < 32 * qt; idx += 64) {
+                    const int row = idx / qt, q = idx - row * qt, k = c * KC + 4 * q, nn = cb * 32 + row;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (nn < N && k < K) v = ld4(g.W + (int64_t)nn * g.ldw + k);
+                    *reinterpret_cast<float4 *>(&reg[row * LDP + 4 * q]) = v;
+                }
+            } else {
+                for (int idx = lane; idx < 32 * 4 * qt; idx += 64) {
+                    const int row = idx / (4 * qt), kk = idx - row * (4 * qt), k = c * KC + kk, nn = cb * 32 + row;
+                    reg[row * LDP + kk] = (nn < N && k < K) ? g.W[(int64_t)nn * g.ldw + k] : 0.f;
+                }
+            }
+            // same wave, LDS operations complete in order: no barrier between these writes and reads
+#pragma unroll
+            for (int kb = 0; kb < KC / 8; ++kb)
+                if (kb < qt / 2) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&reg[l31 * LDP + 8 * kb + 4 * lh]);
+                    const int wi = (c * (KC / 8) + kb) * 4;
+                    w[wi] = v.x; w[wi + 1] = v.y; w[wi + 2] = v.z; w[wi + 3] = v.w;
+                }
+        }
+        __syncthreads();                                            // the regions alias the chunk buffers
+    }
+    for (int i = t; i < NTAB * KP; i += NT) {
+        const int r = i / KP, k = i - r * KP;
+        tab[i] = k < K4 ? g.tab[r * K4 + k] : 0.f;
+    }
+
+    // ---- per-lane epilogue constants (the lane's column never changes)
+    const int N4 = (N + 3) & ~3;
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;                   // EPI_FWD: bias; EPI_MASK: mean, scale, beta, invstd of column n
+    if (EPI == EPI_FWD) e0 = n < N ? g.bias[n] : 0.f;
+    if (EPI == EPI_MASK && n < N4) {
+        Affine a(g.prev_aff, N4);
+        e0 = a.mean[n]; e1 = a.scale[n]; e2 = a.beta[n]; e3 = a.invstd[n];
+    }
+    double st0 = 0.0, st1 = 0.0;
+
+    // ---- streamed operand: raw registers of one chunk in flight, turned into operand values when staged
+    struct Raw { float4 y[A_IT]; float4 z[POOLED ? NZ : (DY ? A_IT : 1)]; int4 a[NZ]; };
+    Raw raw;
+    const int64_t tiles = g.tiles;
+    const int G = gridDim.x;
+    // item i of chunk c: idx = t + NT * i over BM rows x QT(c) quads; row = idx / QT, q = idx % QT
+    auto fetch_item = [&](int64_t tile, int c, int i) {
+        const int qt = QT(c), qv = QV(c);
+        const unsigned tl = (unsigned)(tile < tiles ? tile : tiles - 1);      // past the end: re-read the last tile (never used)
+        if (POOLED && (i == A_IT - 1 || zslot(i + 1) != zslot(i))) {
+            // The (dZp, arg) quad of a group is shared by all of the thread's items in that group: it is requested behind
+            // the LAST of them (the items of the chunk being staged still read the previous one), by every thread, from
+            // the row of the group's first item (always inside the tile; the last pass of a chunk may be partly filled).
+            int i0 = i;
+            while (i0 > 0 && zslot(i0 - 1) == zslot(i)) --i0;
+            const int idx0 = t + NT * i0, row0 = idx0 / qt, q0 = idx0 - row0 * qt;
+            const unsigned grp = (tl * BM + row0) / (unsigned)(PKP > 0 ? PKP : 1);
+            raw.z[POOLED ? zslot(i) : 0] = ld4(g.dZp + row_off(grp, g.ldo) + c * KC + 4 * q0);
+            raw.a[POOLED ? zslot(i) : 0] = ld4i(g.arg + row_off(grp, g.ldo) + c * KC + 4 * q0);
+        }
+        const int idx = t + NT * i, row = idx / qt, q = idx - row * qt;
+        if (NT * i >= BM * qt) return;                                   // static: this chunk has fewer items
+        if (NT * (i + 1) > BM * qt && idx >= BM * qt) return;            // the last, partly filled pass
+        const unsigned qq = q < qv ? q : qv - 1;                               // a pad quad re-reads the last valid one (zeroed when staged)
+        const unsigned m = tl * BM + row;
+        const int k = c * KC + 4 * qq;
+        raw.y[i] = ld4(g.A + row_off(m, g.lda) + k);
+        if (MODE == MODE_DYDENSE) raw.z[DY ? i : 0] = ld4(g.dZ + row_off(m, g.ldz) + k);
+    };
+    auto stage_item = [&](float *dst, int64_t tile, int c, int i) {
+        const int qt = QT(c), qv = QV(c);
+        const int idx = t + NT * i, row = idx / qt, q = idx - row * qt;
+        if (NT * i >= BM * qt) return;                                   // static: this chunk has fewer items
+        if (NT * (i + 1) > BM * qt && idx >= BM * qt) return;            // the last, partly filled pass
+        const int k = c * KC + 4 * q;
+        float4 x = raw.y[i];
+        if (MODE == MODE_BNRELU) {
+            const float4 mu = *reinterpret_cast<const float4 *>(&tab[k]);
+            const float4 sc = *reinterpret_cast<const float4 *>(&tab[KP + k]);
+            const float4 be = *reinterpret_cast<const float4 *>(&tab[2 * KP + k]);
+            x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
+            x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+            x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
+            x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+        }
+        if (DY) {
+            const DyParams dp = dy_params_tab(tab, KP, k, true);
+            float4 dz = raw.z[POOLED ? zslot(i) : (DY ? i : 0)];
+            if (POOLED) {
+                const int4 a = raw.a[POOLED ? zslot(i) : 0];
+                const int kk = (int)(((unsigned)(tile < tiles ? tile : tiles - 1) * BM + row) & (unsigned)(PKP - 1));
+                dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f;
+                dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
+            }
+            x = dy_from(dz, x, dp);
+        }
+        if (qv != qt && q >= qv) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(&dst[row * LDP + 4 * q]) = x;
+    };
+
+    int64_t tile = blockIdx.x;
+    float *cur = As0, *nxt = As1;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) fetch_item(tile, 0, i);
+    __syncthreads();                                                // table complete (and the W regions released)
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) stage_item(cur, tile, 0, i);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        if (NCH > 1) fetch_item(tile, 1, i); else fetch_item(tile + G, 0, i);
+    }
+
+    while (tile < tiles) {
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            __syncthreads();                                        // chunk c is in `cur`; every wave is done with `nxt`
+            const int kbs = QT(c) / 2;                              // 8-wide k blocks of this chunk (static after unrolling)
+            const bool last = c == NCH - 1;
+            const int64_t t1 = last ? tile + G : tile;              // the chunk staged during this one ...
+            const int c1 = last ? 0 : c + 1;
+            const bool last1 = c1 == NCH - 1;
+            const int64_t t2 = last1 ? t1 + G : t1;                 // ... and the one requested
+            const int c2 = last1 ? 0 : c1 + 1;
+            const float *ap = cur + (rs * TM * 32 + l31) * LDP + 4 * lh;
+            // Operand reads run one k block ahead of the MFMAs that consume them (two register sets).  The memory clobbers pin
+            // the LDS / global operations to their k block: without them the compiler hoists every read of the chunk to its
+            // top (TM x 8 x 4 registers: spills) and sinks the staging behind the last MFMA, where both waves of a SIMD
+            // would do it at the same time with the matrix pipe idle.
+            float4 a[ADB ? 2 : 1][TM];
+            if (ADB) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4 *>(ap + i * 32 * LDP);
+            }
+#pragma unroll
+            for (int kb = 0; kb < KC / 8; ++kb) {
+                if (kb < kbs) {
+                    asm volatile("" ::: "memory");
+                    if (ADB && kb + 1 < kbs) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            a[ADB ? (kb + 1) & 1 : 0][i] = *reinterpret_cast<const float4 *>(ap + i * 32 * LDP + 8 * (kb + 1));
+                    }
+                    if (!ADB) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4 *>(ap + i * 32 * LDP + 8 * kb);
+                    }
+                    // staging item i of the next chunk rides behind k block i (the last items share the last block)
+#pragma unroll
+                    for (int i = 0; i < A_IT; ++i) {
+                        const int slot = i < kbs ? i : kbs - 1;
+                        if (slot == kb) {
+                            stage_item(nxt, t1, c1, i);
+                            fetch_item(t2, c2, i);
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const float4 av = a[ADB ? kb & 1 : 0][i];
+                        const int wi = (c * (KC / 8) + kb) * 4;
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w[wi + 0], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w[wi + 1], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w[wi + 2], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w[wi + 3], acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        // ---- epilogue straight from the accumulators: column on the lane, 128 contiguous bytes per half-wave and register.
+        // The lane offset is made opaque once per tile: loop-invariant addresses would otherwise be hoisted out of the tile
+        // loop into 2 x 16 x TM registers (and spilled).
+        {
+            const unsigned row0 = (unsigned)tile * BM + rs * TM * 32 + 4 * lh;
+            unsigned lo = (unsigned)n;
+            asm volatile("" : "+v"(lo));
+            float s0 = 0.f, s1 = 0.f;
+            if (EPI == EPI_FWD) {
+                float *yb = g.Out + row_off(row0, g.ldout);
+                unsigned off = lo;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float y = acc[i][r] + e0;
+                        if (n < N4) __builtin_nontemporal_store(y, yb + off);      // pad columns receive exact zeros (w = bias = 0)
+                        s0 += y;
+                        s1 = __builtin_fmaf(y, y, s1);
+                        off += ((r & 3) == 3 ? (r == 15 ? 5u : 5u) : 1u) * (unsigned)g.ldout;   // rows (r&3) + 8 (r>>2): +1 +1 +1 +5
+                    }
+            } else if (EPI == EPI_MASK) {
+                const float *pb = g.prevY + row_off(row0, g.ldp);
+                float *xb = g.Out + row_off(row0, g.ldout);
+                unsigned offp = lo, offx = lo;
+                asm volatile("" : "+v"(offx));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float pv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        pv[r] = n < N4 ? pb[offp] : 0.f;
+                        offp += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldp;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float y = pv[r];
+                        const float dz = bn_act(y, e0, e1, e2) > 0.f ? acc[i][r] : 0.f;   // pad columns: scale = beta = 0 -> 0
+                        if (n < N4) __builtin_nontemporal_store(dz, xb + offx);
+                        s0 += dz;
+                        s1 = __builtin_fmaf(dz, (y - e0) * e3, s1);
+                        offx += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldout;
+                    }
+                }
+            } else {
+                float *xb = g.Out + row_off(row0, g.ldout);
+                unsigned off = lo;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (n < N4) xb[off] = acc[i][r];
+                        off += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldout;
+                    }
+            }
+            if (EPI != EPI_STORE) { st0 += (double)s0; st1 += (double)s1; }
+        }
+        tile += G;
+    }
+    if (EPI != EPI_STORE && g.red != nullptr) {
+        st0 += __shfl_xor(st0, 32, 64);
+        st1 += __shfl_xor(st1, 32, 64);
+        if (lh == 0 && n < N) {
+            double *rep = g.red + (size_t)(blockIdx.x % PN2_STAT_REPLICAS) * 2 * N;
+            atomicAdd(rep + n, st0);
+            atomicAdd(rep + N + n, st1);
+        }
+    }
+}
+
+template <int K4, int NCB, int RS, int TM, int KC, int MODE, int EPI, bool BNN, int PKP = 0, bool ADB = true>
+int launch_regw(const RegwArgs &g, hipStream_t s) {
+    constexpr int KP = (K4 + 7) & ~7, BM = 32 * TM * RS, LDP = KC + 4;
+    constexpr int NTAB = MODE == MODE_PLAIN ? 0 : (MODE == MODE_BNRELU ? 3 : 4);
+    constexpr size_t lds = sizeof(float) * (2 * BM * LDP + NTAB * KP);
+    static_assert(BNN || NCB * RS * 32 <= 2 * BM, "the W staging regions must fit inside the chunk buffers");
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = regw_nt_kernel<K4, NCB, RS, TM, KC, MODE, EPI, BNN, PKP, ADB>;
+    static int raised_dev[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!raised_dev[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PN2_ELAUNCH;
+        raised_dev[dev] = 1;
+    }
+    const int64_t cap = pn2_num_cus();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles < cap ? g.tiles : cap)), dim3(64 * NCB * RS), lds, s, g);
+    return pn2_launch_status();
+}
+
+inline int wide_env(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------ dispatch
+// Shapes with an instantiation (every one is a fully unrolled kernel of its own).  Rows: whole tiles of BM; the caller runs
+// the remainder through the streamed kernels.  *bm_out = the tile height the instantiation uses.
+//
+// forward (K -> N):  128->128, 128->256, 128->196, 196->256         (sa2 of MSG, sa3 of SSG, the FP / head stacks)
+// dgrad  (C_out -> C_in):  128->128, 256->128, 196->128, 256->196
+#define PN2_WIDE_MIN_ROWS_DEFAULT 65536
+
+int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
+                 int64_t P, int K, int N, double *stats, hipStream_t s, int64_t *rows_done) {
+    static const int on = wide_env("PN2_WIDE", 1), min_rows = wide_env("PN2_WIDE_MIN_ROWS", PN2_WIDE_MIN_ROWS_DEFAULT);
+    *rows_done = 0;
+    if (!on || P < min_rows || ldx != ((K + 3) & ~3)) return PN2_EUNSUPPORTED;
+    RegwArgs g{};
+    g.A = X; g.lda = ldx; g.tab = in_affine; g.W = W; g.ldw = ldw; g.bias = bias; g.Out = Y; g.ldout = ldy; g.red = stats;
+    g.K = K; g.N = N;
+#define WIDE_FWD(KK, NN, NCB, RS, TM)                                                                                    \
+    if (K == KK && N == NN) {                                                                                            \
+        constexpr int BM = 32 * TM * RS;                                                                                 \
+        g.tiles = P / BM;                                                                                                \
+        *rows_done = g.tiles * BM;                                                                                       \
+        if (in_affine) return launch_regw<((KK + 3) & ~3), NCB, RS, TM, 64, MODE_BNRELU, EPI_FWD, false>(g, s);          \
+        return launch_regw<((KK + 3) & ~3), NCB, RS, TM, 64, MODE_PLAIN, EPI_FWD, false>(g, s);                          \
+    }
+    WIDE_FWD(128, 128, 4, 2, 2)
+    WIDE_FWD(128, 256, 8, 1, 4)
+    WIDE_FWD(128, 196, 7, 1, 4)
+    WIDE_FWD(196, 256, 8, 1, 4)
+#undef WIDE_FWD
+    return PN2_EUNSUPPORTED;
+}
+
+int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
+                   const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev, const float *prev_affine,
+                   float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, hipStream_t s, int64_t *rows_done) {
+    static const int on = wide_env("PN2_WIDE", 1), min_rows = wide_env("PN2_WIDE_MIN_ROWS", PN2_WIDE_MIN_ROWS_DEFAULT);
+    *rows_done = 0;
+    if (!on || P < min_rows || ldy != ((K + 3) & ~3) || prev_Y == nullptr) return PN2_EUNSUPPORTED;
+    if (!dZ && (Kpool <= 0 || P % Kpool != 0)) return PN2_EUNSUPPORTED;
+    RegwArgs g{};
+    g.A = Y; g.lda = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.kshift = 0; g.tab = coef;
+    g.W = W; g.ldw = ldw; g.Out = dXout; g.ldout = ldxo; g.prevY = prev_Y; g.ldp = ld_prev; g.prev_aff = prev_affine; g.red = prev_red;
+    g.K = K; g.N = N;
+#define WIDE_DGRAD(KK, NN, NCB, RS, TM, KC, PKP, ADB)                                                                    \
+    if (K == KK && N == NN && (PKP == 0 ? dZ != nullptr : (dZ == nullptr && Kpool == PKP))) {                           \
+        constexpr int BM = 32 * TM * RS;                                                                                 \
+        g.tiles = P / BM;                                                                                                \
+        *rows_done = g.tiles * BM;                                                                                       \
+        return launch_regw<((KK + 3) & ~3), NCB, RS, TM, KC, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, EPI_MASK, true, PKP, ADB>(g, s); \
+    }
+    WIDE_DGRAD(128, 128, 4, 2, 2, 64, 0, true)
+    WIDE_DGRAD(196, 128, 4, 2, 2, 64, 0, false)
+    WIDE_DGRAD(256, 128, 4, 2, 1, 128, 64, true)
+    WIDE_DGRAD(256, 128, 4, 2, 1, 128, 128, true)
+    WIDE_DGRAD(256, 196, 7, 1, 2, 64, 128, true)
+    WIDE_DGRAD(256, 196, 7, 1, 2, 64, 64, true)
+#undef WIDE_DGRAD
+    return PN2_EUNSUPPORTED;
+}

@@ -171,9 +171,11 @@ class GraphedStep:
             self.parity ^= 1
             self.feeds[i].stage()
             self.graphs[i].replay()
+            U.bump_param_generation()            # whatever the captured step wrote (BN buffers, an optimiser step)
             return self.losses[i]
         self.feed.stage()
         self.graph.replay()
+        U.bump_param_generation()
         return self.loss
 
 

@@ -21,6 +21,7 @@ gradient in every step.
 import torch
 
 from . import _lib
+from . import pointnet_util
 from .parallel import FlatGradBucket
 
 _p = _lib.ptr
@@ -116,6 +117,7 @@ class Adam(torch.optim.Optimizer):
                                          float(group["weight_decay"]), rec["t"], _p(rec["lr_dev"]), _p(rec["step_dev"]),
                                          int(self.fused_zero_grad), st), "pn2_adam_step")
         self._grads_clear = self.fused_zero_grad
+        pointnet_util.bump_param_generation()       # parameters written through raw pointers: eval-mode folds are stale
         return loss
 
     def zero_grad(self, set_to_none=False):

@@ -72,6 +72,8 @@ def broadcast_module(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+    from . import pointnet_util
+    pointnet_util.bump_param_generation()
 
 
 def shard_range(global_units, rank, world):

@@ -18,6 +18,7 @@ Layout notes
 """
 import contextlib
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -545,6 +546,8 @@ class _SharedMLP(torch.autograd.Function):
         else:
             _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), out.shape[1], _p(arg), st),
                    "pn2_bn_relu_max")
+        if training:
+            bump_param_generation()             # running statistics were written through raw pointers
         ctx.meta = (chans, pool, bool(training), P)
         ctx.geom = None if geom is None else (g_xyz, g_new, g_idx, bool(g_first), g_inv)   # index/coordinate tensors: no cycle
         ctx.gather = (gB, gN, gD) if gather else None
@@ -840,19 +843,39 @@ def shared_mlp(rows, c_in, convs, bns, pool, training):
 # (torch.no_grad() / inference_mode: the reference's viewer loop, pcdvis.py:118-136); PN2_FUSED_EVAL=0 keeps the
 # layer-by-layer kernels (A/B runs, and the path eval-mode autograd uses).
 FUSED_EVAL = os.environ.get("PN2_FUSED_EVAL", "1") == "1"
-_fold_cache = {}
+_fold_cache = weakref.WeakKeyDictionary()       # first conv of a stack -> fold entry (dies with the module: no id() aliasing)
+_PARAM_GEN = [0]
+
+
+def bump_param_generation():
+    """Tell the eval-mode fold cache that parameters or BatchNorm buffers MAY have been written behind autograd's back.
+
+    ``tensor._version`` only counts writes made through torch: the HIP library updates running statistics
+    (pn2_bn_finalize), parameters (pn2_adam_step) and everything a replayed hipGraph touches through raw pointers.
+    Every such path calls this (``_SharedMLP.forward`` in training mode, ``optim.Adam.step``, ``GraphedStep.replay``,
+    ``parallel.broadcast_module``); a fold made under an older generation is redone on its next use."""
+    _PARAM_GEN[0] += 1
 
 
 def _folded_layers(convs, bns):
     """(ctypes array of pn2_eval_layer, tensors kept alive) with W' = diag(gamma / sqrt(var + eps)) W and
-    b' = (b - mean) * gamma / sqrt(var + eps) + beta, computed in fp64, rows padded to round8(C_in); cached per weight version."""
-    key = tuple(id(m) for m in convs) + tuple(id(m) for m in bns)
+    b' = (b - mean) * gamma / sqrt(var + eps) + beta, computed in fp64, rows padded to round8(C_in).
+
+    Cached per stack.  An entry is fresh while the parameter generation (see bump_param_generation) and the autograd
+    versions of all six tensors per layer are unchanged; a stale entry is refreshed IN PLACE, so a hipGraph that captured a
+    pn2_fused_eval launch keeps reading valid memory and sees the new weights on its next replay (the pointers baked into
+    the graph never change for the lifetime of the module)."""
+    ids = tuple(id(m) for m in convs) + tuple(id(m) for m in bns)
     ver = tuple(int(t._version) for conv, bn in zip(convs, bns)
                 for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var))
-    hit = _fold_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1], hit[2]
-    keep, arr = [], (_lib.EvalLayer * len(convs))()
+    shapes = tuple((conv.weight.shape[0], conv.weight.numel() // conv.weight.shape[0], conv.weight.device) for conv in convs)
+    hit = _fold_cache.get(convs[0])
+    if hit is not None and hit["ids"] == ids and hit["shapes"] == shapes:
+        if hit["ver"] == ver and hit["gen"] == _PARAM_GEN[0]:
+            return hit["arr"], hit["keep"]
+        keep, arr = hit["keep"], hit["arr"]
+    else:
+        hit, keep, arr = None, [], (_lib.EvalLayer * len(convs))()
     for l, (conv, bn) in enumerate(zip(convs, bns)):
         co = conv.weight.shape[0]
         ci = conv.weight.numel() // co
@@ -860,12 +883,16 @@ def _folded_layers(convs, bns):
         w = conv.weight.detach().double().reshape(co, ci) * scale[:, None]
         b = (conv.bias.detach().double() - bn.running_mean.detach().double()) * scale + bn.bias.detach().double()
         ldw = (ci + 7) & ~7
-        wp = torch.zeros(co, ldw, device=w.device, dtype=torch.float32)
-        wp[:, :ci] = w.float()
-        bp = b.float().contiguous()
-        keep += [wp, bp]
-        arr[l].W, arr[l].bias, arr[l].K, arr[l].N, arr[l].ldw = wp.data_ptr(), bp.data_ptr(), ci, co, ldw
-    _fold_cache[key] = (ver, arr, keep)
+        if hit is None:
+            wp = torch.zeros(co, ldw, device=w.device, dtype=torch.float32)
+            bp = torch.empty(co, device=w.device, dtype=torch.float32)
+            keep += [wp, bp]
+            arr[l].W, arr[l].bias, arr[l].K, arr[l].N, arr[l].ldw = wp.data_ptr(), bp.data_ptr(), ci, co, ldw
+        else:
+            wp, bp = keep[2 * l], keep[2 * l + 1]
+        wp[:, :ci].copy_(w)                        # pad columns stay zero
+        bp.copy_(b)
+    _fold_cache[convs[0]] = {"ids": ids, "shapes": shapes, "ver": ver, "gen": _PARAM_GEN[0], "arr": arr, "keep": keep}
     return arr, keep
 
 

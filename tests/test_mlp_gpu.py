@@ -41,6 +41,10 @@ def torch_mlp(rows, convs, bns, pool, training, dtype):
     # 64-row tile inside one group, 96-wide blocks (three co / ci blocks: dW tiles split by row halves), a ragged tail
     # (P % 64 = 8), and K = 16 < tile rows (four groups per tile)
     (65536, 0, [128, 128, 64]), (131072, 64, [32, 64, 128]), (40008, 0, [96, 96, 32]), (65536, 16, [64, 96, 128]),
+    # the register-stationary family (csrc/mlp_wide.hip): the sa2 stacks of MSG-SemSeg -- forward 128->128 / 128->256 /
+    # 128->196 / 196->256, dgrad 256->128 and 256->196 on the max-pool's sparse dZ (groups of 64 and of 128), 196->128 and
+    # 128->128 dense -- with a ragged tail of whole groups behind the last full tile
+    (131072 + 192, 64, [128, 128, 128, 256]), (131072 + 128, 128, [128, 128, 196, 256]), (65536 + 64, 64, [32, 128, 196, 256]),
 ])
 def test_shared_mlp_vs_torch(dev, P, pool, chans):
     gen = torch.Generator().manual_seed(P + len(chans))
