@@ -34,6 +34,11 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+# C-ABI GEMM entry point -> kernel families of tools/pmc_traffic.py that serve it
+GEMM_FAMILIES = {"pn2_conv1x1_wgrad": ["gemm_tn_kernel", "wgrad_skinny_kernel"],
+                 "pn2_conv1x1_dgrad": ["gemm_nt_kernel<dgrad>", "regw_nt_kernel<dgrad>"],
+                 "pn2_conv1x1_bwd": ["gemm_bwd_fused_kernel"],
+                 "pn2_conv1x1_fwd": ["gemm_nt_kernel<fwd>", "fwd_res_kernel", "regw_nt_kernel<fwd>"]}
 
 WORKLOADS = {
     "msg": "PointNet2 MSG SemSeg (SetAbstractionMsg 3 radii + FeaturePropagation), B=16x4096x(3+6), fwd+bwd",
@@ -109,6 +114,9 @@ def build_net(workload, dev, npoint_scale=1):
 
 # SURVEY.md section 8(d), per input point: (ALG_BYTES, FLOP) of one forward + backward step at N = 4096 points per cloud
 STEP_MODEL = {"msg": (225604, 464.5e9 / 65536), "ssg": (55689, 92.8e9 / 65536), "sa": (20720, 5.28e9 / 32768)}
+# cfg5 of BASELINE.json (dense scan, B=8 x 65 536): MSG with npoint x16 (ALG_BYTES 118.13 GB, 3 716 GFLOP per step) and the
+# reference's SSG net with its fixed npoints (8.108 GB, 244.6 GFLOP), per input point
+STEP_MODEL_CFG5 = {("msg", 16): (118.13e9 / 524288, 3716e9 / 524288), ("ssg", 1): (8.108e9 / 524288, 244.6e9 / 524288)}
 
 
 def make_step(workload, net, pts, labels, bucket):
@@ -153,6 +161,40 @@ def _cpu_info():
         pass
     n_phys = len(phys) if phys else logical
     return model, max(1, min(n_phys, logical)), logical
+
+
+def cpu_baseline_slice(workload, batch, n_points, npoint_scale):
+    """cfg5 (dense scans): the reference algorithm needs > 100 GB for the [8, 8192, 65536] int64 sort of a whole batch, so the
+    CPU side runs ONE cloud (B = 1) with the reference's own ATen operator sequence and the result is extrapolated to the
+    batch ("cfg5 on CPU runs cloud-by-cloud"; BatchNorm statistics are then per cloud, which changes
+    no operator's cost).  One step, timed as it is (a second one would double a leg that already takes minutes)."""
+    import torch
+    from oracle import torch_ref as T
+    from pointnet12_amd import synthetic as syn
+    pts_np, lab_np = syn.kitti_batch(0, 1, n_points)
+    pts, lab = torch.from_numpy(pts_np), torch.from_numpy(lab_np)
+    T.set_geometry("aten")
+    torch.manual_seed(0)
+    net = T.RefMSGSemSeg(13, 6, npoint_scale=npoint_scale) if workload == "msg" else T.RefSSGSemSeg(13, 6)
+    net.train()
+    model, n_phys, logical = _cpu_info()
+    threads = min(8, logical)
+    saved = torch.get_num_threads()
+    try:
+        torch.set_num_threads(threads)
+        torch.manual_seed(1234)
+        t0 = time.perf_counter()
+        net.zero_grad()
+        T.seg_loss(net(pts), lab).backward()
+        secs = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(saved)
+        T.set_geometry("c")
+    return {"value": round(n_points / secs, 1), "unit": "points/s", "cores": threads, "kind": "port", "physical_cores": n_phys,
+            "logical_cpus": logical, "cpu_model": model, "s_per_cloud": round(secs, 2), "s_per_step_extrapolated": round(secs * batch, 1),
+            "sample": "ONE cloud of the batch (B=1 x %d pts; the reference's dense [B,S,N] matrices do not fit a whole batch), oracle "
+                      "net of oracle/torch_ref.py with the reference's ATen operator sequence for FPS / ball query / 3-NN, train mode, "
+                      "one cold step at %d threads; the batch of %d clouds costs %d x this" % (n_points, threads, batch, batch)}
 
 
 def cpu_baseline(workload, batch, budget_s=150.0):
@@ -242,28 +284,99 @@ def self_launch(n):
     sys.exit(rc if rc else (0 if lines else 1))
 
 
+def timed_protocol(step, all_reduce, fence, steps, warmup, world, dist, torch, dev=None):
+    """The rank protocol of the benchmark, shared by the real run and --dry-run: W untimed steps, fence (barrier + device
+    synchronise), exactly K timed steps, fence; every step = ``step()`` followed by the gradient ``all_reduce()``.  Returns
+    (elapsed of the SLOWEST rank, {"allreduce_ms", "rank_ms_per_step_min", "rank_ms_per_step_max"}): the collective is
+    timed on its own (HIP events on the stream it is issued from; wall clock on CPU) so that a scaling loss at N GPUs
+    can be attributed to it, and the per-rank spread shows a straggler."""
+    use_events = dev is not None
+    for _ in range(warmup):
+        step()
+        all_reduce()
+    fence()
+    marks = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        if use_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            all_reduce()
+            e1.record()
+            marks.append((e0, e1))
+        else:
+            a = time.perf_counter()
+            all_reduce()
+            marks.append(time.perf_counter() - a)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in marks) if use_events else sum(marks) * 1e3
+    info = {"allreduce_ms": round(ar_ms / max(steps, 1), 4)}
+    mine = elapsed / max(steps, 1) * 1e3
+    if world > 1:
+        t = torch.tensor([elapsed, -elapsed, ar_ms / max(steps, 1)], dtype=torch.float64, device=dev if use_events else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0].item())
+        info["rank_ms_per_step_min"] = round(-float(t[1].item()) / max(steps, 1) * 1e3, 3)
+        info["rank_ms_per_step_max"] = round(elapsed / max(steps, 1) * 1e3, 3)
+        info["allreduce_ms"] = round(float(t[2].item()), 4)                # the slowest rank's
+    else:
+        info["rank_ms_per_step_min"] = info["rank_ms_per_step_max"] = round(mine, 3)
+    return elapsed, info
+
+
 def dry_run(args, dist, torch):
-    """The rank protocol of a real run -- rendezvous, barrier, K timed (empty) steps, MAX over ranks, one JSON line from
-    rank 0 -- on CPU with the gloo backend."""
+    """The benchmark's rank protocol on CPU with gloo ranks and no GPU: the same ``timed_protocol`` as the real run around
+    the ORACLE SSG network (oracle/torch_ref.py, two small clouds per rank) accumulating into the real
+    ``parallel.FlatGradBucket`` (autograd mode) and its all-reduce -- rendezvous on 127.0.0.1, barrier, K timed steps, MAX
+    over ranks, one JSON line from rank 0 relayed by the parent (tests/test_bench_launch_cpu.py)."""
+    from oracle import torch_ref as T
+    from pointnet12_amd import parallel
+    from pointnet12_amd import synthetic as syn
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(0.001 * (rank + 1))               # uneven ranks: the reported time must be the slowest one's
-    elapsed = time.perf_counter() - t0
+    torch.set_num_threads(1)
+    per_rank = 2
+    lo, _ = parallel.shard_range(per_rank * world, rank, world)
+    pts_np, lab_np = syn.kitti_batch(lo, per_rank, 256)
+    pts, lab = torch.from_numpy(pts_np), torch.from_numpy(lab_np)
+    torch.manual_seed(rank)                          # different initial parameters per rank: the broadcast must fix that
+    net = T.RefSSGSemSeg(13, 6).train()
+    parallel.broadcast_module(net)
+    bucket = parallel.FlatGradBucket(net, direct=False)
+
+    def step():
+        bucket.zero()
+        torch.manual_seed(1234)
+        T.seg_loss(net(pts), lab).backward()
+        time.sleep(0.002 * rank)                     # uneven ranks: the reported time must be the slowest one's
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    elapsed, info = timed_protocol(step, bucket.all_reduce, fence, args.steps, args.warmup, world, dist, torch)
+    # every rank now holds the same averaged bucket and the same parameters
+    digest = torch.tensor([float(bucket.flat.double().abs().sum()), float(sum(p.double().abs().sum() for p in net.parameters()))],
+                          dtype=torch.float64)
+    same = True
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        hi, lo_ = digest.clone(), digest.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        same = bool(((hi - lo_).abs() <= 1e-9 * hi.abs()).all())
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "points/sec fwd+bwd, PointNet2 SemSeg B=16x4096 pts", "value": 0.0, "unit": "points/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "dry_run": True}))
+        line = {"metric": "points/sec fwd+bwd, PointNet2 SemSeg B=16x4096 pts", "value": 0.0, "unit": "points/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "dry_run": True,
+                "ranks_agree": same, "grad_bucket_bytes": bucket.nbytes}
+        line.update(info)
+        print(json.dumps(line))
 
 
 def main():
@@ -345,29 +458,15 @@ def main():
     else:
         graphed = compute
 
-    def step():
-        loss = graphed()
-        bucket.all_reduce()                          # the only collective of the path (no-op on one GPU)
-        return loss
-
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     torch.manual_seed(1234)                  # FPS start draws
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # one step = the graph replay, then the only collective of the path (no-op on one GPU), issued right behind it
+    elapsed, rank_info = timed_protocol(graphed, bucket.all_reduce, fence, args.steps, args.warmup, world if use_dist else 1,
+                                        dist, torch, dev)
     ms_per_step = elapsed / args.steps * 1e3
     value = batch * world * n_points * args.steps / elapsed
 
@@ -431,29 +530,53 @@ def main():
         # HBM traffic of that kernel family from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes), per launch.
         # The file carries the digest of the kernel sources it was collected with: a stale file is not quoted.
-        fams = {"pn2_conv1x1_wgrad": ["gemm_tn_kernel", "wgrad_skinny_kernel"], "pn2_conv1x1_fwd": ["gemm_nt_kernel<fwd>", "fwd_res_kernel"],
-                "pn2_conv1x1_dgrad": ["gemm_nt_kernel<dgrad>"], "pn2_conv1x1_bwd": ["gemm_bwd_fused_kernel"]}.get(top)
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)))
-        if fams and cands:
-            pmc_path = cands[-1]
-            doc = json.load(open(pmc_path))
-            hit = [doc.get("families", {}).get(f) for f in fams]
+        pmc_doc, pmc_name, pmc_fresh = None, None, False
+        if cands:
+            pmc_name = os.path.basename(cands[-1])
+            pmc_doc = json.load(open(cands[-1]))
+            pmc_fresh = pmc_doc.get("csrc_sha256") == csrc_digest()
+
+        def pmc_traffic(entry):
+            """HBM bytes per launch of an entry point's kernel families from the digest-checked PMC file, or None."""
+            if not (pmc_doc and pmc_fresh):
+                return None
+            hit = [pmc_doc.get("families", {}).get(f) for f in GEMM_FAMILIES.get(entry, [])]
             hit = [h for h in hit if h]
-            if hit and doc.get("csrc_sha256") == csrc_digest():
-                roofline["traffic"] = round(sum(h["hbm_bytes_per_step"] for h in hit) / sum(h["launches_per_step"] for h in hit))
+            if not hit:
+                return None
+            return round(sum(h["hbm_bytes_per_step"] for h in hit) / sum(h["launches_per_step"] for h in hit))
+
+        if top in GEMM_FAMILIES:
+            roofline["traffic"] = pmc_traffic(top)
+            if roofline["traffic"] is not None:
                 roofline["traffic_note"] = "HBM bytes per launch, PMC (profiles/%s, kernel families %s); algorithmic bytes per launch %d" % (
-                    os.path.basename(pmc_path), " + ".join(fams), round(v[3] / v[1]))
-            elif hit:
-                roofline["traffic_note"] = "profiles/%s was collected with other kernel sources (digest differs): not quoted" % (
-                    os.path.basename(pmc_path))
+                    pmc_name, " + ".join(GEMM_FAMILIES[top]), round(v[3] / v[1]))
+            elif pmc_doc:
+                roofline["traffic_note"] = "profiles/%s was collected with other kernel sources (digest differs): not quoted" % pmc_name
+        # all four GEMM entry points, weakest first: the line must not look healthier than its worst big kernel
+        fam_rows = []
+        for entry in GEMM_FAMILIES:
+            x = agg.get(entry)
+            if not x or x[0] <= 0:
+                continue
+            e_tf, e_gbs = x[2] / (x[0] / 1e3) / 1e12, x[3] / (x[0] / 1e3) / 1e9
+            fam_rows.append({"name": entry, "ms_per_step": round(x[0] / prof_steps, 4), "launches_per_step": x[1] // prof_steps,
+                             "TFLOPs": round(e_tf, 2), "frac": round(e_tf / F32_MFMA_PEAK_TF, 4), "alg_GBs": round(e_gbs, 1),
+                             "hbm_frac": round(e_gbs / HBM_PEAK_GBS, 4), "alg_bytes": round(x[3] / x[1]),
+                             "traffic": pmc_traffic(entry)})
+        roofline["families"] = sorted(fam_rows, key=lambda r: r["frac"])
         roofline["avg_launch_us"] = round(v[0] / v[1] * 1e3, 2)
         roofline["launches"] = v[1] // prof_steps
         roofline["device_ms_all_kernels_per_step"] = round(sum(x[0] for x in agg.values()) / prof_steps, 3)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and n_points == 4096:
-        cpu = cpu_baseline(args.workload, batch)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if n_points == 4096:
+            cpu = cpu_baseline(args.workload, batch)
+        elif args.workload in ("msg", "ssg"):
+            cpu = cpu_baseline_slice(args.workload, batch, n_points, args.npoint_scale)
 
     if rank == 0:
         line = {
@@ -468,14 +591,16 @@ def main():
                        "grad_bucket_bytes": bucket.nbytes},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
+        line.update(rank_info)                       # allreduce_ms, rank_ms_per_step_min / _max
         # whole-step fractions on SURVEY.md section 8(d)'s byte / flop model (I/O + five passes over every pre-BN
         # activation; 6 x forward MACs), per GPU: the headline the north star asks for next to the absolute number
-        model = STEP_MODEL.get(args.workload)
-        if model and n_points == 4096 and getattr(args, "npoint_scale", 1) in (1, None):
+        model = STEP_MODEL.get(args.workload) if (n_points == 4096 and args.npoint_scale == 1) else (
+            STEP_MODEL_CFG5.get((args.workload, args.npoint_scale)) if n_points == 65536 else None)
+        if model:
             per_gpu = value / world
             executed = sum(k["gflop_per_step"] for k in kernels.values()) * 1e9 if kernels else None
             line["step_roofline"] = {
-                "alg_bytes_per_point": model[0], "flop_per_point_reference_formulation": model[1],
+                "alg_bytes_per_point": round(model[0]), "flop_per_point_reference_formulation": model[1],
                 "hbm_GBs": round(per_gpu * model[0] / 1e9, 1), "hbm_frac": round(per_gpu * model[0] / (HBM_PEAK_GBS * 1e9), 4),
                 # what the matrix cores really did: flops summed over the launches of the instrumented pass (the
                 # factorised first layers skip 94 of the reference formulation's 464.5 GFLOP on MSG)

@@ -293,7 +293,10 @@ int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int ldo, const i
  * Input: X != NULL: plain rows [P, ldx] with P passed in `B` (FP modules, heads);  X == NULL: grouped rows formed on the
  * fly from idx [B,S,Knb] (xyz [B,N,3] minus new_xyz [B,S,3], cat with points [B,N,D]; xyz_first as pn2_group;
  * idx == NULL with S == 1, Knb == N, new_xyz == NULL: group_all, un-centred).  pool: 0 (out [P, ldo], ReLU applied) or
- * Knb (out [P / Knb, ldo]); Knb must be 16 or a multiple of 32.  L <= 4; activations of a 32-row tile stay in LDS. */
+ * Knb (out [P / Knb, ldo]); Knb must be 16 or a multiple of 32.  L <= 4; activations of a 32-row tile stay in LDS.
+ * Deviation from the reference: ReLU is fmaxf(x, 0) and the pooling an integer atomicMax on the bits of the non-negative
+ * result, both of which DROP a NaN activation (torch.relu / torch.max propagate it).  A diverged model therefore shows
+ * finite pooled features here; the training-mode path (pn2_bn_relu_max) and the un-pooled outputs keep NaNs visible. */
 typedef struct {
     const float *W;
     const float *bias;
@@ -311,11 +314,13 @@ int pn2_fused_eval(const float *X, int ldx, const float *xyz, const float *point
 int pn2_invert_index(const int64_t *idx, int B, int M, int T, int32_t *members, int32_t *owners, int32_t *scratch,
                      pn2_stream_t stream);
 /* pn2_three_interp_bwd over the target-sorted 3-NN index (idx viewed as [B, 3N], T = S): runs of equal target are
- * summed in registers, one atomic row-add per run.  grad_points2 [B,S,D], caller zeroes. */
+ * summed in registers; a run that lies inside one chunk of the member list is STORED, the (at most two) runs that
+ * straddle a chunk's ends are added atomically.  grad_points2 [B,S,D]: the caller MUST zero it (targets without
+ * members are never written, and the straddling runs accumulate). */
 int pn2_three_interp_bwd_seg(const float *grad_out, int ld, int col0, const int32_t *members, const int32_t *owners,
                              const float *weight, int B, int N, int S, int D, float *grad_points2, pn2_stream_t stream);
-/* pn2_group_affine_bwd over the source-sorted ball-query index (idx viewed as [B, S*K], T = N).  G [B*N, ldg],
- * caller zeroes; dWx accumulated as in pn2_group_affine_bwd.  C <= 256.  dwx_scratch: float[PN2_DWX_REPLICAS * 3 *
+/* pn2_group_affine_bwd over the source-sorted ball-query index (idx viewed as [B, S*K], T = N).  G [B*N, ldg]:
+ * the caller MUST zero it (same store-versus-atomic rule as pn2_three_interp_bwd_seg); dWx accumulated as in pn2_group_affine_bwd.  C <= 256.  dwx_scratch: float[PN2_DWX_REPLICAS * 3 *
  * round4(C)] zeroed by the caller, or NULL.  With it the per-workgroup dWx partials are added to one of
  * PN2_DWX_REPLICAS copies and a second small launch folds the copies into dWx (all resident workgroups finish
  * together; their 3*C same-word atomics on dWx itself cost up to 4x the rest of the launch). */

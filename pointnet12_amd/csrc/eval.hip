@@ -168,13 +168,8 @@ extern "C" int pn2_fused_eval(const float *X, int ldx, const float *xyz, const f
     const int64_t P = X ? (int64_t)B : (int64_t)B * S * Knb;      // plain rows: the caller passes the row count in B
     PN2_CHECK_ARG(pool == 0 || P % pool == 0);
     hipStream_t s = pn2_s(stream);
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
-            return PN2_ELAUNCH;
-        raised = true;
-    }
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&fused_eval_kernel), raised) != PN2_OK) return PN2_ELAUNCH;
     if (pool > 32) pn2_fill_u32(out, 0u, (P / pool) * (int64_t)ldo, s);       // atomicMax target: relu outputs are >= 0
     EvalInput in{X, ldx, xyz, points, new_xyz, idx, N, S, Knb, D, xyz_first};
     hipLaunchKernelGGL(fused_eval_kernel, dim3((unsigned)pn2_cdiv(P, EV_ROWS)), dim3(EV_THREADS), lds, s, in, ar, pool, out, ldo, P, LP);

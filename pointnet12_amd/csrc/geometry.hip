@@ -556,13 +556,10 @@ int launch_fps_pruned(const float *xyz, int B, int N, const int64_t *start, int 
     kernel_t k_lds, k_mem;
     if constexpr (ROWS) { k_lds = &fps_rows_kernel<THREADS, PPT, true>; k_mem = &fps_rows_kernel<THREADS, PPT, false>; }
     else { k_lds = &fps_pruned_kernel<THREADS, PPT, true>; k_mem = &fps_pruned_kernel<THREADS, PPT, false>; }
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k_mem), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return PN2_ELAUNCH;
-        raised = true;
-    }
+    static Pn2PerDevice raised_lds, raised_mem;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(k_lds), raised_lds) != PN2_OK ||
+        pn2_raise_dynamic_lds(reinterpret_cast<const void *>(k_mem), raised_mem) != PN2_OK)
+        return PN2_ELAUNCH;
     if (in_lds)
         hipLaunchKernelGGL(k_lds, dim3(B), dim3(THREADS), fixed + (size_t)N * 16, s, xyz, N, start, npoint, out);
     else
@@ -725,13 +722,8 @@ int launch_fps(const float *xyz, int B, int N, const int64_t *start, int npoint,
     size_t lds = (in_lds ? (size_t)N * 16 : 0) + 32;           // + the three rotating reduction words
     if (in_lds) {
         if (lds > 64 * 1024) {   // above the default dynamic-LDS window: opt in once per instantiation
-            static bool raised = false;
-            if (!raised) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<THREADS, PPT, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                    return PN2_ELAUNCH;
-                raised = true;
-            }
+            static Pn2PerDevice raised;
+            if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&fps_kernel<THREADS, PPT, true>), raised) != PN2_OK) return PN2_ELAUNCH;
         }
         hipLaunchKernelGGL((fps_kernel<THREADS, PPT, true>), dim3(B), dim3(THREADS), lds, s, xyz, N, start, npoint, out);
     } else

@@ -18,6 +18,7 @@
 //     because dW is accumulated with atomics anyway) -- is dealt to the waves by a host-side LPT plan so every wave
 //     issues the same number of MFMAs.  dW accumulators stay in registers across all tiles of the workgroup.
 #include "mlp_loaders.h"
+#include <algorithm>
 
 namespace {
 
@@ -455,13 +456,9 @@ int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, 
     ResPlan plan;
     if (!make_res_plan(CI_T, &plan)) return PN2_EINVAL;
     const size_t lds = bwd_res_lds_bytes(32 * CO_T, 32 * CI_T, DBUF);
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return PN2_ELAUNCH;
-        raised = true;
-    }
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>), raised) != PN2_OK)
+        return PN2_ELAUNCH;
     const int64_t cap = pn2_num_cus();                             // one 8-wave workgroup per CU
     hipLaunchKernelGGL((bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>), dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(512), lds, s, dy, Yp,
                        ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, plan);
@@ -737,13 +734,8 @@ int launch_fwd_res(const float *X, int ldx, const float *aff, const float *W, in
     size_t lds = fixed + nw * per_wave;
     const size_t red = sizeof(double) * 2 * N * nw;                 // the final fold reuses the image
     if (lds < red) lds = red;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fwd_res_kernel<K_T, N_T, ACT, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return PN2_ELAUNCH;
-        raised = true;
-    }
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&fwd_res_kernel<K_T, N_T, ACT, POOL>), raised) != PN2_OK) return PN2_ELAUNCH;
     const int64_t slabs = P / 32;                                  // whole slabs; the caller handles P % 32
     int64_t grid = pn2_cdiv(slabs / (POOL ? pool.U : 1), nw);
     if (grid > pn2_num_cus()) grid = pn2_num_cus();
@@ -805,6 +797,7 @@ extern "C" int pn2_res_supported(int64_t P, int C_out, int C_in) {
 // it to the streamed dgrad + wgrad pair.  Kpool = 0: dense dZ; masked: the layer has a BatchNorm + ReLU input (prev_affine).
 extern "C" int pn2_bwd_res_supported(int64_t P, int C_out, int C_in, int Kpool, int masked) {
     if (!pn2_res_supported(P, C_out, C_in)) return 0;
+    if (P * (int64_t)std::max(C_out, C_in) >= (1LL << 32)) return 0;     // 32-bit element offsets inside the fused kernel
     const int64_t tiles = P / RES_BM;
     const auto is = [&](int co, int ci) { return C_out == co && C_in == ci; };
     if (Kpool == 0 && masked) return is(32, 32) || is(64, 64) || is(96, 64) || (tiles >= 4096 && is(128, 128));
@@ -883,6 +876,10 @@ extern "C" int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int l
     PN2_CHECK_ARG(dZ ? (ldz == ldy) : (kshift >= 0 && ldo % 4 == 0 && ldo >= C_out && prev_affine != nullptr && P % Kpool == 0));
     int64_t tiles = P / RES_BM, P_full = tiles * RES_BM;
     int rc = PN2_OK;
+    // the fused kernel addresses with 32-bit element offsets (tile base + lane term): past 2^32 elements of any of its
+    // matrices (16 GiB: the K = 128 branch of the dense scans at B = 16) the streamed pair below takes all rows
+    const int64_t ld_max = std::max(std::max((int64_t)ldy, (int64_t)ld_prev), std::max((int64_t)ldxo, dZ ? (int64_t)ldz : (int64_t)ldo));
+    if (P * ld_max >= (1LL << 32)) { tiles = 0; P_full = 0; }
     if (tiles > 0) {
         ResDy dy{dZ, dZp, arg, ldo, kshift, Y, ldy, coef};
         rc = dispatch_bwd_res(dZ ? 0 : Kpool, prev_affine != nullptr, C_out, C_in, dy, prev_Y, ld_prev, prev_affine, W, ldw, tiles, dXout, ldxo,

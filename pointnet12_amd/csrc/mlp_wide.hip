@@ -341,14 +341,8 @@ int launch_regw(const RegwArgs &g, hipStream_t s) {
     static_assert(BNN || NCB * RS * 32 <= 2 * BM, "the W staging regions must fit inside the chunk buffers");
     static_assert(lds <= 160 * 1024, "LDS");
     auto kern = regw_nt_kernel<K4, NCB, RS, TM, KC, MODE, EPI, BNN, PKP, ADB>;
-    static int raised_dev[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (!raised_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return PN2_ELAUNCH;
-        raised_dev[dev] = 1;
-    }
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
     const int64_t cap = pn2_num_cus();
     hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles < cap ? g.tiles : cap)), dim3(64 * NCB * RS), lds, s, g);
     return pn2_launch_status();

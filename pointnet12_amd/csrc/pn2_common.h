@@ -17,16 +17,43 @@ static inline hipStream_t pn2_s(pn2_stream_t s) { return reinterpret_cast<hipStr
 
 static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Compute units of the current device (a CPX partition or a CU-masked queue reports its own count).
+// Current device, clamped to the per-device tables below (a process driving more than PN2_MAX_DEVICES GPUs shares the
+// last slot, which only costs it a redundant attribute call or a CU count of the wrong device for grid sizing).
+#define PN2_MAX_DEVICES 16
+static inline int pn2_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < PN2_MAX_DEVICES ? dev : PN2_MAX_DEVICES - 1;
+}
+
+// Compute units of the CURRENT device (a CPX partition or a CU-masked queue reports its own count); cached per device:
+// a process may drive several GPUs (one rank per GPU is the supported layout, but nothing here assumes it).
 static inline int pn2_num_cus() {
-    static int cus = 0;
-    if (cus == 0) {
+    static int cus[PN2_MAX_DEVICES] = {0};
+    const int slot = pn2_device_slot();
+    if (cus[slot] == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        int n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        cus[slot] = n > 0 ? n : 256;
     }
-    return cus;
+    return cus[slot];
+}
+
+// Kernels that use more than 64 KiB of dynamic LDS raise the function attribute once PER DEVICE (the attribute belongs to the
+// device's code object: a flag per process would skip it on the second GPU).  Usage: static Pn2PerDevice done; if
+// (!done.get()) { hipFuncSetAttribute(...); done.set(); }
+struct Pn2PerDevice {
+    bool flag[PN2_MAX_DEVICES] = {false};
+    bool get() const { return flag[pn2_device_slot()]; }
+    void set() { flag[pn2_device_slot()] = true; }
+};
+static inline int pn2_raise_dynamic_lds(const void *kernel, Pn2PerDevice &done) {
+    if (done.get()) return PN2_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PN2_ELAUNCH;
+    done.set();
+    return PN2_OK;
 }
 
 // 64-bit max across a wave with xor-shuffles; every lane ends with the result.

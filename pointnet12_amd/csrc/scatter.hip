@@ -7,8 +7,10 @@
 // every target element receives 24..32 same-address adds).  The index is known as soon as the neighbour search
 // is done -- on the prefetch stream, one step ahead -- so it is sorted once by target (per cloud: counts -> offsets ->
 // member lists, a counting sort) and the backward becomes a SEGMENTED reduction over the sorted member array: every
-// lane group takes a fixed chunk of 16 consecutive members, sums runs of equal target in registers and flushes a
-// run with one atomic row-add when the target changes.  Perfectly balanced whatever the list lengths are (a
+// lane group takes a chunk of 16 / 32 / 64 consecutive members (by level size), sums runs of equal target in registers and
+// flushes a run when the target changes: a run that lies INSIDE the chunk is complete and is STORED (the buffer must arrive
+// zeroed all the same: targets without members are never written), only the (at most two) runs that straddle a chunk's ends
+// are added atomically.  Perfectly balanced whatever the list lengths are (a
 // KITTI-shaped cloud has targets with hundreds of members next to targets with none: one-wave-per-target gathers ran
 // 2x SLOWER than the atomics), and ~10x fewer atomics than the element-wise scatter.
 #include "pn2_common.h"
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(256) void invert_fill_kernel(const int64_t *__restr
     owners[(int64_t)b * M + pos] = (int)v;
 }
 
-// The whole counting sort of ONE cloud in ONE workgroup, histogram and cursors in LDS (T <= 16 384 targets = 64 KiB):
+// The whole counting sort of ONE cloud in ONE workgroup, histogram and cursors in LDS (T <= 16 384 targets: 4 (T + 20) bytes,
+// 65 616 at the limit -- the launcher raises the dynamic-LDS attribute above 64 KiB):
 // count with ds_add, scan in place, fill through returning ds_add cursors, pad the tail with -1.  One launch instead of
 // two fills + three kernels whose global atomics queue up on a few thousand hot counters (a dense scan's 3-NN index
 // puts 196 608 entries of a cloud on 1 024 targets: the three passes took 0.37 ms per call, a quarter of the cfg5 SSG
@@ -373,6 +376,11 @@ int pn2_invert_index(const int64_t *idx, int B, int M, int T, int32_t *members, 
     hipStream_t s = pn2_s(stream);
     int32_t *counts = scratch, *offsets = scratch + (size_t)B * T;        // scratch: int32 [B, 2T + 1]
     if (T <= 16384) {                                                      // one LDS-resident pass per cloud
+        // T = 16 384 (sa1 of the dense scans) needs 65 616 bytes: above the default 64 KiB dynamic-LDS window
+        static Pn2PerDevice raised;
+        if (sizeof(int) * ((size_t)T + 20) > 64 * 1024 &&
+            pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&invert_lds_kernel), raised) != PN2_OK)
+            return PN2_ELAUNCH;
         hipLaunchKernelGGL(invert_lds_kernel, dim3((unsigned)B), dim3(1024), sizeof(int) * ((size_t)T + 20), s, idx, M, T, members,
                            owners, offsets);
         return pn2_launch_status();

@@ -1,7 +1,8 @@
 """CPU: `python bench.py --gpus N` launches its own ranks (it used to exit unless torchrun wrapped it).
 
 --dry-run runs the rank protocol of the real benchmark (rendezvous on 127.0.0.1, barrier, K timed steps, MAX over ranks,
-ONE JSON line from rank 0 relayed by the parent) with gloo ranks and no GPU work."""
+ONE JSON line from rank 0 relayed by the parent) with gloo ranks: the oracle SSG network accumulating into the real
+parallel.FlatGradBucket, averaged by its all-reduce, no GPU."""
 import json
 import os
 import subprocess
@@ -26,7 +27,12 @@ def test_bench_self_launches_two_ranks_and_prints_one_json_line():
     assert len(lines) == 1, p.stdout
     doc = json.loads(lines[0])
     assert doc["n_gpus"] == 2 and doc["steps"] == 4 and doc["dry_run"] is True
-    assert doc["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step: the line carries the MAX over ranks
+    # the dry run drives the oracle SSG network into the real FlatGradBucket and its gloo all-reduce through the SAME timed
+    # protocol as the GPU run: the ranks (different seeds before the broadcast) must end with identical parameters and bucket
+    assert doc["ranks_agree"] is True and doc["grad_bucket_bytes"] == 968173 * 4
+    assert doc["allreduce_ms"] > 0.0
+    # rank 1 sleeps 2 ms per step more than rank 0: the line carries the MAX over ranks, and says how far apart they are
+    assert doc["ms_per_step"] == doc["rank_ms_per_step_max"] >= doc["rank_ms_per_step_min"]
 
 
 def test_bench_single_rank_needs_no_launcher():

@@ -544,6 +544,57 @@ def test_eval_network_fused_vs_oracle(dev):
     assert float((a - b.cpu()).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
 
 
+def test_fused_eval_follows_training(dev):
+    """Train -> eval -> train -> eval, the reference's epoch loop (pcdseg.py:69,190): the eval-mode fold (BatchNorm into the
+    conv weights) must follow writes the HIP library makes through raw pointers -- running statistics by pn2_bn_finalize,
+    parameters by pn2_adam_step -- which tensor._version does not see.  Checked against the layer-by-layer eval kernels
+    (PN2_FUSED_EVAL=0, which read the live parameters), and through a hipGraph that captured the fused launch BEFORE the
+    training steps (its baked-in weight pointers must stay valid and show the refreshed fold)."""
+    from pointnet12_amd import optim, synthetic as syn
+    torch.manual_seed(11)
+    mod = U.PointNetSetAbstraction(128, 0.3, 32, 9, [32, 48, 64], False).to(dev)
+    pts = torch.from_numpy(syn.kitti_batch(801, 2, 1024)[0]).to(dev)
+    xyz, feat = pts[:, :3].contiguous(), pts[:, 3:].contiguous()
+    start = torch.zeros(2, dtype=torch.int64, device=dev)
+    opt = optim.Adam(mod.parameters(), lr=1e-2)
+
+    def evaluate(fused):
+        mod.eval()
+        U.FUSED_EVAL = fused
+        try:
+            with torch.no_grad():
+                return mod(xyz, feat, fps_start=start)[1].clone()
+        finally:
+            U.FUSED_EVAL = True
+
+    first = evaluate(True)
+    assert float((first - evaluate(False)).abs().max()) <= 1e-5 * max(1.0, float(first.abs().max()))
+    # a graph that captured the fused launch now
+    mod.eval()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side), torch.no_grad():
+        mod(xyz, feat, fps_start=start)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            g_out = mod(xyz, feat, fps_start=start)[1]
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for _ in range(3):
+        mod.train()
+        opt.zero_grad()
+        out = mod(xyz, feat, fps_start=start)[1]
+        (out * out).mean().backward()
+        opt.step()
+    after = evaluate(True)
+    ref = evaluate(False)
+    assert float((after - first).abs().max()) > 1e-3, "three Adam steps at lr 1e-2 must move the eval output"
+    assert float((after - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float((g_out - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("K,co,D,xyz_first", [(16, 32, 6, False), (32, 64, 6, True), (64, 64, 3, False), (32, 64, 9, False)])
 def test_gather_conv_first_layer_equals_group_then_gemm(dev, K, co, D, xyz_first):
     """pn2_group_conv_fwd (gather + first conv in one launch, the sa1 stacks) against pn2_group followed by the GEMM: same

@@ -196,3 +196,31 @@ def test_aten_geometry_equals_c_restatement():
         finally:
             T.set_geometry("c")
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-5
+
+
+def test_shipped_checkpoint_eval_golden():
+    """G7: the reference's shipped KITTI checkpoint in eval mode.  The fixture holds the input cloud, the
+    REFERENCE's log-probabilities and the checkpoint's sha256; the weights themselves never enter the repo, so this runs only
+    where the reference tree is mounted (the development container) and is skipped on the GPU box.  It pins, against the
+    reference's own numbers: the 156 `module.`-prefixed keys loading into the oracle net AND into this package's net class
+    (the state_dict contract of SURVEY.md 8(b)), and the oracle's eval-mode arithmetic (running statistics, no dropout)."""
+    import os
+    path = os.path.join(os.environ.get("PN2_REFERENCE", "/root/reference"), "checkpoints", "pointnet2-inview-0.55884-0001.pth")
+    if not os.path.exists(path):
+        pytest.skip("reference checkpoint not mounted (GPU box): the fixture's input/output pair needs its weights")
+    g = golden("g7_checkpoint_eval.npz")
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == str(g["sha256"])
+    sd = torch.load(path, map_location="cpu")
+    assert len(sd) == int(g["n_keys"]) == 156 and all(k.startswith("module.") for k in sd)
+    sd = {k[len("module."):]: v for k, v in sd.items()}
+    orc = T.RefSSGSemSeg(19, 1)
+    orc.load_state_dict(sd)                      # strict: every key and shape of the reference's SA / FP / head modules
+    orc.eval()
+    from pointnet12_amd import pointnet2 as M    # the product's model zoo: same attribute names, same shapes (no GPU needed)
+    net = M.PointNet2SemSeg(19, 1)
+    assert net.load_state_dict(sd, strict=True) is not None
+    with torch.no_grad():
+        torch.manual_seed(int(g["seed"]))
+        mine = orc(torch.from_numpy(g["points"])).numpy()
+    assert mine.shape == g["log_probs"].shape == (1, 2048, 19)
+    assert np.abs(mine - g["log_probs"]).max() <= 2e-5

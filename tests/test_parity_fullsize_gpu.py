@@ -182,6 +182,24 @@ def test_cfg5_single_cloud_vs_oracle(dev):
         torch.cuda.empty_cache()
 
 
+def test_cfg5_two_clouds_vs_oracle(dev):
+    """BASELINE.json configs[4] with MORE than one cloud in the batch (round 2 verdict: the B=1 case never couples two dense
+    scans): B=2 x 65 536 through the reference's SSG net -- two clouds share the cooperative multi-workgroup FPS launch, the
+    Morton-ordered ball query and every BatchNorm's batch statistics -- forward + loss + backward against the oracle in fp32
+    and in fp64 (same assertions as the single-cloud case)."""
+    pts_np, lab_np = syn.kitti_batch(11, 2, 65536)
+    pts, labels = torch.from_numpy(pts_np), torch.from_numpy(lab_np)
+    net, orc = _nets("ssg", dev)
+    o32 = _run_oracle(orc, pts, labels, torch.float32)
+    o64 = _run_oracle(orc, pts, labels, torch.float64)
+    hip = _run_hip(net, pts, labels, dev)
+    r = _compare("cfg5_ssg_B2x65536", hip, o32, o64)
+    assert r["hip_vs_orc32_max"] <= REL_CAP * max(1.0, r["log_probs_absmax"]), r
+    assert r["hip_vs_fp64_rms"] <= FACTOR * r["orc32_vs_fp64_rms"], r
+    assert r["hip_vs_fp64_max"] <= FACTOR * r["orc32_vs_fp64_max"], r
+    assert r["grad_l2_hip_vs_fp64_median"] <= GRAD_FACTOR * r["grad_l2_orc32_vs_fp64_median"], r
+
+
 @pytest.mark.parametrize("kind,scale", [("ssg", 1), ("msg", 16)])
 def test_cfg5_full_batch_permutation_equivariance(dev, kind, scale):
     """BASELINE.json configs[4] as a WORKLOAD: B=8 x 65 536, forward + backward of the whole SA/FP stack (MSG: P up to
@@ -270,6 +288,7 @@ def test_zoo_net_matches_reference_and_oracle(dev, tag):
     """The four other networks of model/pointnet2.py:7-139 (train mode, dropout off, B=2 x 1024): outputs against the
     REFERENCE's numbers (tests/golden/g10_zoo.npz), gradients against the oracle net on the same state."""
     g = golden("g10_zoo.npz")
+    noise, g6n = golden("g10_noise.npz"), golden("g6_noise.npz")
     make, make_orc, n_in = ZOO[tag]
     torch.manual_seed(int(g["init_seed"]))
     orc = make_orc()
@@ -292,17 +311,23 @@ def test_zoo_net_matches_reference_and_oracle(dev, tag):
         ref = g["%s/out/%d" % (tag, i)]
         mine = t.detach().cpu().numpy()
         mine = mine if mine.size <= 4096 else mine.reshape(-1)[::17]
-        # B*N = 2048 behind up to six BatchNorm-coupled stages: the reference moves 5e-5..9e-5 against itself here
-        assert np.abs(mine - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), (tag, i, np.abs(mine - ref).max())
+        # B*N = 2048 behind up to six BatchNorm-coupled stages: the bound is TWICE what the reference moves against itself on
+        # this very net when only its thread count changes (tests/golden/g10_noise.npz, tools/make_golden.py g10n: 7e-6 .. 9e-5),
+        # and never below the smaller of the two G6 self-noise figures (nets of the same depth, g6_noise.npz)
+        out_tol = max(2.0 * float(noise[tag + "/out_rel"]), float(min(g6n["ssg/log_probs_absdiff"], g6n["msg/log_probs_absdiff"])))
+        assert np.abs(mine - ref).max() <= out_tol * max(1.0, np.abs(ref).max()), (tag, i, np.abs(mine - ref).max(), out_tol)
     gw = torch.randn(ys[0].shape, generator=torch.Generator().manual_seed(int(g["gw_seed"])))
     (ys[0] * gw.to(dev)).sum().backward()
     got = {n: p.grad for n, p in net.named_parameters()}
+    # per-tensor gradient L2 norms: the reference's own 8-thread runs sit 1.5e-2 .. 1.7e-1 from its 1-thread run (a handful of
+    # argmax / ReLU decisions of the tiny batch fall the other way): twice that, per net
+    grad_tol = 2.0 * float(noise[tag + "/grad_l2_rel"])
     for n, l2 in zip(g[tag + "/grad_names"], g[tag + "/grad_l2"]):
         n = str(n)
         if _zero_grad_bias(n):
             continue
         mine = float(got[n].double().norm())
-        assert abs(mine - l2) <= 3e-2 * l2 + 1e-6 * float(g[tag + "/grad_l2"].max()), (n, mine, l2)
+        assert abs(mine - l2) <= grad_tol * l2 + 1e-6 * float(g[tag + "/grad_l2"].max()), (n, mine, l2, grad_tol)
 
 
 def test_partseg_msg_shape_of_the_reference_self_test(dev):

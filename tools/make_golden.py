@@ -449,6 +449,10 @@ def g10_zoo():
             ("partseg_ssg", lambda: R2.PointNet2PartSegSsg(50), lambda: T.RefPartSegSsg(50, dropout=0.0), (xyz,)),
             ("partseg_msg", lambda: R2.PointNet2PartSegMsg_one_hot(50), lambda: T.RefPartSegMsgOneHot(50, dropout=0.0),
              (xyz, nrm, cls))]
+    # ONE thread for both sides: with 8 threads the summation order of the BatchNorm / GEMM reductions follows the thread
+    # timing, a handful of argmax / ReLU decisions of the tiny batch then fall differently from run to run and the gradient
+    # check below passed or failed by luck (round 2 verdict).  The reference's own thread noise is measured by g10n.
+    torch.set_num_threads(1)
     for tag, make_ref, make_orc, ins in nets:
         torch.manual_seed(77)
         ref = make_ref()
@@ -477,7 +481,7 @@ def g10_zoo():
             if ("conv" in n and n.endswith("bias") and n != "conv2.bias") or (n.startswith("fc") and n.endswith("bias") and n != "fc3.bias"):
                 continue          # zero gradient under the BatchNorm that follows
             worst = max(worst, abs(np.linalg.norm(a) - np.linalg.norm(b)) / max(np.linalg.norm(a), 1e-12))
-        check(worst <= 2e-2, "%s: per-tensor gradient L2 norms within 2e-2 (%.2e; flip noise of the tiny batch)" % (tag, worst))
+        check(worst <= 1e-4, "%s: per-tensor gradient L2 norms within 1e-4 (%.2e; one thread on both sides: deterministic)" % (tag, worst))
         out[tag + "/n_out"] = np.int64(len(res["ref"][0]))
         for i, a in enumerate(res["ref"][0]):
             out["%s/shape/%d" % (tag, i)] = np.array(a.shape, np.int64)
@@ -489,7 +493,62 @@ def g10_zoo():
     out["init_seed"] = np.int64(77)
     out["fwd_seed"] = np.int64(88)
     out["gw_seed"] = np.int64(5)
+    out["threads"] = np.int64(1)
+    torch.set_num_threads(8)
     save("g10_zoo.npz", **out)
+
+
+def _zoo_inputs():
+    pts_np, _ = syn.kitti_batch(400, 2, 1024)
+    xyz = torch.from_numpy(np.ascontiguousarray(pts_np[:, :3]))
+    nrm = torch.from_numpy(np.ascontiguousarray(pts_np[:, 3:6]))
+    cls = torch.zeros(2, 16)
+    cls[0, 3] = 1.0
+    cls[1, 11] = 1.0
+    return xyz, nrm, cls
+
+
+def g10_noise():
+    """How far the REFERENCE's zoo nets move against themselves (the g10 setting: train mode, dropout off, B=2 x 1024) when
+    only the thread count changes: the 1-thread run g10_zoo.npz stores against three 8-thread runs.  The GPU test of these
+    nets (tests/test_parity_fullsize_gpu.py) allows twice this instead of a quoted constant."""
+    print("G10n reference self-noise of the zoo nets, 8 threads (x3) vs 1")
+    xyz, nrm, cls = _zoo_inputs()
+    nets = [("cls_msg", lambda: R2.PointNet2ClsMsg(), (xyz,)), ("cls_ssg", lambda: R2.PointNet2ClsSsg(), (xyz,)),
+            ("partseg_ssg", lambda: R2.PointNet2PartSegSsg(50), (xyz,)),
+            ("partseg_msg", lambda: R2.PointNet2PartSegMsg_one_hot(50), (xyz, nrm, cls))]
+    out = {}
+
+    def run(make_ref, ins, threads):
+        torch.set_num_threads(threads)
+        torch.manual_seed(77)
+        ref = make_ref()
+        for m in ref.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        ref.train()
+        torch.manual_seed(88)
+        y = ref(*ins)
+        ys = y if isinstance(y, tuple) else (y,)
+        gw = torch.randn(ys[0].shape, generator=torch.Generator().manual_seed(5))
+        (ys[0] * gw).sum().backward()
+        return [t.detach().numpy().copy() for t in ys], {k: p.grad.numpy().astype(np.float64) for k, p in ref.named_parameters()}
+
+    for tag, make_ref, ins in nets:
+        base_y, base_g = run(make_ref, ins, 1)
+        d_out, d_l2 = 0.0, 0.0
+        for _ in range(3):
+            y, g = run(make_ref, ins, 8)
+            d_out = max(d_out, max(np.abs(a - b).max() / max(1.0, np.abs(a).max()) for a, b in zip(base_y, y)))
+            for n in base_g:
+                if ("conv" in n and n.endswith("bias") and n != "conv2.bias") or (n.startswith("fc") and n.endswith("bias") and n != "fc3.bias"):
+                    continue
+                d_l2 = max(d_l2, abs(np.linalg.norm(base_g[n]) - np.linalg.norm(g[n])) / max(np.linalg.norm(base_g[n]), 1e-12))
+        out[tag + "/out_rel"] = np.float64(d_out)
+        out[tag + "/grad_l2_rel"] = np.float64(d_l2)
+        print("  %s: outputs move %.2e (of max(1, |out|)), per-tensor gradient L2 norms %.2e" % (tag, d_out, d_l2))
+    torch.set_num_threads(8)
+    save("g10_noise.npz", **out)
 
 
 def g7_checkpoint():
@@ -517,8 +576,9 @@ def g7_checkpoint():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6n", "g7", "g10"]
-    table = dict(g1=g1_fps, g2=g2_ball, g3=g3_sqdist, g4=g4_interp, g5=g5_modules, g6=g6_nets, g7=g7_checkpoint, g10=g10_zoo, g6n=g6_noise)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6n", "g7", "g10", "g10n"]
+    table = dict(g1=g1_fps, g2=g2_ball, g3=g3_sqdist, g4=g4_interp, g5=g5_modules, g6=g6_nets, g7=g7_checkpoint, g10=g10_zoo, g6n=g6_noise,
+                 g10n=g10_noise)
     for w in which:
         table[w]()
     print("all oracle checks passed")

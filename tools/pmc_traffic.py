@@ -21,6 +21,10 @@ def family(name):
         fam += "<" + ("fwd" if "EpiFwd" in name else "dgrad") + ">"
     if fam == "bwd_res_kernel":
         fam = "gemm_bwd_fused_kernel"
+    if fam == "regw_nt_kernel":                  # template arguments: K4, NCB, RS, TM, KC, MODE, EPI (0 = forward), ...
+        targs = re.search(r"regw_nt_kernel<([^>]*)>", name)
+        epi = targs.group(1).split(",")[6].strip() if targs else "0"
+        fam += "<fwd>" if epi == "0" else "<dgrad>"
     return fam
 
 
