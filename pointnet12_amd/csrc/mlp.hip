@@ -179,7 +179,13 @@ struct NtLds {
                                                       : (kStage > kReduce ? kStage : kReduce);
 };
 
-template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi>
+// ACCS: independent partial accumulators per 32x32 output tile.  The four MFMAs that consume one ds_read_b128 (k-lanes x, y, z,
+// w) and the next k block's all accumulate into the SAME tile: one dependent chain per tile, and a dependent
+// v_mfma_f32_32x32x2_f32 issues only every ~130 cycles (64 when independent).  Kernels whose waves hold one or two tiles and run
+// one or two waves per SIMD (the few-row launches: one workgroup per CU) were bound by exactly that chain (2048 x 1536 -> 256:
+// 33 us whether the k-steps were 32 or 64 deep, one or three in flight).  ACCS = 4 gives every k-lane its own accumulator; the
+// partials are summed once per tile (48 v_add per tile and wave).
+template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi, int ACCS = 1, bool ROT = false>
 __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, int n_lo) {
     constexpr int KS = 4 / (WR * WC);                // waves sharing one wave tile: they split every k-step between them
     static_assert(WR * WC * KS == 4 && (KS == 1 || KS == 2), "four waves");
@@ -219,6 +225,12 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
         __syncthreads();
     }
     const int nk = (K4 + BK - 1) / BK;
+    // Every workgroup walks the k-steps of a tile in its own rotation (sum order differs per workgroup, deterministically):
+    // launched together, the workgroups of a few-row product otherwise read the SAME column block of X and W at the same
+    // time, whose cache lines -- one per row, a row pitch apart -- sit on very few L2 channels when the pitch is a multiple
+    // of a few KB (K = 512, 1536, ...).
+    const int krot = ROT ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)nk) : 0;
+    auto kmap = [&](int ks_) { const int v = ks_ + krot; return ROT ? (v >= nk ? v - nk : v) : ks_; };
     const int lrow = t / TPR, lkq = (t % TPR) * 4;    // loader coordinates
     const int brow = t / TPRB, bcq = (t % TPRB) * 4;  // B loader coordinates (row of the LDS layout, first of 4 columns)
     const int ecg = t % CG, erow = t / CG;            // epilogue coordinates
@@ -235,7 +247,8 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     // requests stay in flight under DEPTH steps of MFMA work (and a tile's epilogue).
     typename ALoad::template Raw<A_IT> ra[DEPTH];
     float4 rb[DEPTH][B_IT];
-    auto fetch = [&](typename ALoad::template Raw<A_IT> &qa, float4 (&qb)[B_IT], int64_t tile, int ks) {
+    auto fetch = [&](typename ALoad::template Raw<A_IT> &qa, float4 (&qb)[B_IT], int64_t tile, int ks_) {
+        const int ks = kmap(ks_);
         const int k = ks * BK + lkq;
         const bool kvalid = k < K4 && tile < tiles_m;
         aload.template issue<A_IT>(qa, tile * BM + lrow, RPL, k, P, kvalid);
@@ -273,8 +286,9 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     constexpr bool PF = DEPTH == 1;
     float4 fa[A_IT], fb[B_IT];
     auto prefinish = [&](int64_t nt) {
-        const bool kv0 = lkq < K4 && nt < tiles_m;
-        const typename ALoad::Params ap0 = aload.params_tab(nt_tab, K4, lkq, kv0);
+        const int k0 = kmap(0) * BK + lkq;
+        const bool kv0 = k0 < K4 && nt < tiles_m;
+        const typename ALoad::Params ap0 = aload.params_tab(nt_tab, K4, k0, kv0);
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) fa[i] = aload.template finish<A_IT>(ra[0], i, kv0 && (nt * BM + lrow + i * RPL < P), ap0);
 #pragma unroll
@@ -282,7 +296,8 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     };
     if (PF) prefinish(tile);
     int buf = 0;
-    f32x16 acc[TM][TN];
+    static_assert(ACCS == 1 || ACCS == 2 || ACCS == 4, "partial accumulators");
+    f32x16 acc[TM][TN], accp[ACCS > 1 ? ACCS - 1 : 1][TM][TN];     // accp: the extra partials (ACCS > 1)
     STAMP_DECL
     while (tile < tiles_m) {
 #pragma unroll
@@ -298,7 +313,11 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                        for (int r = 0; r < 16; ++r) {
+                            acc[i][j][r] = 0.f;
+#pragma unroll
+                            for (int u = 0; u < ACCS - 1; ++u) accp[u][i][j][r] = 0.f;
+                        }
             }
             float *Ab = As + buf * (BM * LDP), *Bb = Bs + buf * (BROWS * LDBS);
             if (PF && ks == 0) {
@@ -310,8 +329,9 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
                         *reinterpret_cast<float4 *>(&Bb[(brow + i * RPLB) * LDBS + bcq]) = fb[i];
                 asm volatile("" ::: "memory");      // keep these stores here: merged with the other branch's they cost 12 v_mov per k-step
             } else {
-                const bool kv = ks * BK + lkq < K4;
-                const typename ALoad::Params ap = aload.params_tab(nt_tab, K4, ks * BK + lkq, kv);
+                const int kc = kmap(ks) * BK + lkq;
+                const bool kv = kc < K4;
+                const typename ALoad::Params ap = aload.params_tab(nt_tab, K4, kc, kv);
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i)
                     *reinterpret_cast<float4 *>(&Ab[(lrow + i * RPL) * LDP + lkq]) =
@@ -346,16 +366,41 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                        if (ACCS == 4) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                            accp[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, accp[0][i][j], 0, 0, 0);
+                            accp[ACCS > 2 ? 1 : 0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, accp[ACCS > 2 ? 1 : 0][i][j], 0, 0, 0);
+                            accp[ACCS > 2 ? 2 : 0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, accp[ACCS > 2 ? 2 : 0][i][j], 0, 0, 0);
+                        } else if (ACCS == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                            accp[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, accp[0][i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                            accp[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, accp[0][i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                        }
                     }
             }
             buf ^= 1;
             STAMP(2)
             if (++ks < nk) continue;
             ks = 0;
+            if (ACCS > 1) {                                    // fold the partial accumulators (fixed order: deterministic)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[i][j][r];
+#pragma unroll
+                            for (int u = 0; u < ACCS - 1; ++u) v += accp[u][i][j][r];
+                            acc[i][j][r] = v;
+                        }
+            }
 
             // ---- epilogue: accumulators -> LDS image [BM][LDC] (aliases the operand buffers) -> rows
             if (PF) prefinish(tile + gridDim.x);           // next tile's first operands: consumed before any store goes out
@@ -431,14 +476,14 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     }
 }
 
-template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi>
+template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, int ACCS = 1, bool ROT = false, class ALoad, class Epi>
 int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, int n_lo = 0, int n_hi = 0) {
     int64_t tiles_m = pn2_cdiv(P, BM);
     unsigned tiles_n = (unsigned)pn2_cdiv((n_hi ? n_hi : N) - n_lo, BN);     // output columns [n_lo, n_hi) of N
     int64_t cap = (int64_t)pn2_num_cus() * MINB / tiles_n;  // MINB resident workgroups per CU in total
     if (cap < 1) cap = 1;
     unsigned gx = (unsigned)(tiles_m < cap ? tiles_m : cap);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi>), dim3(gx, tiles_n), dim3(NTHREADS),
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi, ACCS, ROT>), dim3(gx, tiles_n), dim3(NTHREADS),
                        (size_t)ALoad::kTab * K4 * sizeof(float), s, aload, bm, P, K4, N, epi, n_lo);
     return pn2_launch_status();
 }
@@ -456,10 +501,24 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
     // -- and 32x64 tiles whose four waves split every k-step in two (summed in the LDS image) double it again.
     // (register budget: three workgroups per CU for the loaders that keep two or three tensors in flight)
     constexpr int SMALL_MINB = ALoad::kRegs >= 8 ? 2 : 3;
-    if (N > 32 && cfg != 7 && cfg != 8 && pn2_cdiv(P, 64) * pn2_cdiv(N, 64) * 2 <= pn2_num_cus())
+    // These few-row launches put ONE workgroup on a CU (one wave per SIMD).  Round 3 looked for what bounds them (2048 x 1536 ->
+    // 256: 35 us, 45 TF) with four A/B builds, all selectable here and all measured EQUAL within 1 us: three k-steps in
+    // flight (2), four independent accumulator chains per tile (3), a rotated k order per workgroup against L2 channel camping
+    // (4), and 64-deep k-steps.  The counters say why (tools/exp/pmc_shape.sh): L2 requests return in ~190 cycles, but a
+    // k-step issues 8.4 VALU + 4.5 SALU instructions per MFMA (64-bit addresses, predicates, the BatchNorm transform) in a
+    // phase of its own -- with a single wave per SIMD nothing runs under the MFMAs (matrix pipe 31 % busy).  What helps is a
+    // second workgroup per CU in another phase, not a deeper ring.
+    static const int sdepth = pn2_env_int("PN2_NT_SMALL_DEPTH", 1);
+    if (N > 32 && cfg != 7 && cfg != 8 && pn2_cdiv(P, 64) * pn2_cdiv(N, 64) * 2 <= pn2_num_cus()) {
+        if (sdepth == 4) return launch_nt<32, 64, 32, 1, 2, 2, 1, BNN, true, 1, true>(aload, bm, P, K4, N, epi, s);   // rotated k order
+        if (sdepth == 3) return launch_nt<32, 64, 32, 1, 2, 2, 1, BNN, true, 4>(aload, bm, P, K4, N, epi, s);         // four chains per tile
+        if (sdepth == 2) return launch_nt<32, 64, 32, 1, 2, 2, 3, BNN, true>(aload, bm, P, K4, N, epi, s);            // three k-steps in flight
         return launch_nt<32, 64, 32, 1, 2, SMALL_MINB, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
-    if (N > 32 && cfg != 7 && pn2_cdiv(P, 64) * pn2_cdiv(N, 128) * 2 <= pn2_num_cus())
+    }
+    if (N > 32 && cfg != 7 && pn2_cdiv(P, 64) * pn2_cdiv(N, 128) * 2 <= pn2_num_cus()) {
+        if (sdepth == 4) return launch_nt<64, 64, 32, 2, 2, 2, 1, BNN, true, 1, true>(aload, bm, P, K4, N, epi, s);
         return launch_nt<64, 64, 32, 2, 2, SMALL_MINB, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    }
     if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     if (N <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
     // 65..96 output channels (64->96, 128->96 in MSG sa1): an exact 96-wide tile instead of 25 % padding MFMAs
@@ -511,7 +570,10 @@ int dispatch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStre
 
 // KS > 1 (narrow products, M and N <= 64): the tile has fewer than four 32x32 wave tiles, so KS waves share one and
 // take every KS-th pair of positions of a stage; each adds its own partial tile (a 32x32 tile is 1024 atomics).
-template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad, int KS = 1>
+// TD: register ring of prefetched stages (few-row products run ONE short chain of stages per workgroup, one or two workgroups per
+// CU: with a single stage in flight that chain runs at global-load latency, see dispatch_nt_vec).
+// ACCS: independent partial accumulators per tile (consecutive position pairs rotate over them), see gemm_nt_kernel.
+template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad, int KS = 1, int TD = 1, int ACCS = 1>
 __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk,
                                                               int M, int N, float *__restrict__ dW, int lddw,
                                                               float *__restrict__ dbias) {
@@ -535,56 +597,85 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
     const int brow = t / (BN / 4), bcq = (t % (BN / 4)) * 4;
     constexpr int AR = NTHREADS / (BM / 4), BR = NTHREADS / (BN / 4);
 
-    f32x16 acc[TM][TN];
+    static_assert(ACCS == 1 || ACCS == 2 || ACCS == 4, "partial accumulators");
+    static_assert((WG_BP / 2 / KS) % ACCS == 0, "position pairs of a stage rotate evenly over the partial accumulators");
+    f32x16 acc[TM][TN], accp[ACCS > 1 ? ACCS - 1 : 1][TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+#pragma unroll
+                for (int u = 0; u < ACCS - 1; ++u) accp[u][i][j][r] = 0.f;
+            }
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    typename DyLoad::template Raw<A_IT> ra;          // raw operands of the next stage (see the loader comment)
-    typename XLoad::template Raw<B_IT> rb;
-    auto fetch = [&](int64_t p0) {
-        dyload.template issue<A_IT>(ra, p0 + arow, AR, m0 + acq, p_end, m0 + acq < M);
-        xload.template issue<B_IT>(rb, p0 + brow, BR, n0 + bcq, p_end, n0 + bcq < N);
+    typename DyLoad::template Raw<A_IT> ra[TD];      // raw operands of the next TD stages (see the loader comment)
+    typename XLoad::template Raw<B_IT> rb[TD];
+    auto fetch = [&](int d, int64_t p0) {
+        dyload.template issue<A_IT>(ra[d], p0 + arow, AR, m0 + acq, p_end, m0 + acq < M);
+        xload.template issue<B_IT>(rb[d], p0 + brow, BR, n0 + bcq, p_end, n0 + bcq < N);
     };
 
     // a thread's channel quads are fixed for the whole launch: the per-channel constants are fetched once
     const typename DyLoad::Params dp = dyload.params(m0 + acq, m0 + acq < M);
     const typename XLoad::Params xp = xload.params(n0 + bcq, n0 + bcq < N);
-    if (p_begin < p_end) fetch(p_begin);
+#pragma unroll
+    for (int d = 0; d < TD; ++d)
+        if (p_begin + (int64_t)d * WG_BP < p_end) fetch(d, p_begin + (int64_t)d * WG_BP);
     int buf = 0;
-    for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_BP) {
-        float *Ab = As[buf], *Bb = Bs[buf];
+    for (int64_t p0 = p_begin; p0 < p_end;) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const float4 v = dyload.template finish<A_IT>(ra, i, (p0 + arow + i * AR < p_end) && (m0 + acq < M), dp);
-            *reinterpret_cast<float4 *>(&Ab[(arow + i * AR) * LDA + acq]) = v;
-            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+        for (int d = 0; d < TD; ++d) {
+            if (p0 >= p_end) break;
+            float *Ab = As[buf], *Bb = Bs[buf];
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const float4 v = dyload.template finish<A_IT>(ra[d], i, (p0 + arow + i * AR < p_end) && (m0 + acq < M), dp);
+                *reinterpret_cast<float4 *>(&Ab[(arow + i * AR) * LDA + acq]) = v;
+                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                *reinterpret_cast<float4 *>(&Bb[(brow + i * BR) * LDB + bcq]) =
+                    xload.template finish<B_IT>(rb[d], i, (p0 + brow + i * BR < p_end) && (n0 + bcq < N), xp);
+            if (p0 + (int64_t)TD * WG_BP < p_end) fetch(d, p0 + (int64_t)TD * WG_BP);
+            __syncthreads();
+#pragma unroll
+            for (int kq = 0; kq < WG_BP / 2 / KS; ++kq) {
+                const int kk = kq * KS + ks;
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = Ab[(kk * 2 + lh) * LDA + wr * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bb[(kk * 2 + lh) * LDB + wc * WTN + j * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int u = kq % ACCS;                  // static after unrolling
+                        if (u == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        else accp[ACCS > 1 ? u - 1 : 0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], accp[ACCS > 1 ? u - 1 : 0][i][j], 0, 0, 0);
+                    }
+            }
+            buf ^= 1;
+            p0 += WG_BP;
         }
+    }
+    if (ACCS > 1) {
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            *reinterpret_cast<float4 *>(&Bb[(brow + i * BR) * LDB + bcq]) =
-                xload.template finish<B_IT>(rb, i, (p0 + brow + i * BR < p_end) && (n0 + bcq < N), xp);
-        if (p0 + WG_BP < p_end) fetch(p0 + WG_BP);
-        __syncthreads();
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int kq = 0; kq < WG_BP / 2 / KS; ++kq) {
-            const int kk = kq * KS + ks;
-            float a[TM], b[TN];
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ab[(kk * 2 + lh) * LDA + wr * WTM + i * 32 + l31];
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bb[(kk * 2 + lh) * LDB + wc * WTN + j * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        buf ^= 1;
+                    for (int u = 0; u < ACCS - 1; ++u) v += accp[u][i][j][r];
+                    acc[i][j][r] = v;
+                }
     }
 
     if constexpr (KS > 1) {
@@ -753,7 +844,7 @@ int launch_skinny(const float *dZ, int ldz, const float *Y, int ldy, const float
     return pn2_launch_status();
 }
 
-template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, int KS = 1, class DyLoad, class XLoad>
+template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, int KS = 1, int TD = 1, int ACCS = 1, class DyLoad, class XLoad>
 int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s,
               int per_cu = MINB) {
     unsigned tm = (unsigned)pn2_cdiv(M, BM), tn = (unsigned)pn2_cdiv(N, BN);
@@ -766,7 +857,7 @@ int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, in
     if (split > 65535) split = 65535;
     int64_t chunk = pn2_cdiv(pn2_cdiv(P, split), WG_BP) * WG_BP;
     split = pn2_cdiv(P, chunk);
-    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad, KS>), dim3(tm, tn, (unsigned)split), dim3(NTHREADS), 0, s,
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad, KS, TD, ACCS>), dim3(tm, tn, (unsigned)split), dim3(NTHREADS), 0, s,
                        dyload, xload, P, chunk, M, N, dW, lddw, dbias);
     return pn2_launch_status();
 }
@@ -796,8 +887,12 @@ int dispatch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, 
     // (the same holds up to P = 65 536 -- 65 536 x 128 x 128: 52.6 -> 35.5 us, 32 768 x 256 x 320: 90 -> 81 us -- and at
     // P = 131 072 for a 128 x 128 product, 72 -> 65 us, but not for 256 x 128, 118 -> 140 us)
     static const int small_p = pn2_env_int("PN2_TN_SMALLP", 65536);
-    if ((P <= small_p || (P <= 2 * (int64_t)small_p && (int64_t)M * N <= 16384)) && cfg != 3)
+    if ((P <= small_p || (P <= 2 * (int64_t)small_p && (int64_t)M * N <= 16384)) && cfg != 3) {
+        static const int tdepth = pn2_env_int("PN2_TN_SMALL_DEPTH", 2);     // stages in flight (latency-bound chains: see TD)
+        if (tdepth >= 3) return launch_tn<64, 64, 32, 2, 2, 2, 1, 2, 1>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+        if (tdepth == 2) return launch_tn<64, 64, 32, 2, 2, 2, 1, 2, 4>(dyload, xload, P, M, N, dW, lddw, dbias, s);
         return launch_tn<64, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
+    }
     if (cfg == 1 || P < 131072) {
         if (narrow_n) return launch_tn<128, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
         if (M <= 64) return launch_tn<64, 128, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);

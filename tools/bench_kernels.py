@@ -17,11 +17,15 @@ from pointnet12_amd import _lib
 from pointnet12_amd._lib import ptr as p
 
 FWD = [(1048576, 9, 64), (1048576, 64, 96), (1048576, 96, 128), (524288, 64, 64), (524288, 64, 128), (262144, 323, 128),
-       (262144, 128, 196), (262144, 196, 256), (131072, 323, 128), (131072, 128, 256), (262144, 32, 64), (65536, 128, 128)]
+       (262144, 128, 196), (262144, 196, 256), (131072, 323, 128), (131072, 128, 256), (262144, 32, 64), (65536, 128, 128),
+       (65536, 137, 128), (8192, 576, 256), (8192, 256, 128), (8192, 320, 128), (2048, 515, 256), (2048, 256, 512), (2048, 512, 1024), (2048, 1536, 256),
+       (2048, 256, 256)]
 # backward shapes: (P, C_l, C_{l-1}, pooled K or 0)
 BWD = [(1048576, 64, 9, 0), (524288, 64, 9, 0), (262144, 32, 9, 0), (1048576, 128, 96, 128), (1048576, 96, 64, 0), (262144, 256, 196, 128), (262144, 196, 128, 0), (262144, 128, 323, 0),
        (524288, 128, 64, 64), (524288, 64, 64, 0), (131072, 256, 128, 64), (65536, 128, 128, 0),
-       (131072, 128, 128, 0), (65536, 128, 137, 0), (262144, 64, 32, 32), (262144, 32, 32, 0), (524288, 64, 32, 32), (524288, 32, 32, 0), (32768, 256, 256, 0), (32768, 256, 320, 0)]
+       (131072, 128, 128, 0), (65536, 128, 137, 0), (262144, 64, 32, 32), (262144, 32, 32, 0), (524288, 64, 32, 32), (524288, 32, 32, 0), (32768, 256, 256, 0), (32768, 256, 320, 0),
+       (8192, 128, 256, 0), (8192, 256, 576, 0), (8192, 128, 320, 0), (2048, 256, 256, 0), (2048, 256, 1536, 0), (2048, 1024, 512, 128), (2048, 512, 256, 0),
+       (2048, 256, 515, 0)]
 
 
 def r4(c):
@@ -51,11 +55,16 @@ def main():
     ap.add_argument("which", nargs="?", default="all")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="comma list of row counts P to keep (profiling runs)")
+    ap.add_argument("--shape", default="", help="keep only this shape: P,K,N (forward) / P,C_l,C_prev (backward)")
     args = ap.parse_args()
     if args.only:
         keep = {int(x) for x in args.only.split(",")}
         FWD[:] = [s_ for s_ in FWD if s_[0] in keep]
         BWD[:] = [s_ for s_ in BWD if s_[0] in keep]
+    if args.shape:
+        want = tuple(int(x) for x in args.shape.split(","))
+        FWD[:] = [s_ for s_ in FWD if s_[:3] == want]
+        BWD[:] = [s_ for s_ in BWD if s_[:3] == want]
     lib = _lib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
