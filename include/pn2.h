@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 6
+#define PN2_ABI_VERSION 7
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -345,6 +345,14 @@ int pn2_nll_loss_fwd(const float *logp, int ld, const int64_t *target, const flo
  * every element of dlogp [R, ld] is written. */
 int pn2_nll_loss_bwd(const int64_t *target, const float *weight, int64_t R, int C, int64_t ignore_index,
                      const float *grad_loss, const float *denom, float *dlogp, int ld, pn2_stream_t stream);
+/* F.log_softmax(x, dim=-1) of the segmentation heads (model/pointnet2.py:175; :46, :103, :138) on rows whose C <= 64 logits
+ * are the leading columns of a padded row (pitch ldx, a multiple of 4: the output of pn2_conv1x1_fwd as it stands -- no
+ * slice copy): out[r, c] = x[r, c] - max_c x - log sum_c exp(x - max) for c < C, pitch ldo >= C. */
+int pn2_log_softmax_fwd(const float *x, int ldx, int64_t R, int C, float *out, int ldo, pn2_stream_t stream);
+/* Its backward, grad_x[r, c] = grad_out[r, c] - exp(out[r, c]) * sum_c grad_out[r, c], written at pitch ldgx <= 64 with
+ * the pad columns c in [C, ldgx) set to zero: the padded gradient pn2_conv1x1_wgrad / _dgrad read as dZ. */
+int pn2_log_softmax_bwd(const float *grad_out, int ldg, const float *out, int ldo, int64_t R, int C, float *grad_x, int ldgx,
+                        pn2_stream_t stream);
 
 /* ---- the optimiser step and the loader's per-cloud preparation --------------
  * pn2_adam_step replaces torch.optim.Adam(params, lr, betas=(0.9, 0.999), eps=1e-08, weight_decay) of

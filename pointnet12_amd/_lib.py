@@ -59,12 +59,14 @@ SIGNATURES = {
     "pn2_nll_loss_workspace_bytes": (_i64, [_i64]),
     "pn2_nll_loss_fwd": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp]),
     "pn2_nll_loss_bwd": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp]),
+    "pn2_log_softmax_fwd": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp]),
+    "pn2_log_softmax_bwd": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _i, _vp]),
     "pn2_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i64, _vp, _vp, _i, _vp]),
     "pn2_prepare_clouds": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PN2_EUNSUPPORTED = -3            # include/pn2.h
 DWX_REPLICAS = 32        # PN2_DWX_REPLICAS of include/pn2.h
 

@@ -84,9 +84,76 @@ __global__ __launch_bounds__(kThreads) void nll_bwd_kernel(const int64_t *__rest
     dlogp[i] = v;
 }
 
+// log_softmax over the C leading columns of rows of pitch ldx (model/pointnet2.py:175, F.log_softmax(x, dim = -1) on the head's
+// [B*N, classes] logits): one thread per row, the row read as float4 quads (a 13-class row of pitch 16 is one 64-byte line).
+// ATen needs a copy (the logits arrive as a column slice of the padded GEMM output) plus its softmax kernel, and in the
+// backward a zero fill plus a strided copy to re-pad the gradient; here both directions read and write the padded layout.
+constexpr int kMaxClasses = 64;
+
+__global__ __launch_bounds__(kThreads) void log_softmax_fwd_kernel(const float *__restrict__ x, int ldx, int64_t R, int C,
+                                                                   float *__restrict__ out, int ldo) {
+    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= R) return;
+    const float *row = x + r * ldx;
+    float v[kMaxClasses];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < kMaxClasses / 4; ++q) {
+        if (4 * q >= C) break;
+        const float4 t = *reinterpret_cast<const float4 *>(row + 4 * q);     // ldx >= round4(C): the quad is inside the row
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+        if (c < C) m = fmaxf(m, v[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+        if (c < C) s += expf(v[c] - m);
+    const float lse = m + logf(s);
+    float *o = out + r * ldo;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+        if (c < C) o[c] = v[c] - lse;
+}
+
+// gx = g - exp(out) * sum(g) on the C leading columns of a row of pitch ldgx; the pad columns are written as zeros (the GEMM
+// backward that consumes gx reads whole float4 quads)
+__global__ __launch_bounds__(kThreads) void log_softmax_bwd_kernel(const float *__restrict__ g, int ldg, const float *__restrict__ out,
+                                                                   int ldo, int64_t R, int C, float *__restrict__ gx, int ldgx) {
+    const int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= R) return;
+    const float *gr = g + r * ldg, *orow = out + r * ldo;
+    float gv[kMaxClasses];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c)
+        if (c < C) { gv[c] = gr[c]; s += gv[c]; }
+    float *d = gx + r * ldgx;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c) {
+        if (c < C) d[c] = gv[c] - expf(orow[c]) * s;
+        else if (c < ldgx) d[c] = 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pn2_log_softmax_fwd(const float *x, int ldx, int64_t R, int C, float *out, int ldo, pn2_stream_t stream) {
+    PN2_CHECK_ARG(x && out && R > 0 && C > 0 && C <= kMaxClasses && ldx % 4 == 0 && ldx >= ((C + 3) & ~3) && ldo >= C);
+    hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3((unsigned)pn2_cdiv(R, kThreads)), dim3(kThreads), 0, pn2_s(stream), x, ldx, R, C, out, ldo);
+    return pn2_launch_status();
+}
+
+int pn2_log_softmax_bwd(const float *grad_out, int ldg, const float *out, int ldo, int64_t R, int C, float *grad_x, int ldgx,
+                        pn2_stream_t stream) {
+    PN2_CHECK_ARG(grad_out && out && grad_x && R > 0 && C > 0 && C <= kMaxClasses && ldg >= C && ldo >= C && ldgx >= C && ldgx <= kMaxClasses);
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)pn2_cdiv(R, kThreads)), dim3(kThreads), 0, pn2_s(stream), grad_out, ldg, out, ldo,
+                       R, C, grad_x, ldgx);
+    return pn2_launch_status();
+}
 
 int64_t pn2_nll_loss_workspace_bytes(int64_t R) {
     (void)R;

@@ -855,8 +855,9 @@ extern "C" int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_aff
 
 extern "C" int pn2_bn_pool_select(const float *pool_ws, const float *affine, int64_t G, int C, float *out, int ldo, int32_t *arg,
                                   pn2_stream_t stream) {
-    PN2_CHECK_ARG(pool_ws && affine && out && arg && G > 0 && C > 0 && C % 32 == 0 && ldo == C &&
-                  (reinterpret_cast<uintptr_t>(pool_ws) & 15) == 0);
+    // ldo: pitch of out AND of arg (out may be a column slice of a wider matrix: the concatenated MSG output)
+    PN2_CHECK_ARG(pool_ws && affine && out && arg && G > 0 && C > 0 && C % 32 == 0 && ldo >= C && ldo % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(pool_ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
     const int64_t n = G * (C >> 2);
     hipLaunchKernelGGL(bn_pool_select_kernel, dim3((unsigned)pn2_cdiv(n, 256)), dim3(256), 0, pn2_s(stream),
                        reinterpret_cast<const float2 *>(pool_ws), C, affine, C, G, C, out, ldo, arg);

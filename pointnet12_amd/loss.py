@@ -18,7 +18,8 @@ class _NllLoss(torch.autograd.Function):
     def forward(ctx, logp, target, weight, ignore_index):
         lib, st = _lib.load(), _lib.stream()
         R, C = logp.shape
-        ws = torch.zeros(lib.pn2_nll_loss_workspace_bytes(R), device=logp.device, dtype=torch.uint8)
+        from .pointnet_util import _zeros_small                         # the zero arena: no fill launch of its own
+        ws = _zeros_small(int(lib.pn2_nll_loss_workspace_bytes(R)), logp.device)
         res = torch.empty(2, device=logp.device, dtype=torch.float32)          # loss, sum of weights
         _lib.check(lib.pn2_nll_loss_fwd(_p(logp), C, _p(target), _p(weight), R, C, ignore_index, _p(ws), res.data_ptr(),
                                         res.data_ptr() + 4, st), "pn2_nll_loss_fwd")

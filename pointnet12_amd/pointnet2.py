@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .pointnet_util import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg,
-                            conv1x1, shared_mlp)
+                            conv1x1, log_softmax_rows, shared_mlp)
 
 
 class _ClsHead(nn.Module):
@@ -52,8 +52,8 @@ class _SegHead(nn.Module):
         B, C, N = l0_points.shape
         rows = l0_points.permute(0, 2, 1).reshape(B * N, C)
         feat = shared_mlp(rows, C, [self.conv1], [self.bn1], 0, self.training)
-        x = conv1x1(self.drop1(feat), self.conv2)
-        return F.log_softmax(x, dim=-1).view(B, N, -1), feat.view(B, N, -1).permute(0, 2, 1)
+        x = conv1x1(self.drop1(feat), self.conv2, padded=True)             # [B*N, round4(classes)], pad columns zero
+        return log_softmax_rows(x, self.conv2.out_channels).view(B, N, -1), feat.view(B, N, -1).permute(0, 2, 1)
 
 
 class PointNet2ClsMsg(_ClsHead):

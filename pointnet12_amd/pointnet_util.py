@@ -66,7 +66,7 @@ def _empty_rows(rows, cols, device):
 # once; the chunk's storage is released when the last view dies.  Under stream capture the arena is only used
 # inside a capture scope announced by pointnet12_amd.graph (a chunk allocated in one capture must not leak into
 # another graph or into eager code: its memset is part of that graph only).
-_ZERO_CHUNK_BYTES = 4 << 20
+_ZERO_CHUNK_BYTES = 16 << 20
 _zero_arenas = {}
 _capture_scope = None
 
@@ -82,7 +82,7 @@ def set_capture_scope(token):
 def _zeros_small(nbytes, device):
     """uint8[nbytes], zero, 256-byte aligned."""
     capturing = torch.cuda.is_current_stream_capturing()
-    if nbytes > _ZERO_CHUNK_BYTES // 4 or (capturing and _capture_scope is None):
+    if nbytes > _ZERO_CHUNK_BYTES // 2 or (capturing and _capture_scope is None):
         return torch.zeros(nbytes, device=device, dtype=torch.uint8)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, _capture_scope if capturing else None)
     a = _zero_arenas.get(key)
@@ -91,6 +91,31 @@ def _zeros_small(nbytes, device):
     off = a[1]
     a[1] = off + ((nbytes + 255) & ~255)
     return a[0][off:off + nbytes]
+
+
+def _zeros_f32(shape, device):
+    """A zero-initialised float32 tensor from the arena: the scatter targets of the backward pass (a few MB each) share the
+    chunk's one clear instead of a fill launch apiece."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return _zeros_small(4 * n, device).view(torch.float32).view(*shape)
+
+
+_const_zeros = {}
+
+
+def _zero_centres(B, C, device):
+    """new_xyz of group_all (pointnet_util.py:151): a constant, created once per (device, B, C) outside any capture."""
+    key = (device.index, B, C)
+    t = _const_zeros.get(key)
+    if t is None:
+        t = torch.zeros(B, 1, C, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            return t
+        torch.cuda.current_stream(device).synchronize()
+        _const_zeros[key] = t
+    return t
 
 
 def _contig_weight(w):
@@ -155,7 +180,7 @@ class _GatherRows(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, C, M = ctx.shape
         grad = grad.contiguous()
-        gp = torch.zeros(B, N, C, device=grad.device, dtype=torch.float32)
+        gp = _zeros_f32((B, N, C), grad.device)
         _check(_lib.load().pn2_gather_rows_bwd(_p(grad), _p(idx), B, N, C, M, _p(gp), _lib.stream()),
                "pn2_gather_rows_bwd")
         return gp, None, None
@@ -338,7 +363,7 @@ class _Group(torch.autograd.Function):
         gp = None
         if D > 0 and ctx.needs_input_grad[1]:
             grad_rows = grad_rows.contiguous()
-            gp = torch.zeros(B, N, D, device=grad_rows.device, dtype=torch.float32)
+            gp = _zeros_f32((B, N, D), grad_rows.device)
             _check(_lib.load().pn2_group_bwd(_p(grad_rows), _p(idx), B, N, S, K, D, xyz_first, ld, _p(gp),
                                              _lib.stream()), "pn2_group_bwd")
         return None, gp, None, None, None, None, None
@@ -393,7 +418,7 @@ class _InterpCat(torch.autograd.Function):
         if D1 and ctx.needs_input_grad[0]:
             g1 = grad_rows.view(B, N, ld)[:, :, :D1]        # a strided view: no copy kernel
         if ctx.needs_input_grad[1]:
-            g2 = torch.zeros(B, S, D2, device=grad_rows.device, dtype=torch.float32)
+            g2 = _zeros_f32((B, S, D2), grad_rows.device)
         if ctx.needs_input_grad[1] and inv_off is not None:         # segmented reduction over the target-sorted index
             _check(lib.pn2_three_interp_bwd_seg(_p(grad_rows), ld, D1, _p(inv_off), _p(inv_mem), _p(w), B, N, S, D2, _p(g2), st),
                    "pn2_three_interp_bwd_seg")
@@ -418,6 +443,8 @@ FUSED_BN_TAILS = os.environ.get("PN2_FUSED_BN_TAILS", "0") == "1"
 POOL_IN_EPILOGUE = os.environ.get("PN2_POOL_EPILOGUE", "1") == "1"
 # narrow first layers: gather + first conv in one launch (pn2_group_conv_fwd); 0: pn2_group then the GEMM (A/B runs)
 GATHER_CONV = os.environ.get("PN2_GATHER_CONV", "1") == "1"
+# MSG scales write their pooled outputs into column slices of one matrix instead of torch.cat; 0: A/B runs
+MSG_CONCAT_IN_PLACE = os.environ.get("PN2_MSG_CONCAT_IN_PLACE", "1") == "1"
 _REPL = 8                         # PN2_STAT_REPLICAS of include/pn2.h
 _MALL_CHUNK_BYTES = 1 << 62       # row-chunked dgrad+wgrad pairing is OFF: measured 10.9 -> 13.1 ms/step at 96 MiB chunks
                                   # (per-launch fixed costs beat the Infinity-Cache hits); kept as a tuning knob
@@ -451,6 +478,10 @@ class _SharedMLP(torch.autograd.Function):
     ``bn_cfg`` = per layer (eps, momentum).  pool == 0: no pooling, output [P, C_L] (FP);
     pool == K: output [P/K, C_L] (SA).  Pre-BN activations of every layer are kept for backward.
 
+    ``dest`` = None, or (buffer [G, ld], first column): the pooled output is written straight into that column slice of a wider
+    matrix (the concatenated output of the MSG scales, pointnet_util.py:260) instead of a tensor of its own that a
+    ``torch.cat`` would copy; the returned tensor is that slice.
+
     ``geom`` = None, or (xyz [B,N,3], new_xyz [B,S,3], idx [B,S,K], xyz_first) for the FACTORISED first layer:
     ``rows`` is then the un-grouped feature tensor [B,N,D] and layer 1 is evaluated as
     ``Zf[b, idx] + W_x (xyz[idx] - centre)`` with ``Zf = W_f f + bias`` computed once per source point
@@ -458,7 +489,7 @@ class _SharedMLP(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, rows, c_in, pool, training, bn_cfg, geom, *flat):
+    def forward(ctx, rows, c_in, pool, training, bn_cfg, geom, dest, *flat):
         lib, st = _lib.load(), _lib.stream()
         dev = rows.device
         L = len(flat) // 7
@@ -539,12 +570,18 @@ class _SharedMLP(torch.autograd.Function):
         cl = chans[-1]
         K = pool if pool else 1
         G = P // K
-        out = _empty_rows(G, cl, dev)
-        arg = torch.empty(G, out.shape[1], device=dev, dtype=torch.int32) if pool else None
-        if pool_ws is not None:
-            _check(lib.pn2_bn_pool_select(_p(pool_ws), _p(affs[-1]), G, cl, _p(out), out.shape[1], _p(arg), st), "pn2_bn_pool_select")
+        if dest is not None and pool and cl % 4 == 0:
+            big, col0 = dest
+            out = big[:, col0:col0 + cl]                       # pitch of the wide matrix; the kernels take it as ldo
         else:
-            _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), out.shape[1], _p(arg), st),
+            out = _empty_rows(G, cl, dev)
+        ldo = out.stride(0)
+        # the argmax shares the output's pitch inside the kernels (arg + g * ldo + c): its own buffer, same pitch
+        arg = torch.empty(G, ldo, device=dev, dtype=torch.int32) if pool else None
+        if pool_ws is not None:
+            _check(lib.pn2_bn_pool_select(_p(pool_ws), _p(affs[-1]), G, cl, _p(out), ldo, _p(arg), st), "pn2_bn_pool_select")
+        else:
+            _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), ldo, _p(arg), st),
                    "pn2_bn_relu_max")
         if training:
             bump_param_generation()             # running statistics were written through raw pointers
@@ -572,7 +609,7 @@ class _SharedMLP(torch.autograd.Function):
         Ws, gammas = saved[3 + 2 * L:3 + 3 * L], saved[3 + 3 * L:3 + 4 * L]
         dev = rows.device
         cl = chans[-1]
-        ldo = out.shape[1]
+        ldo = out.stride(0)                    # (a column slice of a wider matrix when the forward was given a ``dest``)
         # The pooled branch reads the incoming gradient once, scalar-wise, at any pitch: a column slice of a wider matrix (a
         # branch of a concatenated MSG output) or an un-padded [G, cl] matrix is passed in place -- no copy kernel at the head
         # of the branch's backward chain.
@@ -581,7 +618,7 @@ class _SharedMLP(torch.autograd.Function):
             ld_grad = grad_out.stride(0)
         else:
             if ldo != cl:
-                g = torch.zeros_like(out)
+                g = torch.zeros(out.shape[0], ldo, device=dev, dtype=torch.float32)
                 g[:, :cl] = grad_out
                 grad_out = g
             grad_out = grad_out.contiguous()
@@ -623,7 +660,7 @@ class _SharedMLP(torch.autograd.Function):
         red_L = red[offs[L - 1]:offs[L]]
         dzp = None
         if pool:
-            dzp = torch.empty_like(out)          # dOut masked by out > 0: the pooled form of dZ_L the GEMM loaders read
+            dzp = torch.empty(G, ldo, device=dev, dtype=torch.float32)    # dOut masked by out > 0: the pooled form of dZ_L the GEMM loaders read (pitch ldo, as arg)
             _check(lib.pn2_pool_bwd_reduce_ld(_p(grad_out), ld_grad, _p(out), ldo, _p(arg), _p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]),
                                               G, K, cl, _p(dzp), _p(red_L), coef_tail(L - 1), st), "pn2_pool_bwd_reduce_ld")
         else:
@@ -712,11 +749,11 @@ class _SharedMLP(torch.autograd.Function):
         if ctx.gather is not None and d_rows is not None:          # gradient of the grouped rows -> the gathered source points
             gB, gN, gD = ctx.gather
             g_idx = ctx.geom[2]
-            gp = torch.zeros(gB, gN, gD, device=dev, dtype=torch.float32)
+            gp = _zeros_f32((gB, gN, gD), dev)
             _check(lib.pn2_group_bwd(_p(d_rows), _p(g_idx), gB, gN, g_idx.shape[1], g_idx.shape[2], gD, int(ctx.geom[3]),
                                      d_rows.shape[1], _p(gp), st), "pn2_group_bwd")
             d_rows = gp
-        return (d_rows, None, None, None, None, None) + tuple(grads)
+        return (d_rows, None, None, None, None, None, None) + tuple(grads)
 
     @staticmethod
     def _first_layer_bwd(ctx, feats, w, dZ, y, coef, co, need_dfeat, w_grad):
@@ -732,7 +769,7 @@ class _SharedMLP(torch.autograd.Function):
         dW = _zeros_small(4 * co * (3 + D), dev).view(torch.float32).view(co, 3 + D) if w_grad is None else w_grad
         ldw = 3 + D
         x_col, f_col = (0, 3) if g_first else (D, 0)
-        G = torch.zeros(B * N, ldc, device=dev, dtype=torch.float32)
+        G = _zeros_f32((B * N, ldc), dev)
         if g_inv is not None and co <= 256:           # segmented reduction over the source-sorted ball-query index
             scratch = _zeros_small(4 * _lib.DWX_REPLICAS * 3 * ldc, dev) if DWX_REPLICAS_SCRATCH else None
             _check(lib.pn2_group_affine_bwd_seg(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new),
@@ -765,7 +802,7 @@ class _Conv1x1(torch.autograd.Function):
     Backward reuses pn2_conv1x1_dgrad / pn2_conv1x1_wgrad with identity BN coefficients."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias):
+    def forward(ctx, rows, weight, bias, padded=False):
         lib, st = _lib.load(), _lib.stream()
         P, ldx = rows.shape
         co = weight.shape[0]
@@ -776,7 +813,10 @@ class _Conv1x1(torch.autograd.Function):
         ctx.save_for_backward(rows, weight)
         ctx.params = (weight, bias)             # leaf parameters (no grad_fn): no reference cycle
         ctx.dims = (P, ci, co, ldx, y.shape[1])
-        return y[:, :co] if y.shape[1] != co else y
+        ctx.padded = bool(padded)
+        # padded: the [P, round4(co)] matrix as the GEMM wrote it (pad columns zero), for a consumer that reads the padded
+        # layout itself (log_softmax_rows) -- the gradient then comes back padded too, with no zero fill + slice copy
+        return y if (padded or y.shape[1] == co) else y[:, :co]
 
     @staticmethod
     def backward(ctx, grad):
@@ -784,7 +824,7 @@ class _Conv1x1(torch.autograd.Function):
         rows, weight = ctx.saved_tensors
         P, ci, co, ldx, ldy = ctx.dims
         dev = rows.device
-        if ldy != co:
+        if ldy != co and not ctx.padded:
             g = torch.zeros(P, ldy, device=dev, dtype=torch.float32)
             g[:, :co] = grad
         else:
@@ -806,14 +846,46 @@ class _Conv1x1(torch.autograd.Function):
                                          None, 0, None,
                                          _p(d_rows), ldx, None, P, co, ci, None, st), "pn2_conv1x1_dgrad")
         if direct:
-            return d_rows, None, None
-        return d_rows, dW.view_as(weight), db
+            return d_rows, None, None, None
+        return d_rows, dW.view_as(weight), db, None
 
 
-def conv1x1(rows, conv):
-    """rows [P, round4(C_in)] -> [P, C_out] through ``conv`` (an nn.Conv1d/Conv2d with kernel size 1), HIP kernels."""
+def conv1x1(rows, conv, padded=False):
+    """rows [P, round4(C_in)] -> [P, C_out] through ``conv`` (an nn.Conv1d/Conv2d with kernel size 1), HIP kernels.
+    ``padded``: return the [P, round4(C_out)] matrix as the GEMM wrote it (for ``log_softmax_rows``)."""
     rows = _gpu_f32(rows, "rows")
-    return _Conv1x1.apply(rows, conv.weight, conv.bias)
+    return _Conv1x1.apply(rows, conv.weight, conv.bias, padded)
+
+
+class _LogSoftmaxRows(torch.autograd.Function):
+    """F.log_softmax(x[:, :C], dim=-1) (model/pointnet2.py:175) on the padded logits [P, round4(C)] of ``conv1x1(...,
+    padded=True)``: one HIP launch each way, the gradient is handed back in the padded layout."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        out = torch.empty(x.shape[0], C, device=x.device, dtype=torch.float32)
+        _check(_lib.load().pn2_log_softmax_fwd(_p(x), x.shape[1], x.shape[0], C, _p(out), C, _lib.stream()), "pn2_log_softmax_fwd")
+        ctx.save_for_backward(out)
+        ctx.ld = x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        out, = ctx.saved_tensors
+        P, C = out.shape
+        if grad.stride(-1) != 1:
+            grad = grad.contiguous()
+        gx = torch.empty(P, ctx.ld, device=out.device, dtype=torch.float32)
+        _check(_lib.load().pn2_log_softmax_bwd(_p(grad), grad.stride(0), _p(out), C, P, C, _p(gx), ctx.ld, _lib.stream()),
+               "pn2_log_softmax_bwd")
+        return gx, None
+
+
+def log_softmax_rows(x_padded, C):
+    """[P, round4(C)] padded logits -> [P, C] log-probabilities (HIP); falls back to ATen beyond 64 classes."""
+    if C > 64 or x_padded.shape[1] > 64:
+        return torch.nn.functional.log_softmax(x_padded[:, :C], dim=-1)
+    return _LogSoftmaxRows.apply(_gpu_f32(x_padded, "logits"), C)
 
 
 def _flat_params(convs, bns):
@@ -826,15 +898,16 @@ def _flat_params(convs, bns):
     return flat, tuple(cfg)
 
 
-def shared_mlp(rows, c_in, convs, bns, pool, training):
-    """rows [P, ld] -> [P/pool, C_out] (pool > 0) or [P, C_out] (pool == 0) through the HIP kernels."""
+def shared_mlp(rows, c_in, convs, bns, pool, training, dest=None):
+    """rows [P, ld] -> [P/pool, C_out] (pool > 0) or [P, C_out] (pool == 0) through the HIP kernels.
+    ``dest`` (training, pooled): see _SharedMLP."""
     flat, cfg = _flat_params(convs, bns)
     rows = _gpu_f32(rows, "rows")
     if rows.dim() != 2 or rows.shape[1] != _r4(c_in):
         raise RuntimeError("rows must be [P, round4(c_in)] with zero pad columns")
     if not training and _fused_eval_ok(c_in, convs, pool) and (pool == 0 or rows.shape[0] % pool == 0):
         return fused_eval_rows(rows, c_in, convs, bns, pool)
-    return _SharedMLP.apply(rows, c_in, pool, training, cfg, None, *flat)
+    return _SharedMLP.apply(rows, c_in, pool, training, cfg, None, dest, *flat)
 
 
 # ------------------------------------------------------------------------------------- eval-mode fused module
@@ -946,7 +1019,7 @@ def _group_inverse(idx, N, D, n_layers, training):
     return _inverse_index(idx.view(B, S * K), N)
 
 
-def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training, inv=None):
+def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training, inv=None, dest=None):
     """Group + shared MLP + max over the K neighbours of one SA scale -> [B*S, C_out].
 
     With enough input features (and a trainable stack of >= 2 layers) the first layer runs factorised over
@@ -958,14 +1031,14 @@ def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training, inv=
         return fused_eval_grouped(xyz, points, new_xyz, idx.contiguous(), S, K, xyz_first, convs, bns)
     if _factorised(D, len(convs), training):
         flat, cfg = _flat_params(convs, bns)
-        return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx, xyz_first, inv), *flat)
+        return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx, xyz_first, inv), dest, *flat)
     if (GATHER_CONV and not FUSED_BN_TAILS and 1 <= D <= 9 and convs[0].out_channels in (32, 64) and (B * S * K) % 64 == 0 and new_xyz is not None and
             idx is not None):
         # narrow first layer (the sa1 stacks): pn2_group and the first conv are one launch (pn2_group_conv_fwd)
         flat, cfg = _flat_params(convs, bns)
-        return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx.contiguous(), xyz_first, None, True), *flat)
+        return _SharedMLP.apply(points, 3 + D, K, training, cfg, (xyz, new_xyz, idx.contiguous(), xyz_first, None, True), dest, *flat)
     rows = _Group.apply(xyz, points, new_xyz, idx, S, K, xyz_first)
-    return shared_mlp(rows, 3 + D, convs, bns, K, training)
+    return shared_mlp(rows, 3 + D, convs, bns, K, training, dest)
 
 
 # --------------------------------------------------------------------------------------- grouping API
@@ -996,7 +1069,7 @@ def sample_and_group_all(xyz, points):
     """pointnet_util.py:140-157: -> zeros [B,1,3], [B,1,N,3+D] (xyz NOT centred)."""
     xyz = _gpu_f32(xyz, "xyz")
     B, N, C = xyz.shape
-    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)          # a fresh tensor: the caller of the public function owns it
     pts = None if points is None else _gpu_f32(points, "points")
     rows = _Group.apply(xyz, pts, None, None, 1, N, True)
     D = 0 if pts is None else pts.shape[2]
@@ -1029,7 +1102,7 @@ class PointNetSetAbstraction(nn.Module):
         pts = None if points is None else _channel_last(points, "points")
         B, N, _ = xyz.shape
         if self.group_all:
-            new_xyz = torch.zeros(B, 1, 3, device=xyz.device)
+            new_xyz = _zero_centres(B, 3, xyz.device)
             if not _recording() and not self.training and _fused_eval_ok(3 + (0 if pts is None else pts.shape[2]), self.mlp_convs, N):
                 out = fused_eval_grouped(xyz, pts, None, None, 1, N, True, self.mlp_convs, self.mlp_bns)
                 return new_xyz.permute(0, 2, 1), out.view(B, 1, -1).permute(0, 2, 1)
@@ -1092,6 +1165,14 @@ class PointNetSetAbstractionMsg(nn.Module):
             main = torch.cuda.current_stream(xyz.device)
             streams = _scale_streams(xyz.device, len(self.radius_list))
         n_scales = len(self.radius_list)
+        # Every scale writes its pooled output straight into its column slice of ONE [B*S, sum C] matrix (the layout
+        # torch.cat(new_points_list, dim=1) of pointnet_util.py:260 produces): no concatenation copy in the forward, and the
+        # backward hands each scale its slice of the incoming gradient in place.
+        widths = [c[-1].out_channels for c in self.conv_blocks]
+        big = None
+        if not _recording() and self.training and MSG_CONCAT_IN_PLACE and all(w % 4 == 0 for w in widths):
+            big = torch.empty(B * S, sum(widths), device=xyz.device, dtype=torch.float32)
+        col = 0
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             # the last scale stays on the calling stream: one branch fewer (a captured step then has four concurrent
@@ -1099,7 +1180,7 @@ class PointNetSetAbstractionMsg(nn.Module):
             on_side = branch and not (MSG_LAST_SCALE_ON_MAIN and i == n_scales - 1)
             if on_side:
                 streams[i].wait_stream(main)
-                for t in (xyz, pts, new_xyz):              # allocated on the main stream, read on the branch
+                for t in (xyz, pts, new_xyz, big):         # allocated on the main stream, used on the branch
                     if t is not None:
                         t.record_stream(streams[i])
                 ctx_mgr = torch.cuda.stream(streams[i])
@@ -1111,7 +1192,8 @@ class PointNetSetAbstractionMsg(nn.Module):
                 if _recording():
                     continue
                 outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
-                                        self.training, inv))                  # features first (:247)
+                                        self.training, inv, None if big is None else (big, col)))   # features first (:247)
+            col += widths[i]
         if branch:
             for i, (st, o) in enumerate(zip(streams, outs)):
                 if MSG_LAST_SCALE_ON_MAIN and i == n_scales - 1:
@@ -1120,8 +1202,28 @@ class PointNetSetAbstractionMsg(nn.Module):
                 o.record_stream(main)                      # produced on the branch, concatenated on the main stream
         if _recording():
             return new_xyz.permute(0, 2, 1), _placeholder(B, sum(c[-1].out_channels for c in self.conv_blocks), S, xyz.device)
-        out = torch.cat(outs, dim=1)                                          # [B*S, sum C]
+        in_place = big is not None and all(o.data_ptr() == big.data_ptr() + 4 * c0 and o.stride(0) == big.shape[1]
+                                           for o, c0 in zip(outs, np.cumsum([0] + widths[:-1])))
+        out = _ConcatView.apply(big, *outs) if in_place else torch.cat(outs, dim=1)       # [B*S, sum C]
         return new_xyz.permute(0, 2, 1), out.view(B, S, -1).permute(0, 2, 1)
+
+
+class _ConcatView(torch.autograd.Function):
+    """The concatenation of tensors that already ARE the column slices of ``big``: forward returns ``big`` (no copy), backward
+    hands every input its column slice of the gradient (views: the pooled backward reads them at their pitch)."""
+
+    @staticmethod
+    def forward(ctx, big, *parts):
+        ctx.widths = [p.shape[1] for p in parts]
+        return big.view(big.shape)
+
+    @staticmethod
+    def backward(ctx, grad):
+        outs, c0 = [], 0
+        for w in ctx.widths:
+            outs.append(grad[:, c0:c0 + w])
+            c0 += w
+        return (None,) + tuple(outs)
 
 
 class PointNetFeaturePropagation(nn.Module):
