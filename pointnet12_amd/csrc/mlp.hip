@@ -1186,6 +1186,9 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
 int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev, const float *prev_affine,
                    float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, hipStream_t s, int64_t *rows_done);
+int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
+                   const float *coef, const float *X, int ldx, const float *x_affine, float *dW, int lddw, float *dbias,
+                   int64_t P, int M, int N, hipStream_t s);
 
 extern "C" {
 
@@ -1345,8 +1348,12 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     PN2_CHECK_ARG(ldy % 4 == 0 && ldy >= round4(M) && ldx % 4 == 0 && ldx >= round4(N) && lddw >= N);
     const int ldc = round4(M);
     hipStream_t s = pn2_s(stream);
+    PN2_CHECK_ARG(dZ ? (ldz % 4 == 0 && ldz >= round4(M)) : (ldo % 4 == 0 && ldo >= round4(M)));
+    {                                                                   // wide layer: all of dW resident in one workgroup (mlp_wide.hip)
+        const int rc = pn2_wide_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, dbias, P, M, N, s);
+        if (rc != PN2_EUNSUPPORTED) return rc;
+    }
     if (dZ) {
-        PN2_CHECK_ARG(ldz % 4 == 0 && ldz >= round4(M));
         static const int skinny = pn2_env_int("PN2_WGRAD_SKINNY", 1);
         if (skinny && x_affine == nullptr && N <= 16 && P >= 4096) {     // first layers: stream dZ / Y once, no MFMA
             switch ((N + 3) / 4) {

@@ -414,3 +414,248 @@ int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
 #undef WIDE_DGRAD
     return PN2_EUNSUPPORTED;
 }
+
+// ================================================================================================ weight gradient
+// dW[M, N] += sum_p dY[p, m] X[p, n] on the wide layers, with the WHOLE product resident: one workgroup keeps all of dW in
+// the accumulator registers of its waves (wave w: output-channel block w x TNW input-channel blocks, 16 registers per 32 x 32
+// tile) and streams its share of the P rows through LDS in chunks of 32 positions.  Against the streamed kernel of mlp.hip
+// (128 x 128 tiles: dY re-read per N tile and X per M tile, 1.7x the algorithmic HBM traffic by the PMC counters of round 2,
+// one barrier per 32 MFMAs):
+//   * every operand row is read ONCE per launch (formed into dY / relu(bn(X)) once, by the thread that staged it);
+//   * a barrier interval is 16 x TNW MFMAs per wave (112 at 256 x 196), the staging of the next chunk rides between the
+//     position pairs of this one (see regw_nt_kernel);
+//   * the price is one full set of dW atomics per workgroup (256 x M x N floats at the memory side's ~1.3 TB/s: 39 us at
+//     256 x 196) -- it is a tail, not a rate.
+namespace {
+
+struct WgradArgs {
+    const float *Y; int ldy;                                       // this layer's pre-BN output [P, ldy]
+    const float *dZ; int ldz;                                      // dense dZ, or
+    const float *dZp; const int32_t *arg; int ldo;                 // pooled: [G, ldo], group size PKP (template)
+    const float *coef;                                             // c0, q1, q0, mean rows of pitch M4
+    const float *X; int ldx; const float *x_aff;                   // layer input [P, ldx]; its affine block (pitch N4) or null
+    float *dW; int lddw; float *dbias;
+    int64_t P; int64_t rows_per_wg; int M; int N;
+};
+
+template <int MM, int NN, int TNW, int DYM, bool XACT, int PKP, int BP, bool BIAS>
+__global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) void wgrad_full_kernel(const WgradArgs g) {
+    constexpr int MB = (MM + 31) / 32, NB = (NN + 31) / 32;
+    constexpr int WN = NB / TNW, NW = MB * WN, NT = 64 * NW;
+    constexpr int LDA = MB * 32 + 4, LDB = NB * 32 + 4;            // LDS row pitches (floats): the two half-waves of a b32
+                                                                   // operand read sit one row apart = 4 banks apart
+    constexpr bool POOLED = DYM == MODE_DYPOOLED;
+    static_assert(NB % TNW == 0 && NW <= 16, "wave grid");
+    float *As0 = wide_lds, *As1 = As0 + BP * LDA, *Bs0 = As1 + BP * LDA, *Bs1 = Bs0 + BP * LDB;
+    float *ctab = Bs1 + BP * LDB;                                  // 4 rows of MB * 32: c0, q1, q0, mean
+    float *xtab = ctab + 4 * MB * 32;                              // 3 rows of NB * 32: mean, scale, beta of the input BatchNorm
+    float *dump = xtab + 3 * NB * 32;                              // NT float4: where the dead items of a partly filled pass store
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int mb = wave / WN, nb0 = (wave % WN) * TNW;
+    constexpr int M = MM, N = NN, M4 = (M + 3) & ~3, N4 = (N + 3) & ~3;
+    constexpr int QA = M4 / 4, QB = N4 / 4;                        // quads per row that exist in memory
+
+    // ---- one-time: tables (zero beyond the real channels), zero pad columns of both chunk buffers
+    for (int i = t; i < 4 * MB * 32; i += NT) { const int r = i / (MB * 32), c = i - r * (MB * 32); ctab[i] = c < M4 ? g.coef[r * M4 + c] : 0.f; }
+    if (XACT)
+        for (int i = t; i < 3 * NB * 32; i += NT) { const int r = i / (NB * 32), c = i - r * (NB * 32); xtab[i] = c < N4 ? g.x_aff[r * N4 + c] : 0.f; }
+    for (int i = t; i < 2 * BP * LDA; i += NT) As0[i] = 0.f;       // (As0, As1 contiguous; Bs0, Bs1 contiguous)
+    for (int i = t; i < 2 * BP * LDB; i += NT) Bs0[i] = 0.f;
+
+    f32x16 acc[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int64_t p_begin = (int64_t)blockIdx.x * g.rows_per_wg;
+    const int64_t p_end = p_begin + g.rows_per_wg < g.P ? p_begin + g.rows_per_wg : g.P;
+    // staging items: dY quads idx = t + NT i over BP x QA, X quads over BP x QB (run-time QA / QB: the loops below are
+    // unrolled to the template bounds and predicated)
+    constexpr int ITA = (BP * QA + NT - 1) / NT, ITB = (BP * QB + NT - 1) / NT;
+    static_assert(!POOLED || NT % QA == 0, "pooled: a thread's dY items share one channel quad");
+    struct Raw { float4 y[ITA]; float4 z[POOLED ? 1 : ITA]; int4 a[1]; float4 x[ITB]; };
+    Raw raw;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Pooled dZ: NT % QA == 0 is required by the host (every item of a thread sits in the same channel quad) and the chunk
+    // lies inside one pooling group (BP <= PKP, chunks aligned to BP): one (dZp, arg) quad per thread and chunk.
+    auto fetch = [&](int64_t p0) {
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) {
+            const int idx = t + NT * i, row = idx / QA, q = idx - row * QA;
+            const int64_t p = p0 + row;
+            const bool v = row < BP && p < p_end;
+            const int64_t pc = v ? p : p_begin;                    // a dead item re-reads a valid row (zeroed / dumped when staged)
+            raw.y[i] = ld4(g.Y + row_off(pc, g.ldy) + 4 * q);
+            if (!POOLED) raw.z[POOLED ? 0 : i] = ld4(g.dZ + row_off(pc, g.ldz) + 4 * q);
+        }
+        if (POOLED) {
+            const int q = t % QA;
+            const int64_t grp = (p0 < p_end ? p0 : p_begin) / (PKP > 0 ? PKP : 1);
+            raw.z[0] = ld4(g.dZp + row_off(grp, g.ldo) + 4 * q);
+            raw.a[0] = ld4i(g.arg + row_off(grp, g.ldo) + 4 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) {
+            const int idx = t + NT * i, row = idx / QB, q = idx - row * QB;
+            const int64_t p = p0 + row;
+            const bool v = row < BP && p < p_end;
+            raw.x[i] = ld4(g.X + row_off(v ? p : p_begin, g.ldx) + 4 * q);
+        }
+    };
+    // (straight-line on purpose: an early return or a uniform branch around the staging would put it into basic blocks of
+    // its own, and the scheduler could not slide its VALU work between the MFMAs of the position pairs)
+    auto stage_a = [&](float *Ad, int64_t p0, int i) {
+        const int idx = t + NT * i, row = idx / QA, q = idx - row * QA;
+        const DyParams dp = dy_params_tab(ctab, MB * 32, 4 * q, true);
+        float4 dz = raw.z[POOLED ? 0 : i];
+        if (POOLED) {
+            const int4 a = raw.a[0];
+            const int kk = (int)((p0 + row) & (int64_t)(PKP - 1));
+            dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f;
+            dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
+        }
+        float4 v = dy_from(dz, raw.y[i], dp);
+        if (!(p0 + row < p_end)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>((BP * QA % NT == 0 || row < BP) ? &Ad[row * LDA + 4 * q] : &dump[4 * t]) = v;
+        if (BIAS) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+    };
+    auto stage_b = [&](float *Bd, int64_t p0, int i) {
+        const int idx = t + NT * i, row = idx / QB, q = idx - row * QB;
+        float4 x = raw.x[i];
+        if (XACT) {
+            const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]);
+            const float4 sc = *reinterpret_cast<const float4 *>(&xtab[NB * 32 + 4 * q]);
+            const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * NB * 32 + 4 * q]);
+            x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
+            x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+            x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
+            x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+        }
+        if (!(p0 + row < p_end)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>((BP * QB % NT == 0 || row < BP) ? &Bd[row * LDB + 4 * q] : &dump[4 * t]) = x;
+    };
+
+    float *Ac = As0, *An = As1, *Bc = Bs0, *Bn = Bs1;
+    if (p_begin < p_end) {
+        fetch(p_begin);
+        __syncthreads();                                            // tables and the zeroed buffers
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) stage_a(Ac, p_begin, i);
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) stage_b(Bc, p_begin, i);
+        fetch(p_begin + BP);                                        // (past the end: dead items, never staged as data)
+    }
+    for (int64_t p0 = p_begin; p0 < p_end; p0 += BP) {
+        __syncthreads();                                            // chunk p0 is in (Ac, Bc); every wave is done with (An, Bn)
+        const float *ap = Ac + lh * LDA + mb * 32 + l31;
+        const float *bp = Bc + lh * LDB + nb0 * 32 + l31;
+        float a[2], b[2][TNW];
+        a[0] = ap[0];
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) b[0][j] = bp[32 * j];
+#pragma unroll
+        for (int s = 0; s < BP / 2; ++s) {
+            asm volatile("" ::: "memory");
+            if (s + 1 < BP / 2) {
+                a[(s + 1) & 1] = ap[2 * (s + 1) * LDA];
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) b[(s + 1) & 1][j] = bp[2 * (s + 1) * LDB + 32 * j];
+            }
+            // the next chunk's staging rides behind the position pairs: dY items first, then X items, then the request for
+            // the chunk after it
+            // (always: past the end the items carry zeros, and nobody reads that chunk)
+#pragma unroll
+            for (int i = 0; i < ITA; ++i)
+                if (s == i) stage_a(An, p0 + BP, i);
+#pragma unroll
+            for (int i = 0; i < ITB; ++i)
+                if (s == ITA + i) stage_b(Bn, p0 + BP, i);
+            if (s == ITA + ITB) fetch(p0 + 2 * BP);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1], b[s & 1][j], acc[j], 0, 0, 0);
+        }
+        float *tp = Ac; Ac = An; An = tp;
+        tp = Bc; Bc = Bn; Bn = tp;
+    }
+    static_assert(ITA + ITB < BP / 2, "the staging must fit between the position pairs of a chunk");
+
+    // ---- flush: every accumulator register is 2 x 128 contiguous bytes of dW
+    const int m_base = mb * 32 + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int n = (nb0 + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + (r & 3) + 8 * (r >> 2);
+            if (m < M && n < N) atomicAdd(g.dW + (int64_t)m * g.lddw + n, acc[j][r]);
+        }
+    }
+    if (BIAS && g.dbias != nullptr) {                               // fold the row groups of each channel quad in LDS
+        __syncthreads();
+        float *sh = wide_lds;
+        *reinterpret_cast<float4 *>(&sh[t * 4]) = bsum;
+        __syncthreads();
+        static_assert(!BIAS || NT % QA == 0, "bias fold: thread t + QA k holds quad t");
+        if (t < QA) {
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = t; k < NT; k += QA) {
+                const float4 v = *reinterpret_cast<const float4 *>(&sh[k * 4]);
+                tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+            }
+            const int m = 4 * t;
+            if (m < M) atomicAdd(g.dbias + m, tot.x);
+            if (m + 1 < M) atomicAdd(g.dbias + m + 1, tot.y);
+            if (m + 2 < M) atomicAdd(g.dbias + m + 2, tot.z);
+            if (m + 3 < M) atomicAdd(g.dbias + m + 3, tot.w);
+        }
+    }
+}
+
+template <int MM, int NN, int TNW, int DYM, bool XACT, int PKP, int BP>
+int launch_wgrad_full(WgradArgs g, hipStream_t s) {
+    constexpr int MB = (MM + 31) / 32, NB = (NN + 31) / 32;
+    constexpr int NW = MB * (NB / TNW), LDA = MB * 32 + 4, LDB = NB * 32 + 4;
+    constexpr size_t lds = sizeof(float) * (2 * BP * LDA + 2 * BP * LDB + 4 * MB * 32 + 3 * NB * 32 + 4 * 64 * NW);
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = wgrad_full_kernel<MM, NN, TNW, DYM, XACT, PKP, BP, false>;
+    if (g.dbias != nullptr) return PN2_EUNSUPPORTED;              // (eval-mode bias gradients: the streamed kernel)
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
+    int64_t wgs = pn2_num_cus();
+    int64_t rows = pn2_cdiv(pn2_cdiv(g.P, wgs), BP) * BP;
+    if (PKP > 0 && rows % PKP != 0 && PKP % rows != 0) rows = pn2_cdiv(rows, PKP) * PKP;   // chunks never straddle a group: BP | PKP
+    g.rows_per_wg = rows;
+    wgs = pn2_cdiv(g.P, rows);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * NW), lds, s, g);
+    return pn2_launch_status();
+}
+
+}  // namespace
+
+// wide weight gradients (C_out x C_in): 256 x 196 and 256 x 128 on the max-pool's sparse dZ (groups of 64 or 128), 196 x 128 and
+// 128 x 128 dense; the input is always a BatchNorm + ReLU of the previous layer's output here
+int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
+                   const float *coef, const float *X, int ldx, const float *x_affine, float *dW, int lddw, float *dbias,
+                   int64_t P, int M, int N, hipStream_t s) {
+    static const int on = wide_env("PN2_WIDE", 1) && wide_env("PN2_WIDE_WGRAD", 1);
+    static const int min_rows = wide_env("PN2_WIDE_WGRAD_MIN_ROWS", 131072);
+    if (!on || P < min_rows || x_affine == nullptr || ldy != ((M + 3) & ~3) || ldx != ((N + 3) & ~3)) return PN2_EUNSUPPORTED;
+    if (!dZ && (Kpool <= 0 || P % Kpool != 0)) return PN2_EUNSUPPORTED;
+    WgradArgs g{};
+    g.Y = Y; g.ldy = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.coef = coef; g.X = X; g.ldx = ldx;
+    g.x_aff = x_affine; g.dW = dW; g.lddw = lddw; g.dbias = dbias; g.P = P; g.M = M; g.N = N;
+#define WIDE_WGRAD(MM, NN, TNW, PKP, BP)                                                                                 \
+    if (M == MM && N == NN && (PKP == 0 ? dZ != nullptr : (dZ == nullptr && Kpool == PKP)))                             \
+        return launch_wgrad_full<MM, NN, TNW, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, true, PKP, BP>(g, s);
+    WIDE_WGRAD(256, 196, 7, 128, 16)
+    WIDE_WGRAD(256, 196, 7, 64, 16)
+    WIDE_WGRAD(256, 128, 4, 64, 32)
+    WIDE_WGRAD(256, 128, 4, 128, 32)
+    WIDE_WGRAD(196, 128, 4, 0, 32)
+    // (128 x 128 at 131 072 rows: 64.4 us against 61.8 streamed -- the atomic tail of 256 full copies outweighs the saved
+    // re-reads on a product this small; instantiation dropped)
+#undef WIDE_WGRAD
+    return PN2_EUNSUPPORTED;
+}

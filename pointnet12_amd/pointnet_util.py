@@ -445,6 +445,21 @@ POOL_IN_EPILOGUE = os.environ.get("PN2_POOL_EPILOGUE", "1") == "1"
 GATHER_CONV = os.environ.get("PN2_GATHER_CONV", "1") == "1"
 # MSG scales write their pooled outputs into column slices of one matrix instead of torch.cat; 0: A/B runs
 MSG_CONCAT_IN_PLACE = os.environ.get("PN2_MSG_CONCAT_IN_PLACE", "1") == "1"
+# Few-row layers (sa3 / fp3 / fp2 of the segmentation nets: P = 2 k .. 8 k rows) put ONE workgroup on a CU and keep its matrix
+# pipe ~30 % busy (csrc/mlp.hip, dispatch_nt_vec); their weight-gradient GEMM feeds nothing downstream, so it is issued on a
+# companion stream and shares the CUs with the data-gradient GEMM of the same layer.  0 = off (A/B); rows up to which it is done.
+WGRAD_SIDE_MAX_ROWS = int(os.environ.get("PN2_WGRAD_SIDE_MAX_ROWS", "0"))
+_wgrad_streams = {}
+
+
+def _wgrad_side_stream(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    s = _wgrad_streams.get(key)
+    if s is None:
+        s = _wgrad_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 _REPL = 8                         # PN2_STAT_REPLICAS of include/pn2.h
 _MALL_CHUNK_BYTES = 1 << 62       # row-chunked dgrad+wgrad pairing is OFF: measured 10.9 -> 13.1 ms/step at 96 MiB chunks
                                   # (per-launch fixed costs beat the Infinity-Cache hits); kept as a tuning knob
@@ -669,6 +684,10 @@ class _SharedMLP(torch.autograd.Function):
                                            _p(dZ), dZ.shape[1], _p(red_L), coef_tail(L - 1), st), "pn2_relu_bwd_reduce")
         grads = [None] * (7 * L)
         d_rows = None
+        side, side_used = None, False
+        if 0 < P <= WGRAD_SIDE_MAX_ROWS:
+            main_stream = torch.cuda.current_stream(dev)
+            side = _wgrad_side_stream(dev)
         for l in range(L - 1, -1, -1):
             co, ci = chans[l + 1], chans[l]
             y, aff = Ys[l], affs[l]
@@ -740,12 +759,23 @@ class _SharedMLP(torch.autograd.Function):
                     else:
                         _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, ci, None, 0, None, c_dx,
                                                      ldx, None, rn, co, ci, None, st), "pn2_conv1x1_dgrad")
-                _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
-                                             None if training else _p(dbias), rn, co, ci, st), "pn2_conv1x1_wgrad")
+                if side is not None and chunk == P:
+                    # the weight gradient on the companion stream: ordered behind everything issued so far on this stream (the
+                    # coefficients, dZ), joined once at the end of this backward
+                    side.wait_stream(main_stream)
+                    with torch.cuda.stream(side):
+                        _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
+                                                     None if training else _p(dbias), rn, co, ci, _lib.stream()), "pn2_conv1x1_wgrad")
+                    side_used = True
+                else:
+                    _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
+                                                 None if training else _p(dbias), rn, co, ci, st), "pn2_conv1x1_wgrad")
             if not direct:
                 grads[7 * l] = dW.view_as(Ws[l])
             if l > 0:
                 dZ = dx
+        if side_used:
+            main_stream.wait_stream(side)
         if ctx.gather is not None and d_rows is not None:          # gradient of the grouped rows -> the gathered source points
             gB, gN, gD = ctx.gather
             g_idx = ctx.geom[2]
