@@ -178,7 +178,9 @@ def cpu_baseline_slice(workload, batch, n_points, npoint_scale):
     net = T.RefMSGSemSeg(13, 6, npoint_scale=npoint_scale) if workload == "msg" else T.RefSSGSemSeg(13, 6)
     net.train()
     model, n_phys, logical = _cpu_info()
-    threads = min(8, logical)
+    # SSG: 8 threads as everywhere else (30 GFLOP per cloud: seconds).  MSG with npoint x16 is 464 GFLOP of conv / BatchNorm
+    # per cloud -- a quarter of an hour at 8 threads -- so that leg uses every physical core of the host (stated in `cores`)
+    threads = min(8, logical) if workload == "ssg" else n_phys
     saved = torch.get_num_threads()
     try:
         torch.set_num_threads(threads)

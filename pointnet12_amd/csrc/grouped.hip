@@ -14,6 +14,8 @@
 
 namespace {
 
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
 // Per-channel sum(y), sum(y*y) for the training-mode BatchNorm are accumulated like in the GEMM epilogue:
 // fp32 per 64 rows -> fp64 registers -> LDS -> one fp64 atomic per channel per workgroup.
 __global__ __launch_bounds__(256) void group_affine_fwd_kernel(const float *__restrict__ Zf, int ldz,
@@ -187,6 +189,8 @@ __global__ __launch_bounds__(256) void group_affine_bwd_kernel(const float *__re
 // instead of two is worth 50 us (MSG 6.50 -> 6.45 ms).  An MFMA form (the weight-resident forward with a gathering loader)
 // would run at the store bound, ~75 us.  model/pointnet_util.py:127-131 + :197 (first conv), :243-247 + :254.
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ float pn2_gc_dump[1024 * 256 * 4];       // dump slots of group_conv_fwd_kernel (16 bytes per thread of 1024 workgroups)
+
 template <int CO>
 __global__ __launch_bounds__(256) void group_conv_fwd_kernel(const float *__restrict__ xyz, const float *__restrict__ points,
                                                              const float *__restrict__ new_xyz, const int64_t *__restrict__ idx,
@@ -194,86 +198,177 @@ __global__ __launch_bounds__(256) void group_conv_fwd_kernel(const float *__rest
                                                              const float *__restrict__ W, int ldw, const float *__restrict__ bias,
                                                              float *__restrict__ X, int ldx, float *__restrict__ Y, int ldy,
                                                              int64_t slabs, double *__restrict__ stats) {
-    constexpr int LT = CO + 4;                                     // tile pitch: 4 mod 8 floats (conflict-free b128 rows)
-    __shared__ __attribute__((aligned(16))) float Wl[CO * 12];    // [CO][12]: the row's 3 + D coefficients, zero padded
-    __shared__ __attribute__((aligned(16))) float bl[CO];         // bias (from LDS: a scalar load per channel would drain lgkmcnt)
+    // Round 3: the conv runs on the matrix cores.  A lane still gathers one grouped row (12 floats in registers, written once
+    // to X for the backward); the rows then pass through this wave's LDS tile to become MFMA operands -- lane (l31, lh) reads
+    // quad lh of row l31 (k = 0..7) and quad 2 (k = 8..11; the lh = 1 half multiplies a zero quad) -- against the weights held
+    // in REGISTERS (8 per 32-column block).  Before: 768 VALU FMAs per row fed by 192 broadcast ds_read_b128 of weights per
+    // slab, which bound the kernel on the LDS return path (1 M x 64: 105 us for 318 MB of stores); now 32 MFMAs and four
+    // operand reads per slab.
+    constexpr int LT = CO + 4;                                     // output tile pitch: 4 mod 8 floats (conflict-free b128 rows)
+    constexpr int LX = 20;                                         // operand tile pitch: 12 used + zero quad at 12..15; 20 = 4 mod 16
+    constexpr int NBK = CO / 32;
     __shared__ __attribute__((aligned(16))) float tile[4][64 * LT];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
     const int cin = 3 + D;
-    for (int i = t; i < CO * 12; i += 256) {
-        const int c = i / 12, k = i - c * 12;
-        Wl[i] = k < cin ? W[(size_t)c * ldw + k] : 0.f;
+    float *T = tile[wave], *XT = tile[wave];                       // the operand rows alias the head of the output tile: they are
+                                                                   // read into registers before the first output row is written
+                                                                   // (two tiles of their own left one workgroup per CU)
+    // this lane's weight slice: wreg[j][4 kb + e] = W[32 j + l31][8 kb + 4 lh + e] (zero beyond the 3 + D real columns)
+    float wreg[NBK][8], bj[NBK];
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * kb + 4 * lh + e;
+                wreg[j][4 * kb + e] = k < cin ? W[(size_t)(32 * j + l31) * ldw + k] : 0.f;
+            }
+        bj[j] = bias[32 * j + l31];
     }
-    for (int i = t; i < CO; i += 256) bl[i] = bias[i];
-    float *T = tile[wave];
-    double st0 = 0.0, st1 = 0.0;                                   // lane = channel (CO = 32: two row halves per channel)
-    __syncthreads();
+    double st[NBK][2];
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) st[j][0] = st[j][1] = 0.0;
     const int xo = xyz_first ? 0 : D, fo = xyz_first ? 3 : 0;
-    // Every wave works on slabs of its own (its own LDS tile: no workgroup barrier in the loop -- LDS operations of one wave
+    // Every wave works on slabs of its own (its own LDS tiles: no workgroup barrier in the loop -- LDS operations of one wave
     // execute in order), and the NEXT slab's index / centre / point reads are in flight while this one is computed and stored.
     const int64_t stride = (int64_t)gridDim.x * 4;
-    float gx, gy, gz, f[9];
-    auto fetch = [&](int64_t slab) {
-        const int64_t r = (slab < slabs ? slab : slabs - 1) * 64 + lane;      // grouped row (past the end: a valid dummy)
-        const int64_t g = r / K, bb = g / S;
-        const int64_t j = idx ? idx[r] : r - g * K;
-        const float *px = xyz + (bb * N + j) * 3;
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-        if (new_xyz) { const float *q = new_xyz + g * 3; cx = q[0]; cy = q[1]; cz = q[2]; }
-        gx = px[0] - cx; gy = px[1] - cy; gz = px[2] - cz;
+    // Two-stage prefetch.  The gather is a dependent chain (neighbour index -> point address), and gfx9 retires loads and
+    // stores through ONE in-order counter: with index and points requested in the same stage, the wait for the index sat
+    // behind the previous slab's 19 stores and every slab paid their HBM acknowledgement (the kernel ran at 3 TB/s of stores
+    // whatever its arithmetic cost: the MFMA version above was no faster than the VALU one).  Now the index of slab s + 2 and
+    // the points of slab s + 1 are requested while slab s is computed, each wait is a counted vmcnt that leaves the stores
+    // issued after the request in flight.
+    float gx, gy, gz, cxr, cyr, czr, f[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) f[k] = 0.f;
-        if (D > 0) {
-            const float *pf = points + (bb * N + j) * D;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) f[k] = k < D ? pf[k] : 0.f;
-        }
+    for (int k = 0; k < 9; ++k) f[k] = 0.f;
+    int64_t jn;                                                    // neighbour index of the slab after next
+    // (branch-free on purpose: a uniform branch around a request makes the compiler's vmcnt bookkeeping fall back to
+    // vmcnt(0); the host guarantees idx, new_xyz and D >= 1)
+    const int dlast = D - 1;
+    // (32-bit row arithmetic: P < 2^31 is checked on the host; an int64 division compiles to a branch between a 32-bit and a
+    // 64-bit path, which again costs the counted waits)
+    // The requests are inline assembly and the waits are counted BY HAND: hipcc's own bookkeeping settles on vmcnt(0..2) in
+    // this loop however it is written (measured: branch-free body, pinned request order, equalised loop entries), i.e. every
+    // slab waits for the HBM acknowledgement of the previous slab's stores.  Issue order of one slab:
+    //     [wait A] use points(s) ... [wait B] 15 point requests(s+1), 1 index request(s+2), 3 X stores, CO/4 Y stores
+    // so behind the points of slab s there are 1 + 3 + CO/4 younger operations (wait A) and behind the index of slab s+1 there
+    // are 3 + CO/4 (wait B).  The waits take the loaded registers as operands: nothing that reads them can move above.
+    // (12-byte requests for the coordinates / centre / feature triples instead of one request per float were tried: the same
+    // 91 us at 1 M rows -- the L1 tag lookups do not bound the gather either)
+    auto ldg = [](const float *p) { float v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v; };
+    auto fetch_idx = [&](int64_t slab) {
+        const unsigned r = (unsigned)(slab < slabs ? slab : slabs - 1) * 64u + (unsigned)lane;   // grouped row (past the end: a valid dummy)
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(jn) : "v"(idx + r) : "memory");
     };
+    auto fetch_pts = [&](int64_t slab, int64_t j) {
+        const unsigned r = (unsigned)(slab < slabs ? slab : slabs - 1) * 64u + (unsigned)lane;
+        const unsigned g32 = r / (unsigned)K, b32 = g32 / (unsigned)S;
+        const int64_t g = g32, bb = b32;
+        const float *px = xyz + (bb * N + j) * 3;
+        const float *q = new_xyz + g * 3;
+        cxr = ldg(q); cyr = ldg(q + 1); czr = ldg(q + 2);            // (subtracted when the row is put together)
+        gx = ldg(px); gy = ldg(px + 1); gz = ldg(px + 2);
+        const float *pf = points + (bb * N + j) * D;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = ldg(pf + (k < dlast ? k : dlast));     // always a valid address; columns beyond D are
+                                                                                   // dropped where x[] is put together
+    };
+    constexpr int kStores = 3 + CO / 4;
+    auto wait_points = [&]() {                                      // wait A
+        if (CO == 64) asm volatile("s_waitcnt vmcnt(20)" : "+v"(gx), "+v"(gy), "+v"(gz), "+v"(cxr), "+v"(cyr), "+v"(czr), "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" : "+v"(gx), "+v"(gy), "+v"(gz), "+v"(cxr), "+v"(cyr), "+v"(czr), "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]) :: "memory");
+    };
+    auto wait_index = [&]() {                                       // wait B
+        if (CO == 64) asm volatile("s_waitcnt vmcnt(19)" : "+v"(jn) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(11)" : "+v"(jn) :: "memory");
+    };
+    static_assert(kStores == 19 || kStores == 11, "the hand-counted waits above");
     int64_t slab = (int64_t)blockIdx.x * 4 + wave;
-    fetch(slab);
+    fetch_idx(slab);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(jn) :: "memory");
+    fetch_pts(slab, jn);
+    fetch_idx(slab + stride);
+    {
+        // As many stores as a slab issues, to this thread's dump slot: the first trip through the loop then meets the same
+        // number of younger operations behind its requests as every later one, and the counted waits hold from the start.
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < kStores; ++i)
+            __builtin_nontemporal_store(z4, reinterpret_cast<v4f *>(pn2_gc_dump + 4 * (blockIdx.x % 1024 * 256 + t)));
+        asm volatile("" ::: "memory");
+    }
     for (; slab < slabs; slab += stride) {
+        wait_points();
         float x[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
             float v = 0.f;
-            v = k == xo ? gx : v; v = k == xo + 1 ? gy : v; v = k == xo + 2 ? gz : v;
+            v = k == xo ? gx - cxr : v; v = k == xo + 1 ? gy - cyr : v; v = k == xo + 2 ? gz - czr : v;
 #pragma unroll
             for (int e = 0; e < 9; ++e) v = (k == fo + e && e < D) ? f[e] : v;
             x[k] = v;
         }
-        fetch(slab + stride);
+        wait_index();
+        fetch_pts(slab + stride, jn);                              // its index was requested one slab ago
+        fetch_idx(slab + 2 * stride);
+        asm volatile("" ::: "memory");                             // the requests stay IN FRONT of this slab's stores (the scheduler
+                                                                   // otherwise sinks them behind the stores: vmcnt(0) again)
         typedef float v4f __attribute__((ext_vector_type(4)));
         {
             float *xr = X + (slab * 64 + lane) * ldx;
+            *reinterpret_cast<float4 *>(&XT[lane * LX + 12]) = make_float4(0.f, 0.f, 0.f, 0.f);     // the zero quad (k = 12..15)
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                if (4 * q < ldx) {
+                *reinterpret_cast<float4 *>(&XT[lane * LX + 4 * q]) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+                {   // a quad beyond the row pitch goes to this thread's dump slot (no branch: see fetch_pts)
                     const v4f v = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-                    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(xr + 4 * q));
+                    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(4 * q < ldx ? xr + 4 * q : pn2_gc_dump + 4 * (blockIdx.x % 1024 * 256 + t)));
                 }
             }
         }
-        // y[c] = (fma chain over k, from 0) + bias[c]: the rounding order of the MFMA path it replaces
-#pragma unroll 2
-        for (int c4 = 0; c4 < CO / 4; ++c4) {
-            float acc[4];
-            const float4 b4 = *reinterpret_cast<const float4 *>(&bl[4 * c4]);
-            const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+        __builtin_amdgcn_wave_barrier();
+        // y = x W^T on v_mfma_f32_32x32x2_f32: two 32-row blocks x NBK 32-column blocks, k = 0..15 (12..15 zero)
+        float4 a0s[2], a1s[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4 w0 = *reinterpret_cast<const float4 *>(&Wl[(4 * c4 + e) * 12]);
-                const float4 w1 = *reinterpret_cast<const float4 *>(&Wl[(4 * c4 + e) * 12 + 4]);
-                const float4 w2 = *reinterpret_cast<const float4 *>(&Wl[(4 * c4 + e) * 12 + 8]);
-                float a = 0.f;
-                a = __builtin_fmaf(x[0], w0.x, a); a = __builtin_fmaf(x[1], w0.y, a); a = __builtin_fmaf(x[2], w0.z, a);
-                a = __builtin_fmaf(x[3], w0.w, a); a = __builtin_fmaf(x[4], w1.x, a); a = __builtin_fmaf(x[5], w1.y, a);
-                a = __builtin_fmaf(x[6], w1.z, a); a = __builtin_fmaf(x[7], w1.w, a); a = __builtin_fmaf(x[8], w2.x, a);
-                a = __builtin_fmaf(x[9], w2.y, a); a = __builtin_fmaf(x[10], w2.z, a); a = __builtin_fmaf(x[11], w2.w, a);
-                acc[e] = a + bq[e];
-            }
-            *reinterpret_cast<float4 *>(&T[lane * LT + 4 * c4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        for (int rb = 0; rb < 2; ++rb) {
+            a0s[rb] = *reinterpret_cast<const float4 *>(&XT[(rb * 32 + l31) * LX + 4 * lh]);          // k = 4 lh + e
+            a1s[rb] = *reinterpret_cast<const float4 *>(&XT[(rb * 32 + l31) * LX + 8 + 4 * lh]);      // k = 8 + 4 lh + e
         }
-        __builtin_amdgcn_wave_barrier();                           // the tile is this wave's own: program order is enough
+        __builtin_amdgcn_wave_barrier();                           // every operand is in registers: the tile may be overwritten
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const float4 a0 = a0s[rb], a1 = a1s[rb];
+#pragma unroll
+            for (int j = 0; j < NBK; ++j) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wreg[j][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wreg[j][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wreg[j][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wreg[j][3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wreg[j][4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wreg[j][5], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wreg[j][6], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wreg[j][7], acc, 0, 0, 0);
+                // bias, statistics straight from the accumulators (column on the lane), rows into the output tile
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y = acc[r] + bj[j];
+                    T[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LT + 32 * j + l31] = y;
+                    s0 += y;
+                    s1 = __builtin_fmaf(y, y, s1);
+                }
+                st[j][0] += (double)s0;
+                st[j][1] += (double)s1;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                           // the tiles are this wave's own: program order is enough
         {
             float *yb = Y + slab * 64 * (int64_t)ldy;
             constexpr int QPR = CO / 4;                            // 16-byte pieces per row
@@ -284,25 +379,18 @@ __global__ __launch_bounds__(256) void group_conv_fwd_kernel(const float *__rest
                 const v4f vv = {v.x, v.y, v.z, v.w};
                 __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(yb + (int64_t)row * ldy + 4 * quad));
             }
-            if (stats != nullptr) {
-                const int c = lane & (CO - 1), r0 = CO == 64 ? 0 : 32 * (lane >> 5), nr = CO == 64 ? 64 : 32;
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-                for (int rr = 0; rr < nr; ++rr) {
-                    const float y = T[(r0 + rr) * LT + c];
-                    s0 += y;
-                    s1 = __builtin_fmaf(y, y, s1);
-                }
-                st0 += (double)s0;
-                st1 += (double)s1;
-            }
         }
-        __builtin_amdgcn_wave_barrier();                           // ... before the next slab overwrites it
+        __builtin_amdgcn_wave_barrier();                           // ... before the next slab overwrites them
     }
     if (stats != nullptr) {
-        if (CO == 32) { st0 += __shfl_xor(st0, 32, 64); st1 += __shfl_xor(st1, 32, 64); }
-        __shared__ double red[4][64][2];
-        red[wave][lane][0] = st0; red[wave][lane][1] = st1;
+        __shared__ double red[4][CO][2];
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+            double a0 = st[j][0], a1 = st[j][1];
+            a0 += __shfl_xor(a0, 32, 64);
+            a1 += __shfl_xor(a1, 32, 64);
+            if (lh == 0) { red[wave][32 * j + l31][0] = a0; red[wave][32 * j + l31][1] = a1; }
+        }
         __syncthreads();
         if (t < CO) {
             double a0 = 0.0, a1 = 0.0;
@@ -314,6 +402,7 @@ __global__ __launch_bounds__(256) void group_conv_fwd_kernel(const float *__rest
     }
 }
 
+
 }  // namespace
 
 extern "C" {
@@ -324,7 +413,8 @@ int pn2_group_conv_fwd(const float *xyz, const float *points, const float *new_x
     PN2_CHECK_ARG(xyz && W && bias && X && Y && B > 0 && N > 0 && S > 0 && K > 0 && D >= 0 && (D == 0 || points) && (idx || K == N));
     PN2_CHECK_ARG(ldw >= 3 + D && ldx % 4 == 0 && ldx >= ((3 + D + 3) & ~3) && ldy % 4 == 0 && ldy >= C_out);
     const int64_t P = (int64_t)B * S * K;
-    if (3 + D > 12 || D > 9 || ldx > 12 || !(C_out == 32 || C_out == 64) || P % 64 != 0 || P >= (1LL << 31)) return PN2_EUNSUPPORTED;
+    if (3 + D > 12 || D > 9 || D < 1 || !idx || !new_xyz || ldx > 12 || !(C_out == 32 || C_out == 64) || P % 64 != 0 || P >= (1LL << 31))
+        return PN2_EUNSUPPORTED;                                   // (the kernel is branch-free: it needs an index, centres and features)
     const int64_t slabs = P / 64;
     int64_t grid = pn2_cdiv(slabs, 4);
     const int64_t cap = (int64_t)pn2_num_cus() * 2;                // persistent: two workgroups per CU (LDS: 4 tiles + W each)

@@ -1,5 +1,5 @@
 # Collect the judged evidence of a state of the tree on the GPU box:  bash tools/collect_profiles.sh <tag>
-# Writes gpurun_out/<tag>/*; copy what should be kept into profiles/ (r01_<tag>_*).
+# Writes gpurun_out/<tag>/*; copy what should be kept into profiles/ (rNN_<tag>_*).
 set -u
 TAG=${1:-vx}
 export TMPDIR=/tmp
@@ -9,8 +9,8 @@ mkdir -p $O
 python3 bench.py > $O/bench_msg.json 2> $O/bench_msg.err
 python3 bench.py --workload ssg > $O/bench_ssg.json 2> $O/bench_ssg.err
 python3 bench.py --workload sa > $O/bench_sa.json 2> $O/bench_sa.err
-python3 bench.py --workload msg --points 65536 --batch 8 --npoint-scale 16 --no-cpu-baseline --steps 5 --warmup 2 > $O/cfg5_msg.json 2> $O/cfg5_msg.err
-python3 bench.py --workload ssg --points 65536 --batch 8 --no-cpu-baseline --steps 10 --warmup 3 > $O/cfg5_ssg.json 2> $O/cfg5_ssg.err
+python3 bench.py --workload msg --points 65536 --batch 8 --npoint-scale 16 --steps 5 --warmup 2 > $O/cfg5_msg.json 2> $O/cfg5_msg.err
+python3 bench.py --workload ssg --points 65536 --batch 8 --steps 10 --warmup 3 > $O/cfg5_ssg.json 2> $O/cfg5_ssg.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_msg -o t -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $O/prof_msg.err
 PN2_MSG_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_msg_serial -o t -- python3 $R/bench.py --no-graph --no-cpu-baseline --no-roofline > /dev/null 2> $O/prof_msg_serial.err
