@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void group_conv_fwd_kernel(const float *__rest
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < kStores; ++i)
-            __builtin_nontemporal_store(z4, reinterpret_cast<v4f *>(pn2_gc_dump + 4 * (blockIdx.x % 1024 * 256 + t)));
+            PN2_STREAM_STORE(z4, reinterpret_cast<v4f *>(pn2_gc_dump + 4 * (blockIdx.x % 1024 * 256 + t)));
         asm volatile("" ::: "memory");
     }
     for (; slab < slabs; slab += stride) {
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void group_conv_fwd_kernel(const float *__rest
                 *reinterpret_cast<float4 *>(&XT[lane * LX + 4 * q]) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
                 {   // a quad beyond the row pitch goes to this thread's dump slot (no branch: see fetch_pts)
                     const v4f v = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-                    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(4 * q < ldx ? xr + 4 * q : pn2_gc_dump + 4 * (blockIdx.x % 1024 * 256 + t)));
+                    PN2_STREAM_STORE(v, reinterpret_cast<v4f *>(4 * q < ldx ? xr + 4 * q : pn2_gc_dump + 4 * (blockIdx.x % 1024 * 256 + t)));
                 }
             }
         }
@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void group_conv_fwd_kernel(const float *__rest
                 const int q = lane + 64 * i, row = q / QPR, quad = q - row * QPR;
                 const float4 v = *reinterpret_cast<const float4 *>(&T[row * LT + 4 * quad]);
                 const v4f vv = {v.x, v.y, v.z, v.w};
-                __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(yb + (int64_t)row * ldy + 4 * quad));
+                *reinterpret_cast<v4f *>(yb + (int64_t)row * ldy + 4 * quad) = vv;   // plain, not streaming: 92 -> 80 us at 1 M rows here
+                                                                                 // (the GEMM epilogues measure the opposite: pn2_common.h)
             }
         }
         __builtin_amdgcn_wave_barrier();                           // ... before the next slab overwrites them

@@ -48,7 +48,7 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
             // operand stream and the weights (+2..6 % on the forward GEMMs, tools/bench_kernels.py)
             typedef float v4f __attribute__((ext_vector_type(4)));
             const v4f yv = {y.x, y.y, y.z, y.w};
-            __builtin_nontemporal_store(yv, reinterpret_cast<v4f *>(Y + row_off(m, ldy) + n));
+            PN2_STREAM_STORE(yv, reinterpret_cast<v4f *>(Y + row_off(m, ldy) + n));
         }
 #else
         *reinterpret_cast<float4 *>(Y + row_off(m, ldy) + n) = y;
@@ -93,7 +93,7 @@ struct EpiDgradMask {       // dZprev = acc * relu'(prev) -> dXout; sum(dZprev),
         {   // streaming store (see EpiFwd); pad lanes: scale = beta = 0 -> 0
             typedef float v4f __attribute__((ext_vector_type(4)));
             const v4f dv = {dz.x, dz.y, dz.z, dz.w};
-            __builtin_nontemporal_store(dv, reinterpret_cast<v4f *>(dX + row_off(m, ldx) + n));
+            PN2_STREAM_STORE(dv, reinterpret_cast<v4f *>(dX + row_off(m, ldx) + n));
         }
         s0.x += dz.x; s0.y += dz.y; s0.z += dz.z; s0.w += dz.w;
         s1.x = __builtin_fmaf(dz.x, (y.x - c[0].x) * c[3].x, s1.x);

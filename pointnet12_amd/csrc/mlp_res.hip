@@ -102,7 +102,7 @@ __device__ float pn2_dump_page[64];
 __device__ float pn2_dump_lines[1024 * 8 * 64];
 
 __device__ __forceinline__ void store_or_dump(float v, float *dst, bool valid, int lane) {
-    __builtin_nontemporal_store(v, valid ? dst : &pn2_dump_page[lane]);
+    PN2_STREAM_STORE(v, valid ? dst : &pn2_dump_page[lane]);
 }
 
 // ----------------------------------------------------------------------------------------------- fused backward
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
                                            : ((blockIdx.x & 1023u) * 8u + (unsigned)wave) * 64u + (unsigned)lane;
             const unsigned xs = dx_rb >= 0 ? (unsigned)ldxo : 0u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(outv[r], sb + (xo + (unsigned)((r & 3) + 8 * (r >> 2)) * xs));
+            for (int r = 0; r < 16; ++r) PN2_STREAM_STORE(outv[r], sb + (xo + (unsigned)((r & 3) + 8 * (r >> 2)) * xs));
         }
         // ---- dW column unit: row quarters [q0, q1) of the tile, 8 row pairs each; per pair ONE wide read of dY[p][CO_T i ..]
         // (the interleaved tiles' A operands) and one of Y_prev[p][ci], then CO_T MFMAs
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
                 const float4 v = *reinterpret_cast<const float4 *>(&Ab[((lane >> 3) + 8 * i) * 36 + (lane & 7) * 4]);
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 const v4f vv = {v.x, v.y, v.z, v.w};
-                __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(yb + (yo + (unsigned)(8 * i) * (unsigned)ldy + 32u * j)));
+                PN2_STREAM_STORE(vv, reinterpret_cast<v4f *>(yb + (yo + (unsigned)(8 * i) * (unsigned)ldy + 32u * j)));
             }
             if (POOL) __builtin_amdgcn_sched_barrier(0);           // one column block at a time: the scans' temporaries do not pile up
         }

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float y = acc[i][r] + e0;
-                        if (n < N4) __builtin_nontemporal_store(y, yb + off);      // pad columns receive exact zeros (w = bias = 0)
+                        if (n < N4) PN2_STREAM_STORE(y, yb + off);      // pad columns receive exact zeros (w = bias = 0)
                         s0 += y;
                         s1 = __builtin_fmaf(y, y, s1);
                         off += ((r & 3) == 3 ? (r == 15 ? 5u : 5u) : 1u) * (unsigned)g.ldout;   // rows (r&3) + 8 (r>>2): +1 +1 +1 +5
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
                     for (int r = 0; r < 16; ++r) {
                         const float y = pv[r];
                         const float dz = bn_act(y, e0, e1, e2) > 0.f ? acc[i][r] : 0.f;   // pad columns: scale = beta = 0 -> 0
-                        if (n < N4) __builtin_nontemporal_store(dz, xb + offx);
+                        if (n < N4) PN2_STREAM_STORE(dz, xb + offx);
                         s0 += dz;
                         s1 = __builtin_fmaf(dz, (y - e0) * e3, s1);
                         offx += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldout;

@@ -6,6 +6,15 @@
 
 #define PN2_WAVE 64
 
+// Stores of activations that only LATER kernels read.  Round 1 measured nontemporal stores 2-6 % faster on the streamed forward
+// GEMMs; round 3 measured the opposite on the store-bound gather + conv kernel (92 -> 80 us at 1 M rows).  One switch for A/B
+// builds of the whole library: make XFLAGS=-DPN2_PLAIN_STORES.
+#ifdef PN2_PLAIN_STORES
+#define PN2_STREAM_STORE(value, ptr) (*(ptr) = (value))
+#else
+#define PN2_STREAM_STORE(value, ptr) __builtin_nontemporal_store((value), (ptr))
+#endif
+
 #define PN2_CHECK_ARG(cond) \
     do {                    \
         if (!(cond)) return PN2_EINVAL; \

@@ -14,7 +14,8 @@ step = rows[a:b]
 n_aten = 0
 for i, r in enumerate(step):
     n = short(r["Kernel_Name"])
-    lib = any(m in n for m in mine) and "elementwise" not in n and "vectorized" not in n and "reduce_kernel" not in n and "Cat" not in n and "softmax" not in n and "dropout" not in n
+    aten = any(m in n for m in ("elementwise_kernel", "vectorized_elementwise", "reduce_kernel<", "CatArray", "softmax_warp", "fused_dropout", "rocclr", "masked_scale"))
+    lib = not aten
     if not lib:
         n_aten += 1
         prev = short(step[i - 1]["Kernel_Name"])[:40] if i else ""
