@@ -185,7 +185,9 @@ int pn2_copy_cols(const float *src, int lds, int scol0, float *dst, int ldd, int
  * columns zero).  W is the Conv weight [N = C_out, K = C_in] as nn.Conv1d/2d stores it, row pitch
  * ldw >= K floats: no padding or alignment is required (16-byte aligned rows with K % 4 == 0 are read as
  * float4, anything else -- a C_in of 9 or 137, or the feature columns sliced out of a [C_out, 3+D]
- * weight -- with guarded scalar loads).  Y pitch ldy (multiple of 4, >= round4(N); pad lanes are
+ * weight -- with guarded scalar loads).  A 16-byte aligned W with ldw % 4 == 0 and ldw >= round4(K) is read as float4
+ * too, the last quad of a row included: its pad entries [K, round4(K)) MUST then be zero (the host side hands over such a
+ * padded copy of the 137-column weight of fp1's first layer: 38.5 -> 30.5 us at 65 536 rows).  Y pitch ldy (multiple of 4, >= round4(N); pad lanes are
  * written as zeros).  in_affine: NULL (X is used as is) or the affine block (4*ldx floats) of
  * the layer that produced X.  stats: NULL or a replicated double[2*N] block (see PN2_STAT_REPLICAS; caller zeroes) receiving
  * sum(y) and sum(y*y) per output channel over the P rows (training-mode BN statistics).  P < 2^31 rows for the three conv1x1 entry points (PN2_EINVAL otherwise). */
@@ -249,7 +251,8 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
 
 /* dgrad: dXact[P,N] = dY[P,K] * W[K,N] with dY formed on the fly from (dZ or the pooled
  * pair dOut/arg, Y, coef); K = C_l, N = C_{l-1}.  W is the SAME Conv weight [C_l, C_{l-1}] the forward
- * read (row pitch ldw >= N, no padding / alignment requirement): the kernel reads it "down the columns",
+ * read (row pitch ldw >= N, no padding / alignment requirement; a 16-byte aligned W with ldw % 4 == 0 and ldw >= round4(N)
+ * is read in whole quads and its pad entries [N, round4(N)) MUST be zero): the kernel reads it "down the columns",
  * no transposed copy exists.  dXout pitch ldxo (multiple of 4, >= round4(N); pad lanes written as zeros).
  *   dZ != NULL: dense dZ [P, ldz];  dZ == NULL: pooled form (dZp [G,ldo] from pn2_pool_bwd_reduce, arg, Kpool).
  * Epilogue, prev_Y != NULL: dZprev = dXact * (bn_relu(prev_Y) > 0) -> dXout, and

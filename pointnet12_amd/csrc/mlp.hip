@@ -164,8 +164,12 @@ __device__ unsigned long long pn2_stamp_buf[8 * 2048];
 // the tile is fetched with guarded scalar loads (weights sliced out of a wider matrix, C_in not a multiple of 4).
 struct BMat { const float *p; int ld; int K; int vec; const float *zp; };
 
+// A row whose length is not a multiple of 4 still takes the float4 path when its PITCH leaves room for the last quad
+// (ld >= round4(len)): the caller then guarantees ZERO pad entries (include/pn2.h) -- the host side makes such a padded copy of
+// the 137- / 323- / 515-column weights once per step (pointnet_util._aligned_weight).
 inline BMat make_bmat(const float *p, int ld, int K, int contiguous_len) {
-    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (contiguous_len & 3) == 0;
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 &&
+                     ((contiguous_len & 3) == 0 || ld >= ((contiguous_len + 3) & ~3));
     return BMat{p, ld, K, vec ? 1 : 0, zero_page_dev()};
 }
 

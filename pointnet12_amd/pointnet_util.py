@@ -125,6 +125,23 @@ def _contig_weight(w):
     return w if w.is_contiguous() else w.contiguous()
 
 
+# Weights whose rows are not 16-byte aligned (C_in = 137 of fp1's first layer, 323, 515 ...) take the GEMM kernels' guarded
+# scalar loaders (fwd 65 536 x 137 -> 128: 60 TF; its dgrad: 37 TF).  From this many rows on, a zero-padded [C_out, round4(C_in)]
+# copy is made once per forward by pn2_copy_cols (one ~5 us launch) and the forward and the data-gradient GEMM read that.
+ALIGN_WEIGHT_MIN_ROWS = int(os.environ.get("PN2_ALIGN_WEIGHT_MIN_ROWS", "32768"))
+
+
+def _aligned_weight(w, ci, co, P):
+    """(tensor to read, row pitch): ``w`` itself, or its zero-padded copy when C_in % 4 != 0 and the layer is long enough."""
+    wc = _contig_weight(w)
+    if ci % 4 == 0 or P < ALIGN_WEIGHT_MIN_ROWS:
+        return wc, ci
+    ld = _r4(ci)
+    wp = _zeros_f32((co, ld), wc.device)
+    _check(_lib.load().pn2_copy_cols(_p(wc), ci, 0, _p(wp), ld, 0, co, ci, _lib.stream()), "pn2_copy_cols")
+    return wp, ld
+
+
 _ident_cache = {}
 
 
@@ -528,6 +545,7 @@ class _SharedMLP(torch.autograd.Function):
         pool_ws = None
         gather = geom is not None and len(geom) > 5 and bool(geom[5])      # (xyz, new_xyz, idx, xyz_first, None, True)
         gathered = None
+        w_pads = {}
         for l in range(L):
             w, b, gamma, beta, rmean, rvar, nbt = flat[7 * l:7 * l + 7]
             co, ci = chans[l + 1], chans[l]
@@ -573,7 +591,10 @@ class _SharedMLP(torch.autograd.Function):
                 else:
                     _check(rc, "pn2_conv1x1_fwd_pool")
             else:
-                _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(_contig_weight(w)), ci, _p(b), _p(y), y.shape[1], P, ci,
+                w_rd, w_ld = _aligned_weight(w, ci, co, P)
+                if w_ld != ci:
+                    w_pads[l] = w_rd                            # the data-gradient GEMM of the backward reads it too
+                _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(w_rd), w_ld, _p(b), _p(y), y.shape[1], P, ci,
                                            co, _p(st_l), fin, st), "pn2_conv1x1_fwd")
             if fin is None:
                 _check(lib.pn2_bn_finalize(_p(st_l), P, co, _p(gamma), _p(beta), eps, mom, int(training),
@@ -606,6 +627,7 @@ class _SharedMLP(torch.autograd.Function):
         if gather:
             rows = gathered                     # what the backward reads as the first layer's input
         ctx.params = flat                       # leaf parameters / buffers (no grad_fn): no cycle either
+        ctx.w_pads = w_pads                     # plain scratch tensors (no grad_fn)
         # save_for_backward (not ctx attributes): `out` is this node's own output, and holding it on ctx would close a
         # reference cycle that only the cyclic GC breaks -- gigabytes of saved activations would pile up for several
         # steps and the caching allocator would stall in hipMalloc/hipFree in the middle of a step.
@@ -730,6 +752,9 @@ class _SharedMLP(torch.autograd.Function):
             dx = None
             if need_dx:
                 w_l = _p(_contig_weight(Ws[l]))             # [co, ci] as stored: the dgrad kernel reads it down the columns
+                w_ld = ci
+                if l in ctx.w_pads:                         # its 16-byte aligned, zero-padded copy made by the forward
+                    w_l, w_ld = _p(ctx.w_pads[l]), ctx.w_pads[l].shape[1]
                 if l > 0:
                     dx = _empty_rows(P, ci, dev)
                 else:
@@ -753,11 +778,11 @@ class _SharedMLP(torch.autograd.Function):
                 if need_dx:
                     c_dx = dx.data_ptr() + 4 * r0 * dx.shape[1]
                     if l > 0:
-                        _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, ci, c_x, ldx, _p(x_aff), c_dx,
+                        _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, w_ld, c_x, ldx, _p(x_aff), c_dx,
                                                      dx.shape[1], _p(red[offs[l - 1]:offs[l]]), rn, co, ci,
                                                      coef_tail(l - 1) if chunk == P else None, st), "pn2_conv1x1_dgrad")
                     else:
-                        _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, ci, None, 0, None, c_dx,
+                        _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, w_ld, None, 0, None, c_dx,
                                                      ldx, None, rn, co, ci, None, st), "pn2_conv1x1_dgrad")
                 if side is not None and chunk == P:
                     # the weight gradient on the companion stream: ordered behind everything issued so far on this stream (the
