@@ -34,4 +34,7 @@ python3 tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 python3 tools/bench_infer.py > $O/infer_single_cloud.jsonl 2> $O/infer.err
 python3 tools/bench_fps.py > $O/fps_probe.txt 2> $O/fps.err
+
+python3 tools/bench_ball.py > $O/ball_query_cfg5.txt 2> $O/ball.err
+python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/tests_gpu.txt
 ls -la $O
