@@ -17,7 +17,7 @@ from pointnet12_amd import _lib
 from pointnet12_amd._lib import ptr as p
 
 FWD = [(1048576, 9, 64), (1048576, 64, 96), (1048576, 96, 128), (524288, 64, 64), (524288, 64, 128), (262144, 323, 128),
-       (262144, 128, 196), (262144, 196, 256), (131072, 323, 128), (131072, 128, 256), (262144, 32, 64), (65536, 128, 128),
+       (262144, 128, 196), (262144, 196, 256), (131072, 323, 128), (131072, 128, 256), (262144, 32, 64), (65536, 128, 128), (131072, 128, 128),
        (65536, 137, 128), (8192, 576, 256), (8192, 256, 128), (8192, 320, 128), (2048, 515, 256), (2048, 256, 512), (2048, 512, 1024), (2048, 1536, 256),
        (2048, 256, 256)]
 # backward shapes: (P, C_l, C_{l-1}, pooled K or 0)
