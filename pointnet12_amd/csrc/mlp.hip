@@ -497,9 +497,267 @@ inline int pn2_env_int(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+// ----------------------------------------------------------------------------- few-row NT GEMM
+// The sa3 / sa4 / fp4 / fp3 / fp2 products (P = 2 k .. 8 k rows, K up to 1536) have too few output tiles for the persistent
+// core above: it puts one workgroup on a CU, and every k-step of that workgroup is load -> transform -> LDS -> barrier -> MFMA
+// with nothing else resident to run under either half (matrix pipe 31 % busy, see dispatch_nt_vec).  This kernel drops the
+// shared staging altogether:
+//  * one workgroup per 32 x 64 output tile; its four waves SPLIT K (contiguous quarters, 32-deep stages) and never meet
+//    until the end -- no barrier, no LDS operand image in the main loop;
+//  * a lane fetches its MFMA operands straight from global memory: 16 bytes (k = 8 kb + 4 (lane >> 5) .. + 3) of row
+//    lane & 31 of the activation tile and of the two 32-row weight tiles.  The four k blocks of a stage touch the same 128-byte
+//    lines back to back (L1 hits); per stage and wave 12 (forward) .. 44 (pooled dgrad) requests against 32 MFMAs;
+//  * two register sets: the requests of stage s + 1 are in flight under the MFMAs of stage s (straight-line code, loads
+//    only: the compiler's vmcnt bookkeeping stays exact);
+//  * addresses are running pointers (32-bit offsets from per-lane bases), no predicates: P % 32, N % 64 and K % 32 must be 0
+//    (every few-row layer of the four networks except the 515- and 137-column ones, which stay on the core above);
+//  * the four partial tiles are summed in LDS in a fixed order (deterministic) and leave through the same epilogue
+//    functors as the core (bias / ReLU mask, per-channel reductions, fused BatchNorm tails).
+template <class T, class U> struct fr_same { static constexpr bool v = false; };
+template <class T> struct fr_same<T, T> { static constexpr bool v = true; };
+
+// KS: waves sharing one 32 x 64 tile (they split K); a workgroup owns 4 / KS consecutive tiles of the (row tile, column tile) grid,
+// column tiles fastest -- its waves then read the same activation rows.  The host picks KS so that about four waves per CU
+// have 4+ stages each.
+template <int KS, bool BNN, class ALoad, class Epi>
+__global__ __launch_bounds__(NTHREADS, 2) void fewrow_nt_kernel(ALoad aload, BMat bm, int K4, int N, Epi epi) {
+    constexpr bool kPlain = fr_same<ALoad, LoadPlain>::v, kBn = fr_same<ALoad, LoadBnRelu>::v;
+    constexpr bool kDense = fr_same<ALoad, LoadDyDense>::v, kPooled = fr_same<ALoad, LoadDyPooled>::v;
+    static_assert(kPlain || kBn || kDense || kPooled, "unknown operand loader");
+    static_assert(KS == 1 || KS == 2 || KS == 4, "waves per tile");
+    constexpr int kTabRows = kPlain ? 0 : kBn ? 3 : 4;
+    constexpr int NT = 4 / KS;
+    constexpr int BM = 32, BN = 64, LDC = BN + 8, CG = BN / 4, RPP = NTHREADS / CG, EP_IT = BM / RPP;
+    __shared__ __attribute__((aligned(16))) float part[4 * BM * LDC];          // 36 KB: one (partial) tile per wave
+    extern __shared__ __attribute__((aligned(16))) float fr_tab[];              // kTabRows x K4 per-channel constants
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tiles_n = N >> 6;
+    const int tile = blockIdx.x * NT + wave / KS, ks = wave % KS;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    if constexpr (kTabRows > 0) {
+        const float *src;
+        int pitch;
+        if constexpr (kBn) { src = aload.aff; pitch = aload.ldx; } else { src = aload.coef; pitch = aload.ldc; }
+        for (int i = t * 4; i < kTabRows * K4; i += NTHREADS * 4) {
+            const int r = i / K4, c = i - r * K4;
+            *reinterpret_cast<float4 *>(fr_tab + i) = ld4(src + r * pitch + c);
+        }
+        __syncthreads();
+    }
+    const int nst = K4 >> 5;
+    const int s_lo = (nst * ks) / KS, s_hi = (nst * (ks + 1)) / KS;
+
+    // per-lane bases: everything after this is base + 32-bit stage offset
+    const float *a0p, *a1p = nullptr;
+    const int32_t *a2p = nullptr;
+    int kk = 0;
+    if constexpr (kPlain || kBn) a0p = aload.X + row_off(m0 + l31, aload.ldx) + 4 * lh;
+    if constexpr (kDense) {
+        a0p = aload.Y + row_off(m0 + l31, aload.ldy) + 4 * lh;
+        a1p = aload.dZ + row_off(m0 + l31, aload.ldz) + 4 * lh;
+    }
+    if constexpr (kPooled) {
+        const unsigned mi = (unsigned)(m0 + l31);
+        const unsigned g = aload.kshift >= 0 ? mi >> aload.kshift : mi / (unsigned)aload.Kp;
+        kk = (int)(mi - g * (unsigned)aload.Kp);
+        a0p = aload.Y + row_off(mi, aload.ldy) + 4 * lh;
+        a1p = aload.dZp + row_off(g, aload.ldo) + 4 * lh;
+        a2p = aload.arg + row_off(g, aload.ldo) + 4 * lh;
+    }
+    const float *bp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        bp[j] = BNN ? bm.p + row_off(4 * lh, bm.ld) + n0 + 32 * j + l31 : bm.p + row_off(n0 + 32 * j + l31, bm.ld) + 4 * lh;
+    const int ldb = bm.ld;
+
+    struct Stage { float4 a0[4], a1[4]; int4 a2[4]; float4 b[2][4]; };
+    auto load = [&](Stage &st, int s) {
+        const int k = 32 * s;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            st.a0[kb] = ld4(a0p + k + 8 * kb);
+            if constexpr (kDense || kPooled) st.a1[kb] = ld4(a1p + k + 8 * kb);
+            if constexpr (kPooled) st.a2[kb] = ld4i(a2p + k + 8 * kb);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                if constexpr (!BNN) {
+                    st.b[j][kb] = ld4(bp[j] + k + 8 * kb);
+                } else {
+                    const float *q = bp[j] + (unsigned)(k + 8 * kb) * (unsigned)ldb;
+                    st.b[j][kb] = make_float4(q[0], q[ldb], q[2 * ldb], q[3 * ldb]);
+                }
+            }
+    };
+    // two accumulator chains per 32 x 32 tile (k lanes x, z / y, w): with one or two waves on a SIMD a single chain per tile
+    // leaves the matrix pipe waiting on the previous MFMA's result every other issue
+    // (forward only: the dgrad loaders' two or three tensors in flight leave no room for the second set, and measured slower with it)
+    constexpr int CH = BNN ? 1 : 2;
+    f32x16 acc[2][CH];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][c][r] = 0.f;
+    auto compute = [&](const Stage &st, int s) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int k = 32 * s + 8 * kb + 4 * lh;
+            float4 a;
+            if constexpr (kPlain) a = st.a0[kb];
+            if constexpr (kBn) {
+                const float4 mu = *reinterpret_cast<const float4 *>(fr_tab + k), sc = *reinterpret_cast<const float4 *>(fr_tab + K4 + k),
+                             be = *reinterpret_cast<const float4 *>(fr_tab + 2 * K4 + k), x = st.a0[kb];
+                a.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
+                a.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+                a.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
+                a.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+            }
+            if constexpr (kDense) a = dy_from(st.a1[kb], st.a0[kb], dy_params_tab(fr_tab, K4, k, true));
+            if constexpr (kPooled) {
+                const float4 go = st.a1[kb];
+                const int4 ar = st.a2[kb];
+                float4 dz;
+                dz.x = ar.x == kk ? go.x : 0.f;
+                dz.y = ar.y == kk ? go.y : 0.f;
+                dz.z = ar.z == kk ? go.z : 0.f;
+                dz.w = ar.w == kk ? go.w : 0.f;
+                a = dy_from(dz, st.a0[kb], dy_params_tab(fr_tab, K4, k, true));
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, st.b[0][kb].x, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, st.b[1][kb].x, acc[1][0], 0, 0, 0);
+            acc[0][CH - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, st.b[0][kb].y, acc[0][CH - 1], 0, 0, 0);
+            acc[1][CH - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, st.b[1][kb].y, acc[1][CH - 1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, st.b[0][kb].z, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, st.b[1][kb].z, acc[1][0], 0, 0, 0);
+            acc[0][CH - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, st.b[0][kb].w, acc[0][CH - 1], 0, 0, 0);
+            acc[1][CH - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, st.b[1][kb].w, acc[1][CH - 1], 0, 0, 0);
+        }
+    };
+
+    // The epilogue's own reads (the previous layer's pre-BN rows, for the ReLU mask): with one or two tiles per workgroup they go out
+    // before the main loop (8 .. 16 registers), with four tiles after it (32 registers that the stage sets need until then).
+    const int ecg = t % CG, erow = t / CG;
+    typename Epi::Pre pre[NT][EP_IT];
+    auto issue_pre = [&]() {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+            const int te = blockIdx.x * NT + tl;
+#pragma unroll
+            for (int i = 0; i < EP_IT; ++i)
+                epi.pre_issue(pre[tl][i], (te / tiles_n) * BM + erow + i * RPP, (te % tiles_n) * BN + ecg * 4, true);
+        }
+    };
+    if constexpr (NT <= 2) issue_pre();
+
+    if (s_lo < s_hi) {
+        // The phases are pinned with scheduling barriers: left alone, the machine scheduler sinks every request down to its first
+        // use (load, s_waitcnt vmcnt(0), MFMA -- the whole point of the second register set undone).
+        Stage sa, sb;
+        int s = s_lo;
+        load(sa, s);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; s + 2 <= s_hi; s += 2) {
+            load(sb, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(sa, s);
+            __builtin_amdgcn_sched_barrier(0);
+            load(sa, s + 2 < s_hi ? s + 2 : s_hi - 1);            // always issued (clamped): straight-line request counting
+            __builtin_amdgcn_sched_barrier(0);
+            compute(sb, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (s < s_hi) compute(sa, s);                             // odd stage count: the clamped request above fetched it
+    }
+
+    // ---- epilogue: every tile of the workgroup row-wise by all 256 threads (16-byte coalesced), partials summed in wave order.
+    if constexpr (NT > 2) issue_pre();
+    float *pw = part + wave * BM * LDC;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)               // D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            pw[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + j * 32 + l31] = CH == 2 ? acc[j][0][r] + acc[j][CH - 1][r] : acc[j][0][r];
+    __syncthreads();
+    float4 s0[NT], s1[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        const int te = blockIdx.x * NT + tl;
+        const int me = (te / tiles_n) * BM, en = (te % tiles_n) * BN + ecg * 4;
+        float4 ec[4];
+        epi.prep(en, N, ec);
+        s0[tl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s1[tl] = s0[tl];
+#pragma unroll
+        for (int i = 0; i < EP_IT; ++i) {
+            const int r = erow + i * RPP;
+            float4 v = *reinterpret_cast<const float4 *>(&part[(tl * KS * BM + r) * LDC + ecg * 4]);
+#pragma unroll
+            for (int w = 1; w < KS; ++w) {
+                const float4 u = *reinterpret_cast<const float4 *>(&part[((tl * KS + w) * BM + r) * LDC + ecg * 4]);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            epi.apply(me + r, en, N, v, ec, pre[tl][i], s0[tl], s1[tl]);
+        }
+    }
+    if (Epi::kHasStats && epi.want_stats()) {              // combine the RPP row-threads of each column, flush once per tile
+        double *red = reinterpret_cast<double *>(part);
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+            __syncthreads();
+            red[t * 8 + 0] = (double)s0[tl].x; red[t * 8 + 1] = (double)s0[tl].y; red[t * 8 + 2] = (double)s0[tl].z; red[t * 8 + 3] = (double)s0[tl].w;
+            red[t * 8 + 4] = (double)s1[tl].x; red[t * 8 + 5] = (double)s1[tl].y; red[t * 8 + 6] = (double)s1[tl].z; red[t * 8 + 7] = (double)s1[tl].w;
+            __syncthreads();
+            if (t < BN) {
+                const int cg = t >> 2, e = t & 3;
+                double a0 = 0.0, a1 = 0.0;
+                for (int j = 0; j < RPP; ++j) {
+                    a0 += red[(j * CG + cg) * 8 + e];
+                    a1 += red[(j * CG + cg) * 8 + 4 + e];
+                }
+                epi.flush(((blockIdx.x * NT + tl) % tiles_n) * BN + t, N, a0, a1);
+            }
+        }
+        if (epi.ticket() != nullptr && tail_is_last_block(epi.ticket(), gridDim.x)) epi.tail(N);
+    }
+}
+
+// false: not this shape (the caller goes on to the persistent core)
+template <bool BNN, class ALoad, class Epi>
+bool launch_fewrow(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, int *rc) {
+    // measured against the persistent core (tools/bench_kernels.py, us): forward 2048 x 1536 -> 256 38.7 -> 25.4, 2048 x 512 -> 1024
+    // 33.3 -> 32.5, 8192 x 576 -> 256 37.5 -> 36.3; dgrad 2048 x 1024 -> 512 (pooled) 49.1 -> 39.7, 2048 x 512 -> 256 16.9 -> 14;
+    // the 8192-row dgrads (dword weight requests down the columns, 1024+ tiles) are 1 .. 3 us slower here and stay on the core
+    static const int max_tiles = BNN ? pn2_env_int("PN2_FEWROW_MAX_TILES_DGRAD", 512) : pn2_env_int("PN2_FEWROW_MAX_TILES", 1024);   // 0: off
+    static const int force_ks = pn2_env_int("PN2_FEWROW_KS", 0);
+    // K = bm.K is the contraction length as the caller states it: a multiple of 32 means there are no pad columns at all
+    if (!bm.vec || (P & 31) || (N & 63) || (K4 & 31) || bm.K != K4 || K4 < 128) return false;
+    const int64_t tiles = (P / 32) * (N / 64);
+    if (tiles > max_tiles || (tiles & 3)) return false;
+    constexpr int tab_rows = fr_same<ALoad, LoadPlain>::v ? 0 : fr_same<ALoad, LoadBnRelu>::v ? 3 : 4;
+    const size_t dyn = (size_t)tab_rows * K4 * sizeof(float);
+    if (dyn + 4 * 32 * 72 * sizeof(float) > 64 * 1024) return false;
+    // about four waves per CU with as many stages each as that allows
+    int ks = tiles * 4 <= 4 * pn2_num_cus() ? 4 : tiles * 2 <= 4 * pn2_num_cus() ? 2 : 1;
+    if (force_ks) ks = force_ks;
+    const dim3 grid((unsigned)(tiles * ks / 4));
+    if (ks == 4) hipLaunchKernelGGL((fewrow_nt_kernel<4, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi);
+    else if (ks == 2) hipLaunchKernelGGL((fewrow_nt_kernel<2, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi);
+    else hipLaunchKernelGGL((fewrow_nt_kernel<1, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi);
+    *rc = pn2_launch_status();
+    return true;
+}
+
 template <bool BNN, class ALoad, class Epi>
 int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
     static const int cfg = pn2_env_int("PN2_NT_CFG", 0);     // tuning hook (tools/bench_kernels.py)
+    {
+        int rc = PN2_OK;
+        if (launch_fewrow<BNN>(aload, bm, P, K4, N, epi, s, &rc)) return rc;
+    }
     // Few rows (the sa3 / fp3 / fp2 stages: P = 2 k .. 8 k): 64x128 tiles would leave most CUs without a workgroup
     // -- 64x64 tiles double the workgroup count (fwd 2048 x 1536 -> 256: 64 workgroups -> 128)
     // -- and 32x64 tiles whose four waves split every k-step in two (summed in the LDS image) double it again.

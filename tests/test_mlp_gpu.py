@@ -45,6 +45,10 @@ def torch_mlp(rows, convs, bns, pool, training, dtype):
     # 128->196 / 196->256, dgrad 256->128 and 256->196 on the max-pool's sparse dZ (groups of 64 and of 128), 196->128 and
     # 128->128 dense -- with a ragged tail of whole groups behind the last full tile
     (131072 + 192, 64, [128, 128, 128, 256]), (131072 + 128, 128, [128, 128, 196, 256]), (65536 + 64, 64, [32, 128, 196, 256]),
+    # the few-row family (mlp.hip fewrow_nt_kernel: four waves split K, operands straight from global memory): the sa3 stack
+    # (group_all-like pooling over 128 rows), the fp3 / fp2 stacks, pooling groups shorter than a tile (16 rows), an odd
+    # number of 32-deep stages per wave (K = 576: 18 stages over four waves)
+    (2048, 128, [256, 256, 512, 1024]), (2048, 0, [1536, 256, 256]), (8192, 0, [576, 256, 128]), (4096, 16, [320, 128, 128]),
 ])
 def test_shared_mlp_vs_torch(dev, P, pool, chans):
     gen = torch.Generator().manual_seed(P + len(chans))
