@@ -353,7 +353,13 @@ extern "C" __global__ void pn2_fps_dbg_touch() {}
 #else
 #define FPS_DBG(k, v)
 #endif
-template <int THREADS, int PPT, bool XYZ_LDS>
+// MAP: which rows of the sorted order a wave owns.  0: one contiguous run (a sample's neighbourhood then falls into two or three
+// waves, which walk their 6 .. 9 touched rows one group after the other while the others idle: 3.2 active waves, 8.7 rows in
+// the slowest, tools/fps_dbg.py).  1: row r belongs to wave r % NW.  2: GROUPS of four consecutive rows (256 sorted points: the
+// unit of the interleaved DPP reduction) are dealt round-robin -- a neighbourhood of twenty rows becomes one group in each of
+// five waves.  Measured, us per iteration, MAP 0 / 1 / 2: N = 25 000 1.64 / 1.55 / 1.41, 28 672 1.89 / 1.67 / 1.54 (B = 8 x 25 000:
+// 1.68 / 1.58 / 1.42); at 16 384 and 20 000 points the wave-level kernel still wins (1.04 and 1.20 against 1.22 and 1.23).
+template <int THREADS, int PPT, bool XYZ_LDS, int MAP>
 __global__ __launch_bounds__(THREADS) void fps_rows_kernel(const float *__restrict__ xyz, int N,
                                                              const int64_t *__restrict__ start, int npoint,
                                                              int64_t *__restrict__ out) {
@@ -435,13 +441,18 @@ __global__ __launch_bounds__(THREADS) void fps_rows_kernel(const float *__restri
     // order; ROW i of the wave -- the i-th point of its 64 lanes -- is 64 consecutive sorted positions: a compact cluster with
     // its own bounding box and its own largest running distance, both held by LANE i of the wave.
     float px[PPT], py[PPT], pz[PPT], md[PPT];
-    const int pbase = wave * WCAP + lane;
+    auto pos_of = [&](int i) {                            // sorted position of this thread's i-th point (a bijection onto [0, CAP))
+        constexpr int FULL = PPT & ~3;
+        if (MAP == 0) return wave * WCAP + i * 64 + lane;
+        if (MAP == 1) return (i * NW + wave) * 64 + lane;
+        return i < FULL ? ((((i >> 2) * NW + wave) * 4 + (i & 3)) * 64 + lane) : (FULL * NW * 64 + ((i - FULL) * NW + wave) * 64 + lane);
+    };
     float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};   // lane i: box of row i (empty: never reached)
     unsigned rmax = 0u;                                   // lane i: bits of the largest running distance of row i (0: empty / exhausted)
     int minidx = 0x7FFFFFFF;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int j = perm[pbase + i * 64];
+        const int j = perm[pos_of(i)];
         float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (j >= 0) {
             px[i] = p[3 * j]; py[i] = p[3 * j + 1]; pz[i] = p[3 * j + 2];
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(THREADS) void fps_rows_kernel(const float *__restri
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
                 if ((tied >> i) & 1ull) {                 // wave-uniform
-                    const int j = perm[pbase + i * 64];
+                    const int j = perm[pos_of(i)];
                     const unsigned c = (md[i] >= 0.f && __float_as_uint(md[i]) == bv) ? 0xFFFFFFFFu - (unsigned)j : 0u;
                     const unsigned cm = pn2_wave_max_u32(c);
                     low = cm > low ? cm : low;
@@ -549,16 +560,23 @@ __global__ __launch_bounds__(THREADS) void fps_rows_kernel(const float *__restri
 
 template <int THREADS, int PPT>
 int launch_fps_pruned(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, hipStream_t s) {
-    constexpr bool ROWS = PPT >= 24;                      // two-level pruning where the wave-level kernel spills (see fps_rows_kernel)
+    // two-level pruning (fps_rows_kernel) where the wave-level kernel spills: 24+ points per thread; PN2_FPS_ROWS_MIN_PPT moves the
+    // hand-over, PN2_FPS_ROWMAP picks the row ownership (A/B runs)
+    static const int rows_min = [] { const char *e = getenv("PN2_FPS_ROWS_MIN_PPT"); return e ? atoi(e) : 24; }();
+    static const int rowmap = [] { const char *e = getenv("PN2_FPS_ROWMAP"); return e ? atoi(e) : 2; }();
     const size_t fixed = sizeof(int) * ((size_t)THREADS * PPT + FPS_NC + 32 + 8 + 6 * (THREADS / 64) + 2) + 64;
     const bool in_lds = fixed + (size_t)N * 16 <= 160 * 1024;
     typedef void (*kernel_t)(const float *, int, const int64_t *, int, int64_t *);
-    kernel_t k_lds, k_mem;
-    if constexpr (ROWS) { k_lds = &fps_rows_kernel<THREADS, PPT, true>; k_mem = &fps_rows_kernel<THREADS, PPT, false>; }
-    else { k_lds = &fps_pruned_kernel<THREADS, PPT, true>; k_mem = &fps_pruned_kernel<THREADS, PPT, false>; }
-    static Pn2PerDevice raised_lds, raised_mem;
-    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(k_lds), raised_lds) != PN2_OK ||
-        pn2_raise_dynamic_lds(reinterpret_cast<const void *>(k_mem), raised_mem) != PN2_OK)
+    kernel_t k_lds = &fps_pruned_kernel<THREADS, PPT, true>, k_mem = &fps_pruned_kernel<THREADS, PPT, false>;
+    if constexpr (PPT >= 16) {
+        if (PPT >= rows_min) {
+            if (rowmap == 0) { k_lds = &fps_rows_kernel<THREADS, PPT, true, 0>; k_mem = &fps_rows_kernel<THREADS, PPT, false, 0>; }
+            else if (rowmap == 1) { k_lds = &fps_rows_kernel<THREADS, PPT, true, 1>; k_mem = &fps_rows_kernel<THREADS, PPT, false, 1>; }
+            else { k_lds = &fps_rows_kernel<THREADS, PPT, true, 2>; k_mem = &fps_rows_kernel<THREADS, PPT, false, 2>; }
+        }
+    }
+    if (pn2_raise_dynamic_lds_once(reinterpret_cast<const void *>(k_lds)) != PN2_OK ||
+        pn2_raise_dynamic_lds_once(reinterpret_cast<const void *>(k_mem)) != PN2_OK)
         return PN2_ELAUNCH;
     if (in_lds)
         hipLaunchKernelGGL(k_lds, dim3(B), dim3(THREADS), fixed + (size_t)N * 16, s, xyz, N, start, npoint, out);

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "../../include/pn2.h"
 
 #define PN2_WAVE 64
@@ -62,6 +65,18 @@ static inline int pn2_raise_dynamic_lds(const void *kernel, Pn2PerDevice &done) 
     if (done.get()) return PN2_OK;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PN2_ELAUNCH;
     done.set();
+    return PN2_OK;
+}
+
+// The same for launchers that pick the kernel at run time: remembered per (kernel, device).
+static inline int pn2_raise_dynamic_lds_once(const void *kernel) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    const std::pair<const void *, int> key(kernel, pn2_device_slot());
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(key)) return PN2_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PN2_ELAUNCH;
+    done.insert(key);
     return PN2_OK;
 }
 
