@@ -123,6 +123,7 @@ def make_step(workload, net, pts, labels, bucket):
     from pointnet12_amd.loss import nll_loss      # F.nll_loss (semseg.py:143) on the HIP library
 
     def step():
+        bucket.wait_reduced()                     # comm stream: the previous step's all-reduce (an event-wait node when captured)
         bucket.zero()
         if workload == "sa":
             _, feat = net(pts[:, :3, :], pts[:, 3:, :])
@@ -304,9 +305,9 @@ def timed_protocol(step, all_reduce, fence, steps, warmup, world, dist, torch, d
         if use_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            all_reduce()
+            own = all_reduce()                   # a collective on a comm stream brings its own pair of events
             e1.record()
-            marks.append((e0, e1))
+            marks.append(own if isinstance(own, tuple) else (e0, e1))
         else:
             a = time.perf_counter()
             all_reduce()
@@ -393,6 +394,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-launch table of the instrumented pass on stderr")
+    ap.add_argument("--no-comm-stream", action="store_true", help="issue the gradient all-reduce on the step's own stream")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute each batch's FPS/ball-query/3-NN inside its own step instead of one step ahead")
@@ -449,6 +451,8 @@ def main():
     net = build_net(args.workload, dev, args.npoint_scale)
     parallel.broadcast_module(net)
     bucket = parallel.FlatGradBucket(net, direct=True)
+    if use_dist and not args.no_comm_stream:
+        bucket.use_comm_stream()             # the all-reduce on its own stream, under the next replay's geometry branch
     compute = make_step(args.workload, net, pts, labels, bucket)     # zero grads + forward + loss + backward
     if not args.no_graph:
         from pointnet12_amd.graph import GraphedStep
@@ -467,7 +471,7 @@ def main():
 
     torch.manual_seed(1234)                  # FPS start draws
     # one step = the graph replay, then the only collective of the path (no-op on one GPU), issued right behind it
-    elapsed, rank_info = timed_protocol(graphed, bucket.all_reduce, fence, args.steps, args.warmup, world if use_dist else 1,
+    elapsed, rank_info = timed_protocol(graphed, bucket.all_reduce_timed, fence, args.steps, args.warmup, world if use_dist else 1,
                                         dist, torch, dev)
     ms_per_step = elapsed / args.steps * 1e3
     value = batch * world * n_points * args.steps / elapsed
@@ -587,6 +591,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "clouds_per_gpu": batch, "points_per_cloud": n_points,
                        "channels": 9, "global_batch": batch * world, "parallelism": "dp%d" % world,
+                       "allreduce_stream": "comm" if bucket.comm is not None else "step",
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
                        "geometry": "in-step" if (args.no_graph or args.no_prefetch)
                        else "next batch's FPS/ball-query/3-NN prefetched on a side stream inside the same graph",

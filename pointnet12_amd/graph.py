@@ -122,7 +122,13 @@ class GraphedStep:
         # 13 small copies that sit on the critical tail of the main stream, ~0.1 ms.)
         self.graphs, self.feeds, self.losses = [], [], []
         self.parity = 0
+        # The tapes are OWNED by this object: T0 was recorded eagerly, i.e. its tensors live in the ordinary allocator pool, and
+        # both graphs hold raw pointers to them (A reads them, B's side branch writes the next geometry into them).  Left to a
+        # local variable they were released when the constructor returned and the allocator handed the same memory to whatever
+        # the caller allocated next -- which the following replays then overwrote with coordinates and indices (found in round
+        # 3 by a test that kept small result tensors across replays; bench.py allocates nothing between replays).
         tapes = [cur, None]
+        self._tapes = [cur]
         pool = None
         for which in (0, 1):
             feed = FpsStartFeed(device)
@@ -157,6 +163,7 @@ class GraphedStep:
                 U.set_capture_scope(None)
                 U.set_geometry_tape(None)
                 U.set_fps_start_feed(None)
+            self._tapes.append(write)
             if which == 0:
                 tapes[1] = write
                 pool = graph.pool()

@@ -70,6 +70,7 @@ class Adam(torch.optim.Optimizer):
                 if [id(p) for p in bucket.params] != [id(p) for p in ps]:
                     raise ValueError("bucket and optimizer must hold the same parameters in the same order")
                 flat_g = bucket.flat
+                self._bucket = bucket
             else:
                 flat_g = _GradViews(ps).flat
             flat_m, flat_v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
@@ -99,6 +100,8 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib, st = _lib.load(), _lib.stream()
+        if getattr(self, "_bucket", None) is not None:
+            self._bucket.wait_reduced()               # an all-reduce on the bucket's comm stream must have landed
         if torch.cuda.is_current_stream_capturing() and any(rec["step_dev"] is None for rec in self._flat):
             # a captured launch would bake the host step count and learning rate in as kernel-argument constants:
             # every replay would then repeat the SAME bias correction and lr, silently

@@ -21,6 +21,41 @@ def _skip_collectives(group=None):
     return dist.get_world_size(group) == 1 and os.environ.get("PN2_FORCE_COLLECTIVES") != "1"
 
 
+class _ExternalEvent:
+    """A HIP event whose WAIT can be captured into a hipGraph while its RECORD happens outside of it, on another stream,
+    after the capture: ``hipStreamWaitEvent(stream, event, hipEventWaitExternal)`` under capture becomes an event-wait node
+    that, at every replay, waits for whatever was recorded on the event most recently (tools/exp/ext_event.py checks
+    exactly that on gfx950 / ROCm 7).  ``torch.cuda.Event(external=True)`` is the same thing but refuses to work on ROCm
+    builds ("External events are disallowed in rocm"), so this goes to the HIP runtime torch itself is linked against."""
+    _hip = None
+
+    def __init__(self):
+        import ctypes
+        if _ExternalEvent._hip is None:
+            _ExternalEvent._hip = ctypes.CDLL("libamdhip64.so")
+        self._ct = ctypes
+        self._ev = ctypes.c_void_p()
+        self._check(self._hip.hipEventCreateWithFlags(ctypes.byref(self._ev), 0x2), "hipEventCreateWithFlags")   # hipEventDisableTiming
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed with HIP error %d" % (what, rc))
+
+    def record(self, stream):
+        self._check(self._hip.hipEventRecord(self._ev, self._ct.c_void_p(stream.cuda_stream)), "hipEventRecord")
+
+    def wait(self, stream):
+        external = 1 if torch.cuda.is_current_stream_capturing() else 0          # hipEventWaitExternal
+        self._check(self._hip.hipStreamWaitEvent(self._ct.c_void_p(stream.cuda_stream), self._ev, external), "hipStreamWaitEvent")
+
+    def __del__(self):
+        try:
+            if self._ev:
+                self._hip.hipEventDestroy(self._ev)
+        except Exception:
+            pass
+
+
 class FlatGradBucket:
     """All parameter gradients as views into one contiguous fp32 buffer.
 
@@ -46,6 +81,24 @@ class FlatGradBucket:
         if direct:
             from . import pointnet_util
             pointnet_util.set_direct_grad_accumulation(True)
+        self.comm = None          # dedicated stream of the collective (use_comm_stream)
+        self.reduced = None       # event: the last all-reduce has finished
+
+    def use_comm_stream(self):
+        """Issue the all-reduce on a stream of its own.  The step that follows only has to wait where it first touches the
+        bucket (``wait_reduced()`` in front of ``zero()`` / of the optimizer's read): captured into a hipGraph that is an
+        event-wait node on the main branch, so the geometry-prefetch branch of the next replay (FPS, ball query, 3-NN: no
+        gradient, no parameter) runs while the collective is still on the wire."""
+        if self.flat.is_cuda and self.comm is None:
+            self.comm = torch.cuda.Stream(device=self.flat.device)
+            self.reduced = _ExternalEvent()
+            self.reduced.record(self.comm)
+        return self
+
+    def wait_reduced(self):
+        """The calling stream waits for the last all-reduce (no-op without a comm stream)."""
+        if self.reduced is not None:
+            self.reduced.wait(torch.cuda.current_stream(self.flat.device))
 
     @property
     def nbytes(self):
@@ -58,12 +111,40 @@ class FlatGradBucket:
         """Average the bucket over ranks (no-op for world size 1 / uninitialised process group)."""
         if _skip_collectives(group):
             return None
-        if dist.get_backend(group) == "gloo":          # gloo has no AVG
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
-        else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+        self._all_reduce(group)
         return self.flat
+
+    def all_reduce_timed(self, group=None):
+        """``all_reduce`` bracketed by two timing events ON THE STREAM THE COLLECTIVE RUNS ON (the comm stream's are recorded
+        after it has caught up with the step, so they time the collective, not the wait for the backward pass).  Returns
+        (start, end), or None when there is no collective to time / no GPU."""
+        if _skip_collectives(group):
+            return None
+        if not self.flat.is_cuda:
+            self._all_reduce(group)
+            return None
+        marks = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self._all_reduce(group, marks)
+        return marks
+
+    def _all_reduce(self, group, marks=None):
+        def collective():
+            if marks:
+                marks[0].record()
+            if dist.get_backend(group) == "gloo":          # gloo has no AVG
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.div_(dist.get_world_size(group))
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+            if marks:
+                marks[1].record()
+        if self.comm is None:
+            collective()
+            return
+        self.comm.wait_stream(torch.cuda.current_stream(self.flat.device))     # the step's gradients are complete
+        with torch.cuda.stream(self.comm):
+            collective()
+            self.reduced.record(self.comm)
 
 
 def broadcast_module(module, src=0, group=None):

@@ -284,6 +284,43 @@ def test_prefetched_geometry_graph_matches_eager(dev):
     assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
 
 
+def test_graph_replays_leave_the_callers_memory_alone(dev):
+    """Every buffer a captured step writes must be owned by the GraphedStep: tensors the caller allocates AFTER the constructor
+    (here: many small ones, which the allocator serves from whatever the constructor released) keep their contents across
+    replays.  (Round 3: the eagerly recorded geometry tape was released at the end of the constructor while the second graph's
+    prefetch branch still wrote into it.)"""
+    import gc
+    from pointnet12_amd import parallel, synthetic as syn
+    from pointnet12_amd.graph import GraphedStep
+    from pointnet12_amd.loss import nll_loss
+    torch.manual_seed(0)
+    net = M.PointNet2SemSeg(13, 6).to(dev).train()
+    bucket = parallel.FlatGradBucket(net, direct=True)
+    pts, lab = syn.kitti_batch(0, 2, 1024)
+    pts, lab = torch.from_numpy(pts).to(dev), torch.from_numpy(lab).to(dev)
+
+    def step():
+        bucket.zero()
+        lp = net(pts)
+        loss = nll_loss(lp.reshape(-1, 13), lab.reshape(-1))
+        loss.backward()
+        return loss
+    torch.manual_seed(1)
+    try:
+        graphed = GraphedStep(step, dev, warmup=2, geometry_fn=lambda: net.features(pts))
+        gc.collect()
+        # sizes from one element up to the tape's largest tensors, in both allocator pools (small blocks < 1 MiB, large above)
+        sentinels = [torch.full((n,), 7.25, device=dev, dtype=torch.float64)
+                     for n in [1] * 64 + [16] * 64 + [512] * 32 + [4096] * 32 + [65536] * 16 + [262144] * 8]
+        torch.cuda.synchronize()
+        for _ in range(6):
+            graphed()
+        torch.cuda.synchronize()
+        assert all(bool((t == 7.25).all()) for t in sentinels)
+    finally:
+        U.set_direct_grad_accumulation(False)
+
+
 def test_cfg2_full_size_set_abstraction_vs_oracle(dev):
     """BASELINE.json configs[1] at its real size: PointNetSetAbstraction(1024, 0.1, 32, 9, [32,32,64]), B=8 x 4096 KITTI-shaped
     clouds, forward + backward, against the oracle module on the host CPU (about 2 s there)."""

@@ -46,6 +46,64 @@ print("RCCL-ONE-RANK-OK")
 """
 
 
+CHILD_COMM = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from pointnet12_amd import parallel, pointnet2 as M, synthetic as syn
+from pointnet12_amd.graph import GraphedStep
+from pointnet12_amd.loss import nll_loss
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+torch.manual_seed(0)
+net = M.PointNet2SemSeg(13, 6).to(dev).train()
+bucket = parallel.FlatGradBucket(net, direct=True).use_comm_stream()
+assert bucket.comm is not None and bucket.reduced is not None
+pts, lab = syn.kitti_batch(0, 2, 1024)
+pts, lab = torch.from_numpy(pts).to(dev), torch.from_numpy(lab).to(dev)
+
+def step():
+    bucket.wait_reduced()
+    bucket.zero()
+    lp = net(pts)
+    loss = nll_loss(lp.reshape(-1, 13), lab.reshape(-1))
+    loss.backward()
+    return loss
+
+torch.manual_seed(1)
+graphed = GraphedStep(step, dev, warmup=2, geometry_fn=lambda: net.features(pts))
+sums = []
+for it in range(6):
+    graphed()
+    marks = bucket.all_reduce_timed()             # on the comm stream, behind the replay
+    assert marks is not None, "the collective was skipped"
+    # NO synchronisation here: the next replay's zero() must itself wait for this all-reduce (the captured event wait);
+    # a replay that zeroed early would hand the collective a half-cleared bucket and the sum below would shrink
+    if it >= 2:
+        bucket.wait_reduced()
+        sums.append(bucket.flat.double().abs().sum())
+torch.cuda.synchronize()
+vals = [float(v) for v in sums]
+assert all(v > 0 and v == v for v in vals), vals
+# same input, BatchNorm in train mode, FPS starts redrawn per replay: the gradient mass stays within a few percent
+assert max(vals) / min(vals) < 1.5, vals
+assert marks[0].elapsed_time(marks[1]) >= 0.0
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL-COMM-STREAM-OK")
+"""
+
+
+def test_one_rank_rccl_all_reduce_on_comm_stream_under_graph_replay(dev):
+    """FlatGradBucket.use_comm_stream(): the collective on its own stream, the captured step waiting for it through an
+    (external) event in front of bucket.zero() -- replayed back to back with no host synchronisation in between."""
+    env = dict(os.environ, PN2_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", CHILD_COMM % ROOT], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0 and "RCCL-COMM-STREAM-OK" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
 def test_one_rank_rccl_bucket_all_reduce(dev):
     env = dict(os.environ, PN2_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
