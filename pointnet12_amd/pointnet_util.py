@@ -143,6 +143,23 @@ def _aligned_weight(w, ci, co, P):
 
 
 _ident_cache = {}
+_bcast_cache = {}
+
+
+def _broadcast_neighbours(B, N, device):
+    """(idx int64 [B,N,3] = 0, weight float32 [B,N,3] = (1, 0, 0)): FeaturePropagation below a group_all stage (S == 1) as an
+    interpolation; constants, created once per (device, B, N) outside any capture."""
+    key = (device.index, B, N)
+    t = _bcast_cache.get(key)
+    if t is None:
+        idx = torch.zeros(B, N, 3, device=device, dtype=torch.int64)
+        w = torch.zeros(B, N, 3, device=device, dtype=torch.float32)
+        w[:, :, 0] = 1.0
+        if torch.cuda.is_current_stream_capturing():
+            return idx, w                              # private to this capture; not cached
+        torch.cuda.current_stream(device).synchronize()
+        t = _bcast_cache[key] = (idx, w)
+    return t
 
 
 def _ident_coef(co, device):
@@ -180,7 +197,7 @@ class _GatherRows(torch.autograd.Function):
         B, N, C = points.shape
         M = idx.numel() // B
         out = torch.empty(B, M, C, device=points.device, dtype=torch.float32)
-        err = torch.zeros(1, device=points.device, dtype=torch.int32) if checked else None
+        err = _zeros_small(4, points.device).view(torch.int32) if checked else None        # (the zero arena: no fill launch)
         _check(_lib.load().pn2_gather_rows(_p(points), _p(idx), B, N, C, M, _p(out), _p(err), _lib.stream()),
                "pn2_gather_rows")
         # the reference's advanced indexing raises on the host; here that costs one device->host read, which a stream
@@ -1099,8 +1116,27 @@ def grouped_mlp(xyz, points, new_xyz, idx, xyz_first, convs, bns, training, inv=
 # --------------------------------------------------------------------------------------- grouping API
 
 def _channel_last(t, name):
-    """[B,C,N] (any strides) -> contiguous [B,N,C]; free when t is a channel-first view of channel-last storage."""
-    return _gpu_f32(t.permute(0, 2, 1), name)
+    """[B,C,N] (any strides) -> contiguous [B,N,C]; free when t is a channel-first view of channel-last storage.
+
+    A caller tensor that really is channel-first (the network input: xyz and features, consumed by sa1 AND by fp1) is copied
+    once: the copy rides on the tensor object (``_pn2_rows``, with the version counter it was made from) and the second
+    consumer gets the same tensor back -- autograd then accumulates both gradients into it as for any shared value."""
+    v = t.permute(0, 2, 1)
+    capturing = torch.cuda.is_current_stream_capturing()
+    # (a differentiable copy belongs to ONE autograd graph: never kept; a capture that did not announce its scope must bake in
+    # nothing that an eager call made or could later replace)
+    if v.is_contiguous() or t.requires_grad or (capturing and _capture_scope is None):
+        return _gpu_f32(v, name)
+    memo = getattr(t, "_pn2_rows", None)
+    if memo is not None and memo[0] == t._version and memo[1] is (_capture_scope if capturing else None) and \
+            memo[2] == torch.is_grad_enabled():
+        return memo[3]
+    r = _gpu_f32(v, name)
+    try:
+        t._pn2_rows = (t._version, _capture_scope if capturing else None, torch.is_grad_enabled(), r)
+    except Exception:                     # (objects that refuse attributes: plain copy every time)
+        pass
+    return r
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
@@ -1311,13 +1347,12 @@ class PointNetFeaturePropagation(nn.Module):
                     _inverse_index(idx.view(B, N * 3), S)
             return _placeholder(B, self.mlp_convs[-1].out_channels, N, x1.device)
         if S == 1:                                      # pointnet_util.py:292-293: broadcast the single feature row
-            interp = p2.expand(B, N, p2.shape[2])
-            rows = interp if p1 is None else torch.cat([p1, interp], dim=-1)
-            c_in = rows.shape[-1]
-            rows = rows.reshape(B * N, c_in)
-            if _r4(c_in) != c_in:
-                rows = torch.nn.functional.pad(rows, (0, _r4(c_in) - c_in))
-            rows = rows.contiguous()
+            # = interpolation from "neighbours" (0, 0, 0) with weights (1, 0, 0): 1 * p + 0 * p + 0 * p is p exactly, so the
+            # same launch that copies points1 and interpolates for S > 1 writes the concatenated rows here too (was: expand +
+            # cat + pad + contiguous in ATen, and a sum in the backward)
+            idx, w = _broadcast_neighbours(B, N, x1.device)
+            rows = _InterpCat.apply(p1, p2, idx, w, None, None)
+            c_in = p2.shape[2] + (0 if p1 is None else p1.shape[2])
         else:
             idx, _, w = three_nn(x1, x2)
             inv = _inverse_index(idx.view(B, N * 3), S) if want_inv else (None, None)
