@@ -161,7 +161,8 @@ int pn2_group_affine_bwd(const float *dZ, int ldz, const float *Y, int ldy, cons
  * cat([points1, interpolated], -1) of :305 is one kernel. */
 int pn2_three_interp(const float *points2, const int64_t *idx, const float *weight, int B, int N, int S, int D,
                      float *out, int ld, int col0, int zero_tail, const float *points1, pn2_stream_t stream);
-/* backward: grad_points2 [B,S,D] += w_k * grad_out[b,n,col0+c] (caller zeroes). */
+/* backward: grad_points2 [B,S,D] += w_k * grad_out[b,n,col0+c] (caller zeroes).  S == 1 (the repeat branch of :292-293: every
+ * index is 0, idx is not read): a deterministic column sum, STORED into grad_points2. */
 int pn2_three_interp_bwd(const float *grad_out, int ld, int col0, const int64_t *idx, const float *weight, int B,
                          int N, int S, int D, float *grad_points2, pn2_stream_t stream);
 

@@ -146,19 +146,29 @@ _ident_cache = {}
 _bcast_cache = {}
 
 
-def _broadcast_neighbours(B, N, device):
-    """(idx int64 [B,N,3] = 0, weight float32 [B,N,3] = (1, 0, 0)): FeaturePropagation below a group_all stage (S == 1) as an
-    interpolation; constants, created once per (device, B, N) outside any capture."""
+def _broadcast_neighbours(B, N, device, want_inv):
+    """(idx int64 [B,N,3] = 0, weight float32 [B,N,3] = (1, 0, 0), members, owners): FeaturePropagation below a group_all
+    stage (S == 1) as an interpolation.  members / owners: the target-sorted form of idx (pn2_invert_index) for the segmented
+    backward -- with every entry pointing at row 0 the plain scatter would queue 3 N atomics per channel on one address.
+    Constants, created once per (device, B, N) outside any capture."""
     key = (device.index, B, N)
     t = _bcast_cache.get(key)
-    if t is None:
+    if t is None or (want_inv and t[2] is None):
         idx = torch.zeros(B, N, 3, device=device, dtype=torch.int64)
         w = torch.zeros(B, N, 3, device=device, dtype=torch.float32)
         w[:, :, 0] = 1.0
+        members = owners = None
+        if want_inv:
+            members = torch.empty(B, 3 * N, device=device, dtype=torch.int32)
+            owners = torch.empty(B, 3 * N, device=device, dtype=torch.int32)
+            scratch = torch.empty(B, 3, device=device, dtype=torch.int32)
+            _check(_lib.load().pn2_invert_index(_p(idx), B, 3 * N, 1, _p(members), _p(owners), _p(scratch), _lib.stream()),
+                   "pn2_invert_index")
+        t = (idx, w, members, owners)
         if torch.cuda.is_current_stream_capturing():
-            return idx, w                              # private to this capture; not cached
+            return t                                   # private to this capture; not cached
         torch.cuda.current_stream(device).synchronize()
-        t = _bcast_cache[key] = (idx, w)
+        _bcast_cache[key] = t
     return t
 
 
@@ -1350,8 +1360,8 @@ class PointNetFeaturePropagation(nn.Module):
             # = interpolation from "neighbours" (0, 0, 0) with weights (1, 0, 0): 1 * p + 0 * p + 0 * p is p exactly, so the
             # same launch that copies points1 and interpolates for S > 1 writes the concatenated rows here too (was: expand +
             # cat + pad + contiguous in ATen, and a sum in the backward)
-            idx, w = _broadcast_neighbours(B, N, x1.device)
-            rows = _InterpCat.apply(p1, p2, idx, w, None, None)
+            idx, w, _, _ = _broadcast_neighbours(B, N, x1.device, False)
+            rows = _InterpCat.apply(p1, p2, idx, w, None, None)      # (backward: pn2_three_interp_bwd's S == 1 column sum)
             c_in = p2.shape[2] + (0 if p1 is None else p1.shape[2])
         else:
             idx, _, w = three_nn(x1, x2)
