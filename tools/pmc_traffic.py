@@ -17,7 +17,7 @@ def family(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name).replace("void ", "")
     m = re.match(r"([A-Za-z0-9_]+)", name)
     fam = m.group(1) if m else name
-    if fam == "gemm_nt_kernel":
+    if fam in ("gemm_nt_kernel", "fewrow_nt_kernel"):
         fam += "<" + ("fwd" if "EpiFwd" in name else "dgrad") + ">"
     if fam == "bwd_res_kernel":
         fam = "gemm_bwd_fused_kernel"
