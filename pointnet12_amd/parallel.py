@@ -21,6 +21,20 @@ def _skip_collectives(group=None):
     return dist.get_world_size(group) == 1 and os.environ.get("PN2_FORCE_COLLECTIVES") != "1"
 
 
+def _loaded_hip_runtime():
+    """Path of the HIP runtime THIS process already runs on (torch ships its own copy next to its extension modules; opening
+    another copy by bare name would give a second runtime whose events mean nothing to torch's streams)."""
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                path = ln.rsplit(" ", 1)[-1].strip()
+                if "libamdhip64.so" in os.path.basename(path):
+                    return path
+    except OSError:
+        pass
+    return "libamdhip64.so"
+
+
 class _ExternalEvent:
     """A HIP event whose WAIT can be captured into a hipGraph while its RECORD happens outside of it, on another stream,
     after the capture: ``hipStreamWaitEvent(stream, event, hipEventWaitExternal)`` under capture becomes an event-wait node
@@ -32,7 +46,7 @@ class _ExternalEvent:
     def __init__(self):
         import ctypes
         if _ExternalEvent._hip is None:
-            _ExternalEvent._hip = ctypes.CDLL("libamdhip64.so")
+            _ExternalEvent._hip = ctypes.CDLL(_loaded_hip_runtime())
         self._ct = ctypes
         self._ev = ctypes.c_void_p()
         self._check(self._hip.hipEventCreateWithFlags(ctypes.byref(self._ev), 0x2), "hipEventCreateWithFlags")   # hipEventDisableTiming
