@@ -284,6 +284,24 @@ def test_prefetched_geometry_graph_matches_eager(dev):
     assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
 
 
+def test_channel_last_copy_is_shared_and_follows_in_place_writes(dev):
+    """The [B,C,N] -> [B,N,C] copy of a caller tensor is made once per version of that tensor (sa1 and fp1 consume the same
+    network input): the same object comes back while the source is unchanged, a fresh copy after an in-place write, and never a
+    kept one for a tensor that requires grad (its copy belongs to one autograd graph)."""
+    x = torch.randn(2, 5, 64, device=dev)
+    a = U._channel_last(x, "x")
+    b = U._channel_last(x, "x")
+    assert a is b and torch.equal(a, x.permute(0, 2, 1))
+    x.mul_(2.0)
+    c = U._channel_last(x, "x")
+    assert c is not a and torch.equal(c, x.permute(0, 2, 1))
+    rows = torch.randn(2, 64, 5, device=dev)
+    v = rows.permute(0, 2, 1)                                   # channel-first VIEW of channel-last storage: no copy at all
+    assert U._channel_last(v, "v").data_ptr() == rows.data_ptr()
+    g = torch.randn(2, 5, 64, device=dev, requires_grad=True)
+    assert U._channel_last(g, "g") is not U._channel_last(g, "g")
+
+
 def test_graph_replays_leave_the_callers_memory_alone(dev):
     """Every buffer a captured step writes must be owned by the GraphedStep: tensors the caller allocates AFTER the constructor
     (here: many small ones, which the allocator serves from whatever the constructor released) keep their contents across
