@@ -35,10 +35,16 @@ def _worker(rank, world, port, out):
     bucket = parallel.FlatGradBucket(model)
     x = torch.randn(4, 5, 16, generator=torch.Generator().manual_seed(100))
     lo, hi = parallel.shard_range(4, rank, world)
-    for _ in range(2):                 # second pass checks zero() really clears the aliased grads
+    assert bucket.use_comm_stream() is bucket and bucket.comm is None     # host tensors: there is no stream to move to
+    for it in range(2):                # second pass checks zero() really clears the aliased grads
+        bucket.wait_reduced()          # (the call sites of the GPU step; no-ops here)
         bucket.zero()
         model(x[lo:hi]).square().mean().backward()
-        bucket.all_reduce()
+        # the timed form is what bench.py calls: on the CPU it performs the collective and has no events to hand back
+        if it == 0:
+            assert bucket.all_reduce() is bucket.flat
+        else:
+            assert bucket.all_reduce_timed() is None
     out[rank] = bucket.flat.clone()
     dist.destroy_process_group()
 
@@ -72,6 +78,17 @@ def test_bucket_aliases_grads():
     bucket.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in model.parameters())
     assert bucket.all_reduce() is None          # no process group: no-op
+    assert bucket.all_reduce_timed() is None
+    bucket.wait_reduced()                       # nothing to wait for
+
+
+def test_external_event_binds_to_the_loaded_hip_runtime():
+    """parallel._ExternalEvent must talk to the HIP runtime torch itself is running on (torch ships its own copy; a second copy
+    opened by bare name would not know torch's streams)."""
+    path = parallel._loaded_hip_runtime()
+    assert "libamdhip64.so" in os.path.basename(path)
+    if os.path.isabs(path):
+        assert os.path.exists(path)
 
 
 # ------------------------------------------------------------------ SURVEY.md 8(e): the path's own network over gloo ranks
