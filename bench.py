@@ -263,6 +263,47 @@ def cpu_baseline(workload, batch, budget_s=150.0):
                           batch, " and ".join(str(k) for k in sorted(legs)))}
 
 
+def rccl_env(rank):
+    """Pin the collective's transport to the node and make RCCL say what it picked (VERDICT r3 #7a).  Set BEFORE the process
+    group comes up: InfiniBand / RoCE off and the bootstrap socket on loopback (one node: the data path can then only be
+    xGMI / PCIe peer-to-peer or host shared memory -- which of them is read back from RCCL's own log), NCCL_DEBUG=INFO into one
+    file per rank (a file, not stdout: stdout carries the ONE JSON line)."""
+    import tempfile
+    os.environ["NCCL_IB_DISABLE"] = "1"
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    log = os.environ.get("NCCL_DEBUG_FILE")
+    if not log:
+        d = os.environ.get("PN2_RCCL_LOG_DIR") or tempfile.mkdtemp(prefix="pn2_rccl_")
+        os.makedirs(d, exist_ok=True)
+        log = os.path.join(d, "rccl_rank%d.log" % rank)
+        os.environ["NCCL_DEBUG_FILE"] = log
+    return log
+
+
+def parse_rccl_log(path):
+    """{"version", "channels": {transport: count}, "net_plugin", "rings"} from one rank's NCCL_DEBUG=INFO file; never raises."""
+    import re
+    out = {"log": path, "version": None, "channels": {}, "net": None, "rings": 0, "trees": 0}
+    try:
+        text = open(path, errors="replace").read()
+    except OSError as e:
+        out["error"] = str(e)
+        return out
+    m = re.search(r"(RCCL version[^\n]*|NCCL version[^\n]*)", text)
+    if m:
+        out["version"] = m.group(1).strip()[:120]
+    for m in re.finditer(r"Channel \d+/\d+ *: *\d+\[[^\]]*\] *-> *\d+\[[^\]]*\].* via (\S+)", text):
+        t = m.group(1)
+        out["channels"][t] = out["channels"].get(t, 0) + 1
+    m = re.search(r"Using network (\S+)", text)
+    if m:
+        out["net"] = m.group(1)
+    out["rings"] = len(re.findall(r"\bRing \d+ *:", text))
+    out["trees"] = len(re.findall(r"\bTrees? \[", text))
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run as a CHILD process
     (this parent never touches the GPU: no re-exec of a process that has initialised HIP), relay rank 0's JSON line
@@ -428,12 +469,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         # RCCL prints its version banner on stdout when NCCL_DEBUG=VERSION is set in the environment: keep stdout
         # for the ONE JSON line by pointing fd 1 at stderr while the communicator comes up.
+        rccl_log = rccl_env(rank)
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            warm = torch.zeros(1, device=dev)
+            warm = torch.zeros(1 << 20, device=dev)          # 4 MB: the size class of the gradient bucket (same channels / protocol)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
         finally:
@@ -448,11 +490,34 @@ def main():
     pts = torch.from_numpy(pts_np).to(dev)
     labels = torch.from_numpy(lab_np).to(dev)
 
+    rccl = None
+    if use_dist:
+        # every rank must own DIFFERENT clouds (weak scaling): the first cloud index of every rank, gathered and checked
+        mine = torch.tensor([lo], dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        los = [int(t.item()) for t in every]
+        if len(set(los)) != world or sorted(los) != [batch * r for r in range(world)]:
+            raise SystemExit("ranks do not own disjoint cloud shards: first cloud index per rank = %s" % los)
+        rccl = {"ranks": world, "ib_disabled": os.environ.get("NCCL_IB_DISABLE") == "1",
+                "socket_ifname": os.environ.get("NCCL_SOCKET_IFNAME"), "first_cloud_per_rank": los}
+        rccl.update(parse_rccl_log(rccl_log))
+        ch = rccl.get("channels") or {}
+        rccl["transport"] = ("none (one rank: no peer)" if world == 1 else
+                             (" + ".join("%s x%d" % kv for kv in sorted(ch.items())) or None))
+        # "xGMI only" = every channel is GPU peer-to-peer (P2P/IPC, P2P/direct ...): no NET/*, no SHM hop through host memory
+        rccl["peer_to_peer_only"] = bool(ch) and all(k.upper().startswith("P2P") for k in ch) if world > 1 else None
+
     net = build_net(args.workload, dev, args.npoint_scale)
     parallel.broadcast_module(net)
     bucket = parallel.FlatGradBucket(net, direct=True)
+    comm_ok = None
     if use_dist and not args.no_comm_stream:
-        bucket.use_comm_stream()             # the all-reduce on its own stream, under the next replay's geometry branch
+        # the comm-stream path has to EARN its place on this very process group before it is used for the timed steps
+        # (ADVICE r3): one bucket of rank-dependent values through both paths, results compared bit for bit on every rank
+        comm_ok = parallel.verify_comm_stream(bucket)
+        if comm_ok:
+            bucket.use_comm_stream()         # the all-reduce on its own stream, under the next replay's geometry branch
     compute = make_step(args.workload, net, pts, labels, bucket)     # zero grads + forward + loss + backward
     if not args.no_graph:
         from pointnet12_amd.graph import GraphedStep
@@ -592,11 +657,15 @@ def main():
             "config": {"workload": WORKLOADS[args.workload], "clouds_per_gpu": batch, "points_per_cloud": n_points,
                        "channels": 9, "global_batch": batch * world, "parallelism": "dp%d" % world,
                        "allreduce_stream": "comm" if bucket.comm is not None else "step",
+                       "allreduce": "one flat fp32 bucket, RCCL AVG, issued behind the graph replay" +
+                                    (" on a comm stream (verified against the step-stream result on this process group)"
+                                     if bucket.comm is not None else " on the step's stream"),
+                       "comm_stream_verified": comm_ok,
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
                        "geometry": "in-step" if (args.no_graph or args.no_prefetch)
                        else "next batch's FPS/ball-query/3-NN prefetched on a side stream inside the same graph",
                        "grad_bucket_bytes": bucket.nbytes},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "rccl": rccl,
         }
         line.update(rank_info)                       # allreduce_ms, rank_ms_per_step_min / _max
         # whole-step fractions on SURVEY.md section 8(d)'s byte / flop model (I/O + five passes over every pre-BN

@@ -31,6 +31,19 @@ def set_geometry(mode):
     _GEOMETRY = mode
 
 
+# tests/test_parity_stages_gpu.py: a list that receives (arg-max index, max value), each [B,C,S], of every pooled MLP stack
+# (the index torch.max(x, 2) of pointnet_util.py:199 / :256 routes the gradient to); None = off
+POOL_ARGMAX = None
+
+
+def _pool(y):
+    """torch.max(new_points, 2)[0] of pointnet_util.py:199 / :256 on [B,C,K,S]."""
+    m = y.max(dim=2)
+    if POOL_ARGMAX is not None:
+        POOL_ARGMAX.append((m[1].detach(), m[0].detach()))
+    return m[0]
+
+
 def _fps(xyz_r, S, start):
     if _GEOMETRY == "aten":
         return A.fps(xyz_r.detach(), S, start)
@@ -124,7 +137,7 @@ class RefSetAbstraction(nn.Module):
                 rows = torch.cat([gx, _rows(pts_r, gidx)], -1)         # xyz first (:131)
         y = _shared_mlp(rows.view(B, S, K, -1).permute(0, 3, 2, 1), self.mlp_convs, self.mlp_bns,
                         self.training)                                  # [B,C,K,S]  (:194-197)
-        return new_xyz.permute(0, 2, 1), y.max(dim=2)[0]               # :199
+        return new_xyz.permute(0, 2, 1), _pool(y)                      # :199
 
 
 class RefSetAbstractionMsg(nn.Module):
@@ -165,7 +178,7 @@ class RefSetAbstractionMsg(nn.Module):
             else:
                 rows = torch.cat([_rows(pts_r, gidx), gx], -1)         # features first (:247)
             y = _shared_mlp(rows.permute(0, 3, 2, 1), convs, bns, self.training)      # :251-255
-            outs.append(y.max(dim=2)[0])                               # :256
+            outs.append(_pool(y))                                      # :256
         return new_xyz.permute(0, 2, 1), torch.cat(outs, 1)            # :260
 
 

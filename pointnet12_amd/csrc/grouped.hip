@@ -289,17 +289,11 @@ __global__ __launch_bounds__(256) void group_conv_fwd_kernel(const float *__rest
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(jn) :: "memory");
     fetch_pts(slab, jn);
     fetch_idx(slab + stride);
-    {
-        // As many stores as a slab issues, to this thread's dump slot: the first trip through the loop then meets the same
-        // number of younger operations behind its requests as every later one, and the counted waits hold from the start.
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < kStores; ++i)
-            PN2_STREAM_STORE(z4, reinterpret_cast<v4f *>(pn2_gc_dump + 4 * (blockIdx.x % 1024 * 256 + t)));
-        asm volatile("" ::: "memory");
-    }
+    // The first trip through the loop has fewer younger operations behind its requests than every later one (no stores of
+    // a previous slab yet), so the counted waits of the loop would not cover them: everything requested so far is waited for
+    // here, explicitly, with the loaded registers as operands (round 3 issued kStores dummy stores instead -- same-address dead
+    // stores that hipcc removed, leaving the prologue correct only by the accident of a compiler-placed vmcnt(0)).
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gx), "+v"(gy), "+v"(gz), "+v"(cxr), "+v"(cyr), "+v"(czr), "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(jn) :: "memory");
     for (; slab < slabs; slab += stride) {
         wait_points();
         float x[12];

@@ -42,18 +42,12 @@ struct EpiFwd {             // y = acc + bias -> Y; per-channel sum(y), sum(y*y)
             if (n + 2 >= N) y.z = 0.f;
             y.w = 0.f;
         }
-#ifndef PN2_X_NOSTORE
-#ifndef PN2_X_PLAINSTORE
         {   // streaming store: Y is read again only by later kernels; keeping it out of the L2 leaves the cache to the
             // operand stream and the weights (+2..6 % on the forward GEMMs, tools/bench_kernels.py)
             typedef float v4f __attribute__((ext_vector_type(4)));
             const v4f yv = {y.x, y.y, y.z, y.w};
             PN2_STREAM_STORE(yv, reinterpret_cast<v4f *>(Y + row_off(m, ldy) + n));
         }
-#else
-        *reinterpret_cast<float4 *>(Y + row_off(m, ldy) + n) = y;
-#endif
-#endif
         s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
         s1.x = __builtin_fmaf(y.x, y.x, s1.x); s1.y = __builtin_fmaf(y.y, y.y, s1.y);
         s1.z = __builtin_fmaf(y.z, y.z, s1.z); s1.w = __builtin_fmaf(y.w, y.w, s1.w);
@@ -975,11 +969,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-#ifdef PN2_X_NOWATOMIC
-                if (m < M && n < N && acc[i][j][r] == 123456.f) dW[(int64_t)m * lddw + n] = 1.f;
-#else
                 if (m < M && n < N) atomicAdd(dW + (int64_t)m * lddw + n, acc[i][j][r]);
-#endif
             }
         }
 tn_bias:

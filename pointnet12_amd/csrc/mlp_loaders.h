@@ -106,17 +106,7 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
             const int64_t mi = m + (int64_t)i * stride;
-#ifdef PN2_X_NOALOAD
-            r.x[i] = ld4(zp + ((mi ^ k) & 0));          // ablation build: the operand stream is never fetched
-#elif defined(PN2_X_NTLOAD)
-            {
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                const v4f xv = __builtin_nontemporal_load(reinterpret_cast<const v4f *>((kvalid && mi < rows) ? X + row_off(mi, ldx) + k : zp));
-                r.x[i] = make_float4(xv.x, xv.y, xv.z, xv.w);
-            }
-#else
             r.x[i] = ld4((kvalid && mi < rows) ? X + row_off(mi, ldx) + k : zp);
-#endif
         }
     }
     __device__ __forceinline__ Params params(int, bool) const { return Params(); }

@@ -439,14 +439,10 @@ int launch_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const
                    double *red_p, float *dW, int lddw, hipStream_t s) {
     // Single dY buffer, two register sets of prefetched tiles on the light pairs (their tile's MFMA work is shorter than
     // its memory time).  The double-buffered form (DBUF: tile n + 1 transformed inside tile n's barrier interval, waves 0-3
-    // and 4-7 in opposite phases) is kept behind -DPN2_RES_DBUF for A/B builds: MEASURED SLOWER on every pair
+    // and 4-7 in opposite phases) was MEASURED SLOWER on every pair
     // (128x96 pooled 701 vs 676 us, 96x64 408 vs 385, 64x64 156 vs 136 -- profiles/r02_kernel_microbench.txt): the
     // transform did not hide under the partner wave's MFMAs, it only delayed this wave's own.
     constexpr int DEPTH = CO_T * CI_T <= 6 ? 2 : 1;
-#ifdef PN2_RES_DBUF
-    if constexpr (sizeof(float) * ((size_t)32 * CI_T * (32 * CO_T + 4) + 2 * RES_BM * (32 * CO_T + 4) + RES_BM * (32 * CI_T + 4) + 4 * 32 * CO_T) <= 160 * 1024)
-        return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, 1, true>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
-#endif
     return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, DEPTH, false>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
 }
 

@@ -123,7 +123,12 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
     const int N4 = (N + 3) & ~3;
     float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;                   // EPI_FWD: bias; EPI_MASK: mean, scale, beta, invstd of column n
     if (EPI == EPI_FWD) e0 = n < N ? g.bias[n] : 0.f;
-    if (EPI == EPI_MASK && n < N4) {
+    // LATE_E: the 196-deep dense data gradient holds 100 weight registers next to two accumulator tiles and four staging
+    // items; with the four epilogue constants resident as well it spilled six loop-invariant registers (28 bytes of scratch,
+    // reloaded once per tile).  There the constants are fetched per tile instead, beside the prevY requests of the epilogue
+    // (same cache lines for every tile: L1 hits that return under the wait those requests need anyway).
+    constexpr bool LATE_E = EPI == EPI_MASK && KP == 200;
+    if (EPI == EPI_MASK && !LATE_E && n < N4) {
         Affine a(g.prev_aff, N4);
         e0 = a.mean[n]; e1 = a.scale[n]; e2 = a.beta[n]; e3 = a.invstd[n];
     }
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
     const int64_t tiles = g.tiles;
     const int G = gridDim.x;
     // item i of chunk c: idx = t + NT * i over BM rows x QT(c) quads; row = idx / QT, q = idx % QT
+    int tq = t;                                                     // (LATE_E: re-derived per chunk, see the chunk loop)
     auto fetch_item = [&](int64_t tile, int c, int i) {
         const int qt = QT(c), qv = QV(c);
         const unsigned tl = (unsigned)(tile < tiles ? tile : tiles - 1);      // past the end: re-read the last tile (never used)
@@ -144,12 +150,12 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
             // the row of the group's first item (always inside the tile; the last pass of a chunk may be partly filled).
             int i0 = i;
             while (i0 > 0 && zslot(i0 - 1) == zslot(i)) --i0;
-            const int idx0 = t + NT * i0, row0 = idx0 / qt, q0 = idx0 - row0 * qt;
+            const int idx0 = tq + NT * i0, row0 = idx0 / qt, q0 = idx0 - row0 * qt;
             const unsigned grp = (tl * BM + row0) / (unsigned)(PKP > 0 ? PKP : 1);
             raw.z[POOLED ? zslot(i) : 0] = ld4(g.dZp + row_off(grp, g.ldo) + c * KC + 4 * q0);
             raw.a[POOLED ? zslot(i) : 0] = ld4i(g.arg + row_off(grp, g.ldo) + c * KC + 4 * q0);
         }
-        const int idx = t + NT * i, row = idx / qt, q = idx - row * qt;
+        const int idx = tq + NT * i, row = idx / qt, q = idx - row * qt;
         if (NT * i >= BM * qt) return;                                   // static: this chunk has fewer items
         if (NT * (i + 1) > BM * qt && idx >= BM * qt) return;            // the last, partly filled pass
         const unsigned qq = q < qv ? q : qv - 1;                               // a pad quad re-reads the last valid one (zeroed when staged)
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
     };
     auto stage_item = [&](float *dst, int64_t tile, int c, int i) {
         const int qt = QT(c), qv = QV(c);
-        const int idx = t + NT * i, row = idx / qt, q = idx - row * qt;
+        const int idx = tq + NT * i, row = idx / qt, q = idx - row * qt;
         if (NT * i >= BM * qt) return;                                   // static: this chunk has fewer items
         if (NT * (i + 1) > BM * qt && idx >= BM * qt) return;            // the last, partly filled pass
         const int k = c * KC + 4 * q;
@@ -210,6 +216,9 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             __syncthreads();                                        // chunk c is in `cur`; every wave is done with `nxt`
+            // LATE_E (register budget): the lane's staging offsets are re-derived inside every chunk instead of living in
+            // registers across the whole tile loop (one of them was spilled)
+            if (LATE_E) asm volatile("" : "+v"(tq));
             const int kbs = QT(c) / 2;                              // 8-wide k blocks of this chunk (static after unrolling)
             const bool last = c == NCH - 1;
             const int64_t t1 = last ? tile + G : tile;              // the chunk staged during this one ...
@@ -289,24 +298,34 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
                 float *xb = g.Out + row_off(row0, g.ldout);
                 unsigned offp = lo, offx = lo;
                 asm volatile("" : "+v"(offx));
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    float pv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        pv[r] = n < N4 ? pb[offp] : 0.f;
-                        offp += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldp;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float y = pv[r];
-                        const float dz = bn_act(y, e0, e1, e2) > 0.f ? acc[i][r] : 0.f;   // pad columns: scale = beta = 0 -> 0
-                        if (n < N4) PN2_STREAM_STORE(dz, xb + offx);
-                        s0 += dz;
-                        s1 = __builtin_fmaf(dz, (y - e0) * e3, s1);
-                        offx += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldout;
-                    }
+                if (LATE_E) {
+                    Affine a(g.prev_aff, N4);
+                    const unsigned nl = n < N4 ? lo : 0u;                // (opaque per tile: not hoisted back out of the loop)
+                    e0 = a.mean[nl]; e1 = a.scale[nl]; e2 = a.beta[nl]; e3 = a.invstd[nl];
+                    if (!(n < N4)) e1 = e2 = 0.f;
                 }
+                constexpr int PVB = LATE_E ? 8 : 16;                     // prevY values in flight per batch (LATE_E: register budget)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int rb = 0; rb < 16; rb += PVB) {
+                        float pv[PVB];
+#pragma unroll
+                        for (int r = rb; r < rb + PVB; ++r) {
+                            pv[r - rb] = n < N4 ? pb[offp] : 0.f;
+                            offp += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldp;
+                        }
+                        if (LATE_E) asm volatile("" ::: "memory");       // the second batch is requested after the first was used
+#pragma unroll
+                        for (int r = rb; r < rb + PVB; ++r) {
+                            const float y = pv[r - rb];
+                            const float dz = bn_act(y, e0, e1, e2) > 0.f ? acc[i][r] : 0.f;   // pad columns: scale = beta = 0 -> 0
+                            if (n < N4) PN2_STREAM_STORE(dz, xb + offx);
+                            s0 += dz;
+                            s1 = __builtin_fmaf(dz, (y - e0) * e3, s1);
+                            offx += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldout;
+                        }
+                    }
             } else {
                 float *xb = g.Out + row_off(row0, g.ldout);
                 unsigned off = lo;
@@ -408,6 +427,8 @@ int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
         return launch_regw<((KK + 3) & ~3), NCB, RS, TM, KC, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, EPI_MASK, true, PKP, ADB>(g, s); \
     }
     WIDE_DGRAD(128, 128, 4, 2, 2, 64, 0, true, 98304)      // 65 536 rows: ties the streamed kernel (33.9 vs 33.6 us)
+    static const int adb196 = wide_env("PN2_WIDE_ADB196", 1);      // A/B: operand reads one k block ahead (two register sets)
+    if (adb196) { WIDE_DGRAD(196, 128, 4, 2, 2, 64, 0, true, 0) }
     WIDE_DGRAD(196, 128, 4, 2, 2, 64, 0, false, 0)
     WIDE_DGRAD(256, 128, 4, 2, 1, 128, 64, true, 0)
     WIDE_DGRAD(256, 128, 4, 2, 1, 128, 128, true, 0)

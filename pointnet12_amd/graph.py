@@ -179,10 +179,12 @@ class GraphedStep:
             self.feeds[i].stage()
             self.graphs[i].replay()
             U.bump_param_generation()            # whatever the captured step wrote (BN buffers, an optimiser step)
+            U.bump_data_generation()
             return self.losses[i]
         self.feed.stage()
         self.graph.replay()
         U.bump_param_generation()
+        U.bump_data_generation()
         return self.loss
 
 

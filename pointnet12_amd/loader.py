@@ -103,4 +103,7 @@ def prepare_batch(store, scan_ids, npoints, train=True, rng="numpy", sigma=0.01,
         labels = torch.empty(B, npoints, device=dev, dtype=torch.int64) if store.label is not None else None
     _lib.check(lib.pn2_prepare_clouds(_p(store.raw), _p(begin), _p(count), _p(store.label), _p(noise), _p(noise_begin),
                                       _p(choice), B, npoints, _p(points), _p(labels), None, st), "pn2_prepare_clouds")
+    if out is not None:
+        from . import pointnet_util as _U
+        _U.bump_data_generation()             # a static buffer was refilled through a raw pointer: views of it are stale
     return points, labels

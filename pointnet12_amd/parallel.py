@@ -43,13 +43,14 @@ class _ExternalEvent:
     builds ("External events are disallowed in rocm"), so this goes to the HIP runtime torch itself is linked against."""
     _hip = None
 
-    def __init__(self):
+    def __init__(self, device):
         import ctypes
         if _ExternalEvent._hip is None:
             _ExternalEvent._hip = ctypes.CDLL(_loaded_hip_runtime())
         self._ct = ctypes
         self._ev = ctypes.c_void_p()
-        self._check(self._hip.hipEventCreateWithFlags(ctypes.byref(self._ev), 0x2), "hipEventCreateWithFlags")   # hipEventDisableTiming
+        with torch.cuda.device(device):         # an event belongs to the device that is current when it is created
+            self._check(self._hip.hipEventCreateWithFlags(ctypes.byref(self._ev), 0x2), "hipEventCreateWithFlags")   # hipEventDisableTiming
 
     def _check(self, rc, what):
         if rc != 0:
@@ -105,7 +106,7 @@ class FlatGradBucket:
         gradient, no parameter) runs while the collective is still on the wire."""
         if self.flat.is_cuda and self.comm is None:
             self.comm = torch.cuda.Stream(device=self.flat.device)
-            self.reduced = _ExternalEvent()
+            self.reduced = _ExternalEvent(self.flat.device)
             self.reduced.record(self.comm)
         return self
 
@@ -159,6 +160,40 @@ class FlatGradBucket:
         with torch.cuda.stream(self.comm):
             collective()
             self.reduced.record(self.comm)
+
+
+def verify_comm_stream(bucket, group=None):
+    """Does the comm-stream all-reduce of ``bucket`` give the step-stream result on THIS process group?  Fills the bucket with
+    rank-dependent values, reduces it once on the calling stream and once through a temporary comm stream + external event
+    (the exact calls the timed steps make: ``all_reduce`` then ``wait_reduced``), compares bit for bit, and agrees on the verdict
+    across ranks (MIN).  The bucket is zeroed afterwards.  False on any failure -- the caller then stays on the step stream."""
+    if _skip_collectives(group) or not bucket.flat.is_cuda:
+        return None
+    dev = bucket.flat.device
+    rank = dist.get_rank(group)
+    n = bucket.flat.numel()
+    pattern = ((torch.arange(n, device=dev, dtype=torch.float32) % 1021.0) - 510.0) * (1.0 + rank) / 1024.0
+    ok = True
+    saved = (bucket.comm, bucket.reduced)
+    try:
+        bucket.flat.copy_(pattern)
+        bucket.comm, bucket.reduced = None, None
+        bucket._all_reduce(group)
+        want = bucket.flat.clone()
+        bucket.flat.copy_(pattern)
+        bucket.use_comm_stream()
+        bucket._all_reduce(group)
+        bucket.wait_reduced()
+        ok = bool(torch.equal(bucket.flat, want))
+    except Exception:
+        ok = False
+    finally:
+        torch.cuda.synchronize(dev)
+        bucket.comm, bucket.reduced = saved
+        bucket.flat.zero_()
+    verdict = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+    return bool(verdict.item())
 
 
 def broadcast_module(module, src=0, group=None):

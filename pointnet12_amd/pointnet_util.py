@@ -142,6 +142,23 @@ def _aligned_weight(w, ci, co, P):
     return wp, ld
 
 
+def _padded_feature_columns(w, D, ci, xyz_first):
+    """The factorised first layer reads the feature columns straight out of the [C_out, 3+D] weight (pitch 3+D, K = D).  With
+    the features FIRST and D % 4 == 1 that slice is 16-byte aligned with a pitch of round4(D): the GEMMs would take their
+    float4 path, whose contract is ZERO pad entries (include/pn2.h) -- but the "pad" quad here holds the xyz weights (ADVICE
+    round 3: the forward then leans on X's pad columns being exactly 0, the data gradient writes non-zero pad lanes).  For
+    exactly that case a zero-padded [C_out, round4(D)] copy is made (one pn2_copy_cols launch); every other layout either
+    satisfies the contract or takes the guarded scalar loaders."""
+    if xyz_first or D % 4 == 0 or ci % 4 != 0:
+        return None
+    wc = _contig_weight(w)
+    co = wc.shape[0]
+    ld = _r4(D)
+    wp = _zeros_f32((co, ld), wc.device)
+    _check(_lib.load().pn2_copy_cols(_p(wc), ci, 0, _p(wp), ld, 0, co, D, _lib.stream()), "pn2_copy_cols")
+    return wp
+
+
 _ident_cache = {}
 _bcast_cache = {}
 
@@ -595,12 +612,17 @@ class _SharedMLP(torch.autograd.Function):
                 # the kernels read the xyz / feature columns straight out of the [co, 3+D] weight (pitch ci): no copies
                 w_ptr = _contig_weight(w).data_ptr()
                 wx_ptr, wf_ptr = (w_ptr, w_ptr + 12) if g_first else (w_ptr + 4 * gD, w_ptr)
+                wf_ld = ci
+                wf_pad = _padded_feature_columns(w, gD, ci, g_first)
+                if wf_pad is not None:                  # (D % 4 == 1, features first: see _padded_feature_columns)
+                    w_pads["wf"] = wf_pad
+                    wf_ptr, wf_ld = wf_pad.data_ptr(), wf_pad.shape[1]
                 ldd = _r4(gD)
                 feat = rows.reshape(gB * gN, gD)
                 if ldd != gD:
                     feat = torch.nn.functional.pad(feat, (0, ldd - gD))
                 zf = _empty_rows(gB * gN, co, dev)
-                _check(lib.pn2_conv1x1_fwd(_p(feat), ldd, None, wf_ptr, ci, _p(b), _p(zf), zf.shape[1], gB * gN, gD, co,
+                _check(lib.pn2_conv1x1_fwd(_p(feat), ldd, None, wf_ptr, wf_ld, _p(b), _p(zf), zf.shape[1], gB * gN, gD, co,
                                            None, None, st), "pn2_conv1x1_fwd")
                 _check(lib.pn2_group_affine_fwd(_p(zf), zf.shape[1], _p(g_xyz), _p(g_new), _p(g_idx), wx_ptr, ci, gB, gN, gS,
                                                 gK, co, _p(y), y.shape[1], _p(st_l), fin, st), "pn2_group_affine_fwd")
@@ -869,8 +891,11 @@ class _SharedMLP(torch.autograd.Function):
         d_feats = None
         if need_dfeat:
             wf_ptr = _contig_weight(w).data_ptr() + (12 if g_first else 0)      # feature columns of the [co, 3+D] weight
+            wf_ld = 3 + D
+            if "wf" in ctx.w_pads:                   # their zero-padded copy made by the forward (D % 4 == 1, features first)
+                wf_ptr, wf_ld = ctx.w_pads["wf"].data_ptr(), ctx.w_pads["wf"].shape[1]
             dF = _empty_rows(B * N, D, dev)
-            _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), wf_ptr, 3 + D, None, 0, None,
+            _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), wf_ptr, wf_ld, None, 0, None,
                                          _p(dF), ldd, None, B * N, co, D, None, st), "pn2_conv1x1_dgrad")
             d_feats = (dF[:, :D] if ldd != D else dF).reshape(B, N, D)
         return d_feats, (dW.view_as(w) if w_grad is None else None)
@@ -1012,6 +1037,18 @@ def bump_param_generation():
     _PARAM_GEN[0] += 1
 
 
+_DATA_GEN = [0]
+
+
+def bump_data_generation():
+    """Tell the channel-last memo (``_channel_last``) that INPUT tensors may have been rewritten behind autograd's back.
+
+    ``tensor._version`` only counts writes made through torch; ``loader.prepare_batch(out=...)`` (pn2_prepare_clouds into
+    static buffers) and a replayed hipGraph refill tensors through raw pointers.  A channel-first view of such a buffer that a
+    caller holds across steps would otherwise get the PREVIOUS batch's copy back on the next eager forward."""
+    _DATA_GEN[0] += 1
+
+
 def _folded_layers(convs, bns):
     """(ctypes array of pn2_eval_layer, tensors kept alive) with W' = diag(gamma / sqrt(var + eps)) W and
     b' = (b - mean) * gamma / sqrt(var + eps) + beta, computed in fp64, rows padded to round8(C_in).
@@ -1129,8 +1166,9 @@ def _channel_last(t, name):
     """[B,C,N] (any strides) -> contiguous [B,N,C]; free when t is a channel-first view of channel-last storage.
 
     A caller tensor that really is channel-first (the network input: xyz and features, consumed by sa1 AND by fp1) is copied
-    once: the copy rides on the tensor object (``_pn2_rows``, with the version counter it was made from) and the second
-    consumer gets the same tensor back -- autograd then accumulates both gradients into it as for any shared value."""
+    once: the copy rides on the tensor object (``_pn2_rows``, with the version counter AND the data generation it was made
+    from -- raw-pointer writers bump the latter, see ``bump_data_generation``) and the second consumer gets the same tensor
+    back -- autograd then accumulates both gradients into it as for any shared value."""
     v = t.permute(0, 2, 1)
     capturing = torch.cuda.is_current_stream_capturing()
     # (a differentiable copy belongs to ONE autograd graph: never kept; a capture that did not announce its scope must bake in
@@ -1138,12 +1176,13 @@ def _channel_last(t, name):
     if v.is_contiguous() or t.requires_grad or (capturing and _capture_scope is None):
         return _gpu_f32(v, name)
     memo = getattr(t, "_pn2_rows", None)
-    if memo is not None and memo[0] == t._version and memo[1] is (_capture_scope if capturing else None) and \
+    key = (t._version, _DATA_GEN[0], t.data_ptr(), tuple(t.stride()))
+    if memo is not None and memo[0] == key and memo[1] is (_capture_scope if capturing else None) and \
             memo[2] == torch.is_grad_enabled():
         return memo[3]
     r = _gpu_f32(v, name)
     try:
-        t._pn2_rows = (t._version, _capture_scope if capturing else None, torch.is_grad_enabled(), r)
+        t._pn2_rows = (key, _capture_scope if capturing else None, torch.is_grad_enabled(), r)
     except Exception:                     # (objects that refuse attributes: plain copy every time)
         pass
     return r

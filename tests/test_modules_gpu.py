@@ -128,9 +128,59 @@ def test_network_matches_reference(dev, tag, make):
     for k in g.files:
         if k.startswith(tag + "/grad/"):
             n = k[len(tag) + 6:]
-            # measured: the reference against ITSELF (8 threads vs 1 thread) differs by 1-3.4e-2 of max on these
-            # tensors at this size (fp1.mlp_convs.0.weight 3.0e-2), so anything tighter would test noise
-            assert relmax(grads[n].grad.cpu().numpy(), g[k]) <= 0.15, n
+            # the bound is TWICE what the reference moves against itself (8 threads vs 1) on its worst sampled tensor at this
+            # size, as measured with the reference (g6_noise.npz ssg/grad_relmax_worst = 3.8e-2; the MSG figure of that file
+            # is taken on a tensor whose exact gradient is zero and says nothing); the fp64 yardstick for the same gradients
+            # is asserted in test_parity_fullsize_gpu.py::test_small_batch_network_vs_fp64_and_reference_self_noise
+            assert relmax(grads[n].grad.cpu().numpy(), g[k]) <= 2.0 * float(golden("g6_noise.npz")["ssg/grad_relmax_worst"]), n
+
+
+def test_head_dropout_in_train_mode(dev):
+    """The one float op of the timed step that no oracle comparison covers: ``F.dropout(p=0.5)`` of the head
+    (model/pointnet2.py:172).  Its mask comes from torch's device Philox stream and cannot equal the reference's CPU draw,
+    so the checks are the ones that do not depend on the draw: survivors are the input scaled by exactly 1/(1-p), the dropped
+    fraction is p within sampling error, the mean is preserved, a different seed gives a different mask, eval mode is the
+    identity -- and the train-step loss stays in the band of the p = 0 oracle step (dropout perturbs, it must not bias)."""
+    from oracle import torch_ref as T
+    from pointnet12_amd import synthetic as syn
+    from pointnet12_amd.loss import nll_loss
+    pts_np, lab_np = syn.kitti_batch(40, 2, 1024)
+    torch.manual_seed(0)
+    net = M.PointNet2SemSeg(13, 6)
+    orc = T.RefSSGSemSeg(13, 6, dropout=0.0)
+    orc.load_state_dict(net.state_dict())
+    net.to(dev).train()
+    seen = {}
+    h = net.drop1.register_forward_hook(lambda m, i, o: seen.update(x=i[0].detach(), y=o.detach()))
+    pts, labels = torch.from_numpy(pts_np).to(dev), torch.from_numpy(lab_np).to(dev)
+    torch.manual_seed(1)
+    torch.cuda.manual_seed(7)
+    loss = nll_loss(net(pts).reshape(-1, 13), labels.reshape(-1))
+    loss.backward()
+    x, y = seen["x"], seen["y"]
+    assert net.drop1.p == 0.5
+    kept = y != 0
+    live = x != 0                                        # (post-ReLU input: its own zeros say nothing about the mask)
+    assert torch.equal(y[kept], x[kept] * 2.0)           # survivors: exactly x / (1 - p)
+    frac = float((kept & live).sum()) / float(live.sum())
+    n = int(live.sum())
+    assert abs(frac - 0.5) <= 5.0 * 0.5 / n ** 0.5       # five sigma of a fair coin over n draws
+    assert abs(float(y.mean()) - float(x.mean())) <= 0.02 * float(x.mean())
+    torch.manual_seed(1)
+    torch.cuda.manual_seed(8)
+    net(pts)
+    assert not torch.equal(seen["y"] != 0, kept)         # another seed, another mask
+    torch.manual_seed(1)
+    orc.train()
+    loss_ref = float(T.seg_loss(orc(torch.from_numpy(pts_np)), torch.from_numpy(lab_np)))
+    assert abs(float(loss) - loss_ref) <= 0.05 * loss_ref, (float(loss), loss_ref)
+    g = net.conv2.weight.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    net.eval()
+    with torch.no_grad():
+        net(pts)
+    assert torch.equal(seen["y"], seen["x"])             # eval mode: identity
+    h.remove()
 
 
 def test_reference_checkpoint_keys_load(dev):
@@ -142,7 +192,7 @@ def test_reference_checkpoint_keys_load(dev):
     assert len(sd) == 156
 
 
-@pytest.mark.parametrize("kind,D", [("ssg", 40), ("ssg", 33), ("msg", 64)])
+@pytest.mark.parametrize("kind,D", [("ssg", 40), ("ssg", 33), ("msg", 64), ("msg", 33), ("msg", 37)])   # msg 33 / 37: features first, D % 4 == 1 (padded copy of the feature columns)
 def test_factorised_first_layer_matches_oracle(dev, kind, D):
     """D >= 32 features: layer 1 runs as Zf[idx] + W_x (xyz - centre) (csrc/grouped.hip); compare the whole module,
     forward and backward, with the oracle module on the same state and inputs."""

@@ -32,10 +32,11 @@ from pointnet12_amd.loss import nll_loss
 pytestmark = pytest.mark.gpu
 
 FACTOR = 2.0            # log-probs: HIP at most this many times further from fp64 than the reference's arithmetic is
-GRAD_FACTOR = 4.0       # gradients: dominated by the handful of argmax / ReLU decisions that fall the other way than in fp64
+GRAD_FACTOR = 3.0       # gradients: dominated by the handful of argmax / ReLU decisions that fall the other way than in fp64
                         # (one flip at a pooled stage re-routes an O(1) gradient through every layer below it): the same
                         # build measured 0.4x and 2.2x the reference's distance on two runs that differ only in the order
-                        # of the fp64 statistics atomics (profiles/r02_parity_fullsize.json)
+                        # of the fp64 statistics atomics (profiles/r02_parity_fullsize.json; the six cases of that file sit at
+                        # 0.5 .. 1.25x: round 4 lowered the factor from 4 to 3 and the worst-tensor allowance from 8 to 4.5)
 REL_CAP = 4e-5          # |HIP - oracle fp32| on log-probs, relative to their magnitude, whatever the yardstick says
 REPORT = {}
 
@@ -126,7 +127,7 @@ def _assert_yardstick(r):
     assert r["hip_vs_orc32_max"] <= REL_CAP * max(1.0, r["log_probs_absmax"]), r
     # gradients: every tensor as close to fp64 as the reference arithmetic's (a tensor the reference gets unusually
     # right is held to the median error instead), and the distribution as a whole
-    assert r["grad_worst_ratio"] <= 2 * GRAD_FACTOR, r
+    assert r["grad_worst_ratio"] <= 1.5 * GRAD_FACTOR, r
     assert r["grad_l2_hip_vs_fp64_median"] <= GRAD_FACTOR * r["grad_l2_orc32_vs_fp64_median"], r
     assert r["grad_l2_hip_vs_fp64_worst"] <= GRAD_FACTOR * r["grad_l2_orc32_vs_fp64_worst"], r
 
@@ -161,6 +162,10 @@ def test_small_batch_network_vs_fp64_and_reference_self_noise(dev, kind):
     assert r["hip_vs_fp64_rms"] <= FACTOR * r["orc32_vs_fp64_rms"], r
     assert r["hip_vs_fp64_max"] <= FACTOR * max(r["orc32_vs_fp64_max"], r["reference_8_vs_1_threads_max"]), r
     assert r["hip_vs_orc32_max"] <= FACTOR * r["reference_8_vs_1_threads_max"], r
+    # gradients against the same fp64 evaluation (round 4: the sampled-tensor check of test_modules_gpu.py rests on this)
+    assert r["grad_l2_hip_vs_fp64_median"] <= GRAD_FACTOR * r["grad_l2_orc32_vs_fp64_median"], r
+    assert r["grad_l2_hip_vs_fp64_worst"] <= GRAD_FACTOR * r["grad_l2_orc32_vs_fp64_worst"], r
+    assert r["grad_worst_ratio"] <= 1.5 * GRAD_FACTOR, r
 
 
 def test_cfg5_single_cloud_vs_oracle(dev):

@@ -1,0 +1,268 @@
+"""GPU: every stage of the benchmark networks, TEACHER-FORCED with the oracle's own inputs, at BASELINE.json's real sizes.
+
+The north star asks for "fp32 MLP+max within 1e-5" of the reference's outputs on identical inputs.  At network level that
+cannot hold between ANY two fp32 evaluations (nine training-mode BatchNorm stages amplify rounding: the reference moves
+9e-5 against itself when only its thread count changes, tests/golden/g6_noise.npz), so the network-level tests use an fp64
+yardstick (test_parity_fullsize_gpu.py).  Here the claim is made where it is well-posed: the oracle network (oracle/torch_ref.py,
+pinned to the reference by tools/make_golden.py) runs forward + backward once on the host CPU and records, for every stage
+(sa1 .. sa4 / fp4 .. fp1 / head; model/pointnet_util.py:160-313, model/pointnet2.py:154-175), the tensors that ENTER it, the
+tensors that leave it and the gradient that comes back into it; the corresponding HIP module is fed exactly those inputs (and
+the same FPS start draw) and must reproduce
+
+  * new_xyz bit for bit, the feature output within FWD_TOL = 1e-5 (absolute; activations are O(1)),
+  * the parameter gradients within GRAD_TOL = 5e-5 of each tensor's largest entry,
+  * the input-feature gradient within GRAD_TOL of its largest entry on all but a counted handful of rows (a ReLU / arg-max
+    decision that falls the other way at a pre-activation within one rounding of zero, resp. between two rows whose post-BN
+    values round equal, re-routes ONE scalar of the incoming gradient: exact arithmetic cannot tell the two apart either),
+  * BatchNorm running statistics after the step (1e-5 relative),
+
+and the positions where the pooled arg-max differs from the reference's (note on the pooled argmax) are COUNTED:
+the rate is asserted, not argued.  Shapes: cfg3 = B=16 x 4096 x (3+6), SSG (the reference's PointNet2SemSeg) and MSG; cfg5 =
+one 65 536-point cloud through SSG and through MSG with npoint x16.  Numbers go to gpurun_out/parity_stages.json (copied to
+profiles/ per round).
+"""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import torch_ref as T
+from pointnet12_amd import pointnet2 as M
+from pointnet12_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-5
+GRAD_TOL = 5e-5
+ARGMAX_RATE = 2e-5          # pooled arg-max positions (among those that carry a gradient: output > 0) allowed to differ
+OUTLIER_ROWS = 1e-3         # fraction of input-gradient rows allowed beyond GRAD_TOL (each traced to a re-routed scalar)
+REPORT = {}
+
+
+def _report(key, value):
+    REPORT[key] = value
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_stages.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _stage_names(kind):
+    return (["sa1", "sa2", "sa3", "sa4", "fp4", "fp3", "fp2", "fp1"] if kind == "ssg"
+            else ["sa1", "sa2", "sa3", "fp3", "fp2", "fp1"])
+
+
+def _nets(kind, dev, npoint_scale=1):
+    torch.manual_seed(0)
+    if kind == "ssg":
+        orc, net = T.RefSSGSemSeg(13, 6, dropout=0.0), M.PointNet2SemSeg(13, 6)
+    else:
+        orc = T.RefMSGSemSeg(13, 6, dropout=0.0, npoint_scale=npoint_scale)
+        net = M.PointNet2SemSegMsg(13, 6, npoint_scale=npoint_scale)
+    net.load_state_dict(orc.state_dict())
+    net.drop1.p = 0.0
+    return net.to(dev).train(), orc.train()
+
+
+def _fps_starts(orc, kind, B, N0):
+    """The start draws the oracle's forward makes after ``torch.manual_seed(1)`` (pointnet_util.py:75: one CPU-generator
+    randint per sampling call, sa1 first), reproduced so that every stage can be re-run alone with ITS draw."""
+    torch.manual_seed(1)
+    starts, n = {}, N0
+    for name in _stage_names(kind):
+        m = getattr(orc, name)
+        if not name.startswith("sa") or getattr(m, "group_all", False):
+            continue
+        starts[name] = T.draw_start(B, n)
+        n = m.npoint
+    return starts
+
+
+def _oracle_pass(orc, kind, pts, labels):
+    """One forward + loss + backward of the oracle network; per stage: inputs (detached), outputs, gradient of the outputs."""
+    rec, hooks = {}, []
+    for name in _stage_names(kind):
+        def hook(mod, inp, out, name=name):
+            outs = out if isinstance(out, tuple) else (out,)
+            for o in outs:
+                if o.requires_grad:
+                    o.retain_grad()
+            rec[name] = {"in": [None if t is None else t.detach().clone() for t in inp],
+                         "in_grad": [t is not None and t.requires_grad for t in inp], "out": outs}
+        hooks.append(getattr(orc, name).register_forward_hook(hook))
+    torch.manual_seed(1)
+    lp = orc(pts)
+    lp.retain_grad()
+    T.seg_loss(lp, labels).backward()
+    for h in hooks:
+        h.remove()
+    last = _stage_names(kind)[-1]
+    rec["head"] = {"in": [rec[last]["out"][0].detach().clone()], "in_grad": [True], "out": (lp,)}
+    for name, r in rec.items():
+        r["gout"] = [None if o.grad is None else o.grad.detach().clone() for o in r["out"]]
+        r["out"] = [o.detach().clone() for o in r["out"]]
+    return rec
+
+
+def _pool_nodes(t):
+    """The _SharedMLP autograd nodes (pooled ones: saved arg-max present) behind a HIP module's output, in forward order."""
+    seen, stack, found = set(), [t.grad_fn], []
+    while stack:
+        fn = stack.pop()
+        if fn is None or id(fn) in seen:
+            continue
+        seen.add(id(fn))
+        if type(fn).__name__ == "_SharedMLPBackward" and fn.saved_tensors[2] is not None:
+            found.append(fn)
+        stack.extend(n for n, _ in fn.next_functions)
+    return found
+
+
+def _argmax_disagreement(hip_out, orc_stage, inputs, start, kind_msg):
+    """(differing, carrying): pooled positions whose recorded arg-max differs from the reference's ``torch.max(x, 2)`` index,
+    among those whose output is > 0 (only they route a gradient; an all-non-positive group is tied at 0 and routes none)."""
+    T.POOL_ARGMAX = []
+    try:
+        with torch.no_grad():
+            st = copy.deepcopy(orc_stage)
+            st(*inputs, **({"start": start} if start is not None else {}))
+        ref = list(T.POOL_ARGMAX)
+    finally:
+        T.POOL_ARGMAX = None
+    nodes = _pool_nodes(hip_out)
+    if len(nodes) != len(ref):
+        return None
+    # branches of an MSG stage: match by channel count and order of appearance (widths can repeat: keep forward order)
+    nodes = sorted(nodes, key=lambda fn: fn.saved_tensors[1].data_ptr())       # column slices of one matrix: ascending = forward order
+    diff = carry = 0
+    for fn, (idx_ref, val_ref) in zip(nodes, ref):                             # idx_ref, val_ref: [B, C, S]
+        out, arg = fn.saved_tensors[1], fn.saved_tensors[2]
+        B, C, S = idx_ref.shape
+        a = arg.view(B, S, -1)[:, :, :C].permute(0, 2, 1).cpu()
+        live = val_ref > 0
+        diff += int(((a.long() != idx_ref) & live).sum())
+        carry += int(live.sum())
+    return diff, carry
+
+
+def _relmax(a, ref):
+    return float((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _run_stages(tag, kind, dev, B, N, npoint_scale=1):
+    pts_np, lab_np = syn.kitti_batch(3, B, N)
+    pts, labels = torch.from_numpy(pts_np), torch.from_numpy(lab_np)
+    net, orc = _nets(kind, dev, npoint_scale)
+    pristine = copy.deepcopy(orc)                       # running statistics before the step
+    starts = _fps_starts(orc, kind, B, N)
+    rec = _oracle_pass(orc, kind, pts, labels)
+    summary, failures = {}, []
+    for name in _stage_names(kind) + ["head"]:
+        r = rec[name]
+        # ---- the oracle stage alone on the recorded inputs: its input gradients (parameter gradients equal the full pass's)
+        o_in = [None if t is None else t.clone().requires_grad_(g) for t, g in zip(r["in"], r["in_grad"])]
+        if name == "head":
+            o_mod = copy.deepcopy(pristine)
+            o_out = (o_mod.head(o_in[0]),)
+            o_params = {k: v for k, v in o_mod.named_parameters() if k.split(".")[0] in ("conv1", "bn1", "conv2")}
+            o_bufs = {k: v for k, v in o_mod.named_buffers() if k.split(".")[0] == "bn1"}
+        else:
+            o_mod = copy.deepcopy(getattr(pristine, name)).train()
+            kw = {"start": starts[name]} if name in starts else {}
+            o_out = o_mod(*o_in, **kw)
+            o_out = o_out if isinstance(o_out, tuple) else (o_out,)
+            o_params, o_bufs = dict(o_mod.named_parameters()), dict(o_mod.named_buffers())
+        torch.autograd.backward([o for o, g in zip(o_out, r["gout"]) if g is not None], [g for g in r["gout"] if g is not None])
+        # ---- the HIP stage on the same inputs
+        h_in = [None if t is None else t.to(dev).requires_grad_(g) for t, g in zip(r["in"], r["in_grad"])]
+        net.zero_grad(set_to_none=True)
+        if name == "head":
+            h_out = (net._seg_head(h_in[0])[0],)
+            h_params = {k: v for k, v in net.named_parameters() if k.split(".")[0] in ("conv1", "bn1", "conv2")}
+            h_bufs = {k: v for k, v in net.named_buffers() if k.split(".")[0] == "bn1"}
+        else:
+            h_mod = getattr(net, name)
+            kw = {"fps_start": starts[name].to(dev)} if name in starts else {}
+            h_out = h_mod(*h_in, **kw)
+            h_out = h_out if isinstance(h_out, tuple) else (h_out,)
+            h_params, h_bufs = dict(h_mod.named_parameters()), dict(h_mod.named_buffers())
+        s = {"rows": int(r["out"][-1].numel() // r["out"][-1].shape[1])}
+        # forward
+        if len(h_out) == 2:
+            s["new_xyz_equal"] = bool(torch.equal(h_out[0].detach().cpu(), r["out"][0]))
+            if not s["new_xyz_equal"]:
+                failures.append((name, "new_xyz differs"))
+        feat_h, feat_o = h_out[-1].detach().cpu(), r["out"][-1]
+        s["fwd_max_abs"] = float((feat_h - feat_o).abs().max())
+        s["fwd_ref_absmax"] = float(feat_o.abs().max())
+        if s["fwd_max_abs"] > FWD_TOL:
+            failures.append((name, "forward %.3g > %.0e" % (s["fwd_max_abs"], FWD_TOL)))
+        # pooled arg-max positions against the reference's
+        if name.startswith("sa"):
+            am = _argmax_disagreement(h_out[-1], getattr(pristine, name), r["in"], starts.get(name), kind == "msg")
+            if am is not None:
+                s["argmax_differs"], s["argmax_carrying"] = am
+                s["argmax_rate"] = am[0] / max(am[1], 1)
+                if s["argmax_rate"] > ARGMAX_RATE:
+                    failures.append((name, "arg-max rate %.3g" % s["argmax_rate"]))
+        # backward
+        torch.autograd.backward([o for o, g in zip(h_out, r["gout"]) if g is not None],
+                                [g.to(dev) for g in r["gout"] if g is not None])
+        torch.cuda.synchronize()
+        worst = ("", 0.0)
+        for k, p in o_params.items():
+            if "conv" in k and k.endswith("bias") and not (name == "head" and k == "conv2.bias"):
+                continue                                 # a bias in front of a training-mode BatchNorm: the exact gradient is 0
+            e = _relmax(h_params[k].grad.detach().cpu(), p.grad)
+            if e > worst[1]:
+                worst = (k, e)
+        s["param_grad_relmax_worst"] = worst[1]
+        s["param_grad_worst_tensor"] = worst[0]
+        if worst[1] > GRAD_TOL:
+            failures.append((name, "parameter gradient %s %.3g" % worst))
+        for i, (a, b) in enumerate(zip(h_in, o_in)):
+            if b is None or not b.requires_grad:
+                continue
+            ga, gb = a.grad.detach().cpu(), b.grad
+            scale = float(gb.abs().max())
+            err = (ga - gb).abs()
+            rows_bad = int((err.amax(dim=1) > GRAD_TOL * scale).sum())      # [B, C, N]: rows = points
+            total = ga.shape[0] * ga.shape[2]
+            s["in%d_grad_relmax" % i] = float(err.max()) / max(scale, 1e-30)
+            s["in%d_grad_l2_rel" % i] = float((ga - gb).norm() / gb.norm().clamp_min(1e-30))
+            s["in%d_grad_rows_beyond_tol" % i] = rows_bad
+            s["in%d_grad_rows" % i] = total
+            if rows_bad > OUTLIER_ROWS * total:
+                failures.append((name, "input %d gradient: %d of %d rows beyond tolerance" % (i, rows_bad, total)))
+        for k, v in o_bufs.items():
+            if k.endswith("num_batches_tracked"):
+                ok = int(h_bufs[k]) == int(v)
+            else:
+                ok = np.allclose(h_bufs[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6)
+            if not ok:
+                failures.append((name, "buffer " + k))
+        summary[name] = s
+        del h_in, h_out
+    _report(tag, summary)
+    assert not failures, (tag, failures, summary)
+
+
+@pytest.mark.parametrize("kind", ["ssg", "msg"])
+def test_cfg3_every_stage_teacher_forced(dev, kind):
+    """BASELINE.json configs[2] (B=16 x 4096 x 9): sa1 of MSG at K = 128 / P = 1 M rows, sa2, the group_all sa3, fp3 / fp2 / fp1
+    at B x 4096 rows, the head -- each against the oracle on the oracle's own stage inputs."""
+    _run_stages("cfg3_%s_B16x4096" % kind, kind, dev, 16, 4096)
+
+
+@pytest.mark.parametrize("kind,scale", [("ssg", 1), ("msg", 16)])
+def test_cfg5_every_stage_teacher_forced(dev, kind, scale):
+    """BASELINE.json configs[4], one 65 536-point cloud (the oracle's dense [B,S,N] formulation does not fit more)."""
+    _run_stages("cfg5_%s_B1x65536" % kind, kind, dev, 1, 65536, scale)
+    torch.cuda.empty_cache()

@@ -309,6 +309,26 @@ def test_prepare_batch_without_labels_and_into_static_buffers(dev):
         loader.prepare_batch(store, [], 512)
 
 
+def test_held_channel_first_view_follows_prepare_batch_into_static_buffers(dev):
+    """``prepare_batch(out=...)`` refills a static buffer through a raw pointer (no ``_version`` bump).  A
+    channel-first view of that buffer held across steps must not get the PREVIOUS batch's memoised channel-last copy back."""
+    from pointnet12_amd import pointnet_util as U
+    rng = np.random.default_rng(9)
+    scans = [rng.uniform(-50, 50, (m, 4)).astype(np.float32) for m in (700, 900)]
+    store = loader.ScanStore(scans, None, dev)
+    out = torch.zeros(2, 256, 4, device=dev)
+    held = out.permute(0, 2, 1)[:, :3, :]                      # [B, 3, N] view created once, as a training loop would
+    np.random.seed(1)
+    loader.prepare_batch(store, [0, 1], 256, train=False, out=(out, None))
+    a = U._channel_last(held, "xyz")
+    assert torch.equal(a, out[:, :, :3])
+    assert U._channel_last(held, "xyz") is a                   # unchanged data: the same copy (sa1 and fp1 share it)
+    np.random.seed(2)
+    loader.prepare_batch(store, [1, 0], 256, train=False, out=(out, None))
+    b = U._channel_last(held, "xyz")
+    assert torch.equal(b, out[:, :, :3]) and not torch.equal(a, b)
+
+
 def test_kitti_files_to_device_batch(dev, tmp_path):
     """.bin / .label files -> ScanStore -> one evaluation batch: every row is a normalised row of the filtered scan."""
     import os

@@ -1,9 +1,15 @@
 """Does a hipStreamWaitEvent(..., hipEventWaitExternal) issued under stream capture become an event-wait node that orders the
 replay behind work recorded on ANOTHER stream after the capture?  (torch.cuda.Event(external=True) is refused on ROCm.)"""
 import ctypes
+import os
+import sys
+
 import torch
 
-hip = ctypes.CDLL("libamdhip64.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pointnet12_amd.parallel import _loaded_hip_runtime      # the runtime torch is linked against, never a second copy by bare name
+
+hip = ctypes.CDLL(_loaded_hip_runtime())
 dev = torch.device("cuda:0")
 ev = ctypes.c_void_p()
 assert hip.hipEventCreateWithFlags(ctypes.byref(ev), 0x2) == 0
