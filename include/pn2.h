@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 7
+#define PN2_ABI_VERSION 8
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -66,6 +66,35 @@ typedef struct pn2_bn_coef_tail {           /* pn2_bn_bwd_coef of the layer whos
     float *dgamma, *dbeta;                  /* may be NULL */
     int accumulate;
 } pn2_bn_coef_tail;
+
+/* Consumer-side BatchNorm (ABI 8).  The statistics -> affine block step of training-mode BatchNorm (pn2_bn_finalize) and the
+ * reductions -> coefficients step of its backward (pn2_bn_bwd_coef) as a PROLOGUE of the first launch that reads the block,
+ * instead of a launch of their own (one fused relu(bn(conv)) per layer in the reference: model/pointnet_util.py:195-197,
+ * :252-255, :309-312).  The entry points that take a `const pn2_bn_lazy *` / `const pn2_bn_coef_lazy *` fill `affine` /
+ * `coef` (which MUST be the very block passed as their in_affine / affine / coef argument) from the finished sums before
+ * they read it; the block is valid for every later launch.  NULL: the block was already written.  Running statistics,
+ * num_batches_tracked and dgamma / dbeta are updated exactly once per call. */
+typedef struct pn2_bn_lazy {
+    const double *stats;          /* replicated sums of the producing launch (PN2_STAT_REPLICAS x 2 x C doubles) */
+    const float *gamma, *beta;    /* BatchNorm weight / bias, float[C] */
+    float eps, momentum;
+    float *running_mean, *running_var;      /* may be NULL */
+    int64_t *num_batches_tracked;           /* may be NULL */
+    float *affine;                /* float[4 * round4(C)], pad entries zero: filled */
+    int64_t count;                /* rows the statistics were taken over */
+    int C;
+} pn2_bn_lazy;
+
+typedef struct pn2_bn_coef_lazy {
+    const double *red;            /* replicated reductions (sum dZ, sum dZ * yhat) of the producing launch */
+    const float *gamma;
+    const float *affine;          /* this layer's affine block */
+    float *coef;                  /* float[4 * round4(C)]: filled */
+    float *dgamma, *dbeta;        /* may be NULL */
+    int accumulate;               /* != 0: dgamma / dbeta are added to */
+    int64_t count;
+    int C;
+} pn2_bn_coef_lazy;
 
 int pn2_version(void);
 const char *pn2_error_string(int code);
@@ -194,7 +223,7 @@ int pn2_copy_cols(const float *src, int lds, int scol0, float *dst, int ldd, int
  * sum(y) and sum(y*y) per output channel over the P rows (training-mode BN statistics).  P < 2^31 rows for the three conv1x1 entry points (PN2_EINVAL otherwise). */
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias,
                     float *Y, int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin,
-                    pn2_stream_t stream);
+                    const pn2_bn_lazy *in_lazy, pn2_stream_t stream);
 
 /* BatchNorm statistics -> affine block.  training != 0: mean/var (biased) from stats/P,
  * running_mean/var (may be NULL) updated with `momentum` and the unbiased variance,
@@ -214,17 +243,17 @@ int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, c
  * then. */
 int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
                          int ldy, int64_t P, int K, int N, double *stats, int Kpool, const float *gamma, float *pool_ws,
-                         pn2_stream_t stream);
+                         const pn2_bn_lazy *in_lazy, pn2_stream_t stream);
 /* out[g,c] = relu(bn(v)) of the recorded extreme value, arg[g,c] = its row (same outputs as pn2_bn_relu_max up to which of
  * several rows with EQUAL post-BN value is named).  C % 32 == 0, ldo == C. */
 int pn2_bn_pool_select(const float *pool_ws, const float *affine, int64_t G, int C, float *out, int ldo, int32_t *arg,
-                       pn2_stream_t stream);
+                       const pn2_bn_lazy *lazy, pn2_stream_t stream);
 
 /* out[g,c] = max_k relu(bn(Y[g*K+k, c])), arg[g,c] = first k attaining it (K = 1: plain
  * BN+ReLU, arg may be NULL).  Y pitch ldy, out / arg pitch ldo: both multiples of 4 and >= round4(C)
  * (rows are moved as float4; the pad columns of out / arg are written too, from the zero pad of `affine`). */
 int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int K, int C, float *out, int ldo,
-                    int32_t *arg, pn2_stream_t stream);
+                    int32_t *arg, const pn2_bn_lazy *lazy, pn2_stream_t stream);
 
 /* Backward, last layer after max-pool: dZp[g,c] = out[g,c] > 0 ? dOut[g,c] : 0 (pitch ldo, pad lanes zero),
  * red[0..C) = sum dZ, red[C..2C) = sum dZ*yhat with dZ[g*K+k,c] = (k == arg[g,c]) ? dZp[g,c] : 0.
@@ -264,7 +293,7 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
                       int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
                       double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail,
-                      pn2_stream_t stream);
+                      const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
 
 /* wgrad: dW[M,N] (pitch lddw, caller zeroes) += sum_p dY[p,m] * Xact[p,n]; M = C_l, N = C_{l-1}.
  * dY formed as in dgrad; Xact = bn_relu(prev_Y) when prev_affine != NULL, else X as is.
@@ -272,7 +301,7 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
 int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg,
                       int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
-                      pn2_stream_t stream);
+                      const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
 
 /* Fused backward of one layer for the narrow, long layers (csrc/mlp_res.hip): dgrad AND wgrad in ONE pass over dZ / Y /
  * prev_Y -- autograd of model/pointnet_util.py:197,254,312 for conv + BatchNorm + ReLU.  dY is formed once per row
@@ -288,7 +317,7 @@ int pn2_bwd_res_supported(int64_t P, int C_out, int C_in, int Kpool, int masked)
 int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool,
                     const float *Y, int ldy, const float *coef, const float *W, int ldw, const float *prev_Y,
                     int ld_prev, const float *prev_affine, float *dXout, int ldxo, double *prev_red, float *dW,
-                    int lddw, int64_t P, int C_out, int C_in, pn2_stream_t stream);
+                    int lddw, int64_t P, int C_out, int C_in, const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
 
 /* Eval-mode fused module (csrc/eval.hip): rows -> L x (linear + ReLU) -> max over the neighbours in ONE launch, BatchNorm
  * folded into the weights by the caller (W' = diag(gamma / sqrt(var + eps)) W, b' likewise; rows of pitch ldw >=

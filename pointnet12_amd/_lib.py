@@ -33,24 +33,24 @@ SIGNATURES = {
     "pn2_three_interp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "pn2_three_interp_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_copy_cols": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _i, _vp]),
-    "pn2_conv1x1_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "pn2_conv1x1_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_group_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
-    "pn2_conv1x1_fwd_pool": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _i, _vp, _vp, _vp]),
-    "pn2_bn_pool_select": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp]),
+    "pn2_conv1x1_fwd_pool": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "pn2_bn_pool_select": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_bn_finalize": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
-    "pn2_bn_relu_max": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
+    "pn2_bn_relu_max": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_pool_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_pool_bwd_reduce_ld": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_relu_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_bn_bwd_coef": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pn2_conv1x1_dgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp,
-                               _i64, _i, _i, _vp, _vp]),
+                               _i64, _i, _i, _vp, _vp, _vp]),
     "pn2_conv1x1_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
-                               _i64, _i, _i, _vp]),
+                               _i64, _i, _i, _vp, _vp]),
     "pn2_res_supported": (_i, [_i64, _i, _i]),
     "pn2_bwd_res_supported": (_i, [_i64, _i, _i, _i, _i]),
     "pn2_conv1x1_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
-                             _i64, _i, _i, _vp]),
+                             _i64, _i, _i, _vp, _vp]),
     "pn2_fused_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "pn2_invert_index": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_three_interp_bwd_seg": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -66,7 +66,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PN2_EUNSUPPORTED = -3            # include/pn2.h
 DWX_REPLICAS = 32        # PN2_DWX_REPLICAS of include/pn2.h
 
@@ -81,6 +81,18 @@ class BnCoefTail(ctypes.Structure):
     """pn2_bn_coef_tail of include/pn2.h."""
     _fields_ = [("ticket", _vp), ("gamma", _vp), ("affine", _vp), ("use_batch_stats", _i), ("coef", _vp), ("dgamma", _vp),
                 ("dbeta", _vp), ("accumulate", _i)]
+
+
+class BnLazy(ctypes.Structure):
+    """pn2_bn_lazy of include/pn2.h: statistics -> affine block inside the first launch that reads the block."""
+    _fields_ = [("stats", _vp), ("gamma", _vp), ("beta", _vp), ("eps", _f), ("momentum", _f), ("running_mean", _vp),
+                ("running_var", _vp), ("num_batches_tracked", _vp), ("affine", _vp), ("count", _i64), ("C", _i)]
+
+
+class BnCoefLazy(ctypes.Structure):
+    """pn2_bn_coef_lazy of include/pn2.h: reductions -> backward coefficients inside the first launch that reads them."""
+    _fields_ = [("red", _vp), ("gamma", _vp), ("affine", _vp), ("coef", _vp), ("dgamma", _vp), ("dbeta", _vp),
+                ("accumulate", _i), ("count", _i64), ("C", _i)]
 
 
 class EvalLayer(ctypes.Structure):

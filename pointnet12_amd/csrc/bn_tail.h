@@ -2,6 +2,25 @@
 #pragma once
 #include "pn2_common.h"
 
+// (outside the anonymous namespace: these cross translation units as arguments of the pn2_wide_* / pn2_fwd_res launchers)
+struct LazyBn {
+    const double *stats;        // nullptr: nothing to do (the block was written by pn2_bn_finalize or by an earlier launch)
+    const float *gamma, *beta;
+    float *affine, *rmean, *rvar;
+    int64_t *nbt;
+    double inv_p, unbias;
+    float eps, momentum;
+    int C;
+};
+
+struct LazyCoef {
+    const double *red;          // nullptr: nothing to do
+    const float *gamma, *aff;
+    float *coef, *dgamma, *dbeta;
+    double inv_p;
+    int C, accumulate;
+};
+
 namespace {
 
 struct Affine {   // views into a float[4*ld] affine block (see pn2.h)
@@ -115,5 +134,69 @@ __device__ __forceinline__ void run_coef_tail(const CoefTail &t, const double *r
     if (threadIdx.x == 0) *t.ticket = 0;
 }
 
+// ----------------------------------------------------------------------------- consumer-side BatchNorm (round 4)
+// The statistics -> affine block step (forward) and the reductions -> coefficients step (backward) as a PROLOGUE of the first
+// kernel that reads the block, instead of a 4.8 us launch of its own on the dependency chain (50 such hops per MSG-SemSeg step).
+// The producing launch has ended, so its fp64 sums are complete and visible; EVERY workgroup of the consumer recomputes the
+// block (the same fp64 arithmetic as bn_finalize_channel / bn_coef_channel: bit-identical values from every workgroup),
+// stores it to the block's global buffer -- where the kernel's loaders and every later kernel read it exactly as before --
+// waits for its own stores and meets at a workgroup barrier.  A CU's vector L1 is write-through and shared by the waves of a
+// workgroup: loads issued behind that barrier see the workgroup's own stores (workgroup-scope coherence, no fence needed),
+// and whatever another workgroup has written to the same lines is the same bytes.  Workgroup (0, 0, 0) alone updates what must
+// be written once: running statistics, num_batches_tracked, dgamma / dbeta.
+__device__ __forceinline__ void lazy_bn_prologue(const LazyBn &z) {
+    if (z.stats == nullptr) return;                                // (uniform: a kernel argument)
+    const bool first = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+    const int ld = (z.C + 3) & ~3;
+    for (int c = threadIdx.x; c < z.C; c += blockDim.x) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < PN2_STAT_REPLICAS; ++r) { s0 += z.stats[r * 2 * z.C + c]; s1 += z.stats[r * 2 * z.C + z.C + c]; }
+        bn_finalize_channel(s0, s1, c, ld, z.inv_p, z.unbias, z.gamma, z.beta, z.eps, z.momentum, first ? z.rmean : nullptr,
+                            first ? z.rvar : nullptr, z.affine);
+    }
+    if (first && threadIdx.x == 0 && z.nbt) *z.nbt += 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this thread's stores have reached the L2
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lazy_coef_prologue(const LazyCoef &z) {
+    if (z.red == nullptr) return;
+    const bool first = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+    const int ld = (z.C + 3) & ~3;
+    for (int c = threadIdx.x; c < z.C; c += blockDim.x) {
+        double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < PN2_STAT_REPLICAS; ++r) { r0 += z.red[r * 2 * z.C + c]; r1 += z.red[r * 2 * z.C + z.C + c]; }
+        bn_coef_channel(r0, r1, c, ld, z.inv_p, z.gamma, z.aff, 1, z.coef, first ? z.dgamma : nullptr, first ? z.dbeta : nullptr,
+                        z.accumulate);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+static inline LazyBn make_lazy_bn(const pn2_bn_lazy *z) {
+    LazyBn o{};
+    if (z && z->stats) {
+        const double n = (double)z->count;
+        o = LazyBn{z->stats, z->gamma, z->beta, z->affine, z->running_mean, z->running_var, z->num_batches_tracked, 1.0 / n,
+                   z->count > 1 ? n / (n - 1.0) : 1.0, z->eps, z->momentum, z->C};
+    }
+    return o;
+}
+
+static inline LazyCoef make_lazy_coef(const pn2_bn_coef_lazy *z) {
+    LazyCoef o{};
+    if (z && z->red) o = LazyCoef{z->red, z->gamma, z->affine, z->coef, z->dgamma, z->dbeta, 1.0 / (double)z->count, z->C, z->accumulate};
+    return o;
+}
+
+static inline bool lazy_bn_ok(const pn2_bn_lazy *z, const float *block, int C) {
+    return z == nullptr || (z->stats && z->gamma && z->beta && z->affine && z->affine == block && z->C == C && z->count > 0);
+}
+
+static inline bool lazy_coef_ok(const pn2_bn_coef_lazy *z, const float *block, int C) {
+    return z == nullptr || (z->red && z->gamma && z->affine && z->coef && z->coef == block && z->C == C && z->count > 0);
+}
 
 }  // namespace

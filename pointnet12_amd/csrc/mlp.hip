@@ -216,6 +216,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     const int l31 = lane & 31, lh = lane >> 5;
     const int n0 = n_lo + blockIdx.y * BN;           // n_lo > 0: this launch covers the output columns from n_lo on
     const int64_t tiles_m = (P + BM - 1) / BM;
+    aload.prologue();                                 // consumer-side BatchNorm: fill the block this loader reads (bn_tail.h)
     if (ALoad::kTab > 0) {                            // per-channel loader constants: global -> LDS once
         const float *src = aload.tab_src();
         for (int i = t * 4; i < ALoad::kTab * K4; i += NTHREADS * 4)
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fewrow_nt_kernel(ALoad aload, BMa
     const int tiles_n = N >> 6;
     const int tile = blockIdx.x * NT + wave / KS, ks = wave % KS;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    aload.prologue();                                 // consumer-side BatchNorm (bn_tail.h)
     if constexpr (kTabRows > 0) {
         const float *src;
         int pitch;
@@ -792,10 +794,10 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
         else rc = launch_nt<64, 128, 16, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 0, 128);
         if (rc != PN2_OK) return rc;
         const int rem = N - 128;
-        if (rem <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 128);
-        if (rem <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 128);
-        if constexpr (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 128);
-        else return launch_nt<128, 96, 16, 4, 1, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 128);
+        if (rem <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, true>(aload.without_lazy(), bm, P, K4, N, epi, s, 128);
+        if (rem <= 64) return launch_nt<128, 64, 32, 2, 2, 2, 1, BNN, true>(aload.without_lazy(), bm, P, K4, N, epi, s, 128);
+        if constexpr (ALoad::kRegs >= 8) return launch_nt<128, 96, 16, 4, 1, 2, 1, BNN, true>(aload.without_lazy(), bm, P, K4, N, epi, s, 128);
+        else return launch_nt<128, 96, 16, 4, 1, 3, 1, BNN, true>(aload.without_lazy(), bm, P, K4, N, epi, s, 128);
     }
     // 64x128 tiles, 16-deep k-steps: more, smaller workgroups per CU hide the operand stream's latency better than
     // 128x128x32 at two per CU (+10..17 %); deeper register prefetch rings (2..4 k-steps) were measured: no gain.
@@ -847,6 +849,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
     const int wr = wt / WC, wc = wt % WC;
     const int l31 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    dyload.prologue();                                // consumer-side BatchNorm backward (a layer without a data gradient)
     const int64_t p_begin = (int64_t)blockIdx.z * chunk;
     const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
     const int arow = t / (BM / 4), acq = (t % (BM / 4)) * 4;      // loader coordinates (fixed per thread)
@@ -1004,9 +1007,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_skinny_kernel(const float *__res
                                                               const float *__restrict__ coef, int ldc,
                                                               const float *__restrict__ X, int ldx, int64_t P, int M, int N,
                                                               int cg_log2, float *__restrict__ dW, int lddw,
-                                                              float *__restrict__ dbias) {
+                                                              float *__restrict__ dbias, LazyCoef lc) {
     constexpr int NA = NQ * 4;                                // accumulators per channel (+1 for the bias sum)
     __shared__ float red[4 * 64 * 4 * (NA + 1)];              // [wave][column group (<= 64)][4 channels][NA + 1]
+    lazy_coef_prologue(lc);                                   // consumer-side BatchNorm backward (bn_tail.h)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int CG = 1 << cg_log2, RS = 256 >> cg_log2;         // float4 column groups per row; rows per workgroup pass
     const int cq = t & (CG - 1), slot = t >> cg_log2;
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_skinny_kernel(const float *__res
 
 template <int NQ>
 int launch_skinny(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, int ldc, const float *X, int ldx,
-                  int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
+                  int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s, LazyCoef lc) {
     int cg_log2 = 3;                                          // 8 column groups = 32 channels at least
     while ((4 << cg_log2) < M && cg_log2 < 6) ++cg_log2;      // up to 64 groups = 256 channels per grid.y slab
     const int CG = 1 << cg_log2, RS = 256 >> cg_log2;
@@ -1092,7 +1096,7 @@ int launch_skinny(const float *dZ, int ldz, const float *Y, int ldy, const float
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((wgrad_skinny_kernel<NQ>), dim3((unsigned)gx, gy), dim3(256), 0, s, dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N,
-                       cg_log2, dW, lddw, dbias);
+                       cg_log2, dW, lddw, dbias, lc);
     return pn2_launch_status();
 }
 
@@ -1192,75 +1196,86 @@ template <bool kPooled>
 __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restrict__ Y, int ldy,
                                                           const float *__restrict__ aff, int lda, int64_t G, int K,
                                                           int lpr_log2, int ksplit, float *__restrict__ out, int ldo,
-                                                          int32_t *__restrict__ arg) {
+                                                          int32_t *__restrict__ arg, LazyBn lz) {
     __shared__ float sh_v[4][64][4];
     __shared__ int sh_k[4][64][4];
+    // Round 4: the grid is bounded (a few workgroups per CU, each walking its groups with a stride) so that the consumer-side
+    // BatchNorm prologue -- every workgroup turns the producer's sums into the affine block before it reads it -- is paid a few
+    // hundred times per launch, not once per group.
+    lazy_bn_prologue(lz);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int LPR = 1 << lpr_log2, RPW = 64 >> lpr_log2;
     const int cq = (blockIdx.x * LPR + (lane & (LPR - 1))) * 4;      // first of this lane's four channels
     const int rsub = lane >> lpr_log2;
-    const int64_t w = ksplit ? (int64_t)blockIdx.y : (int64_t)blockIdx.y * 4 + wv;   // group (pooled) / wave index
     const bool colv = cq < lda;
     Affine a(aff, lda);
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
     if (colv) { mu = ld4(a.mean + cq); sc = ld4(a.scale + cq); be = ld4(a.beta + cq); }
+    const int64_t wstep = ksplit ? (int64_t)gridDim.y : (int64_t)gridDim.y * 4;
     if (!kPooled) {                               // K == 1: RPW groups per wave, no reduction
-        const int64_t g = w * RPW + rsub;
-        if (!colv || g >= G) return;
-        const float4 y = ld4(Y + g * ldy + cq);
-        float4 o;
-        o.x = fmaxf(bn_act(y.x, mu.x, sc.x, be.x), 0.f);
-        o.y = fmaxf(bn_act(y.y, mu.y, sc.y, be.y), 0.f);
-        o.z = fmaxf(bn_act(y.z, mu.z, sc.z, be.z), 0.f);
-        o.w = fmaxf(bn_act(y.w, mu.w, sc.w, be.w), 0.f);
-        *reinterpret_cast<float4 *>(out + g * ldo + cq) = o;
-        if (arg) *reinterpret_cast<int4 *>(arg + g * ldo + cq) = make_int4(0, 0, 0, 0);
+        const int64_t waves = (G + RPW - 1) / RPW;
+        for (int64_t w = (int64_t)blockIdx.y * 4 + wv; w < waves; w += wstep) {
+            const int64_t g = w * RPW + rsub;
+            if (!colv || g >= G) continue;
+            const float4 y = ld4(Y + g * ldy + cq);
+            float4 o;
+            o.x = fmaxf(bn_act(y.x, mu.x, sc.x, be.x), 0.f);
+            o.y = fmaxf(bn_act(y.y, mu.y, sc.y, be.y), 0.f);
+            o.z = fmaxf(bn_act(y.z, mu.z, sc.z, be.z), 0.f);
+            o.w = fmaxf(bn_act(y.w, mu.w, sc.w, be.w), 0.f);
+            *reinterpret_cast<float4 *>(out + g * ldo + cq) = o;
+            if (arg) *reinterpret_cast<int4 *>(arg + g * ldo + cq) = make_int4(0, 0, 0, 0);
+        }
         return;
     }
-    if (w >= G) return;                           // wave-uniform (workgroup-uniform with ksplit)
-    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int bk[4] = {0, 0, 0, 0};
     const int kq = ksplit ? (K + 3) >> 2 : K;     // rows of this wave: [k_lo, k_hi)
     const int k_lo = ksplit ? wv * kq : 0, k_hi = k_lo + kq < K ? k_lo + kq : K;
-    if (colv) {
-        const float *y = Y + w * K * ldy + cq;
+    // (ksplit: w is uniform over the workgroup, so the barriers inside the loop are met by all four waves)
+    for (int64_t w = ksplit ? (int64_t)blockIdx.y : (int64_t)blockIdx.y * 4 + wv; w < G; w += wstep) {
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bk[4] = {0, 0, 0, 0};
+        if (colv) {
+            const float *y = Y + w * K * ldy + cq;
 #pragma unroll 8
-        for (int k = k_lo + rsub; k < k_hi; k += RPW) {
-            const float4 v = ld4(y + (int64_t)k * ldy);
-            const float o[4] = {fmaxf(bn_act(v.x, mu.x, sc.x, be.x), 0.f), fmaxf(bn_act(v.y, mu.y, sc.y, be.y), 0.f),
-                                fmaxf(bn_act(v.z, mu.z, sc.z, be.z), 0.f), fmaxf(bn_act(v.w, mu.w, sc.w, be.w), 0.f)};
+            for (int k = k_lo + rsub; k < k_hi; k += RPW) {
+                const float4 v = ld4(y + (int64_t)k * ldy);
+                const float o[4] = {fmaxf(bn_act(v.x, mu.x, sc.x, be.x), 0.f), fmaxf(bn_act(v.y, mu.y, sc.y, be.y), 0.f),
+                                    fmaxf(bn_act(v.z, mu.z, sc.z, be.z), 0.f), fmaxf(bn_act(v.w, mu.w, sc.w, be.w), 0.f)};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (o[e] > best[e]) { best[e] = o[e]; bk[e] = k; }
+                for (int e = 0; e < 4; ++e)
+                    if (o[e] > best[e]) { best[e] = o[e]; bk[e] = k; }
+            }
         }
-    }
-    for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float ov = __shfl_xor(best[e], off, 64);
-            const int ok = __shfl_xor(bk[e], off, 64);
-            if (ov > best[e] || (ov == best[e] && ok < bk[e])) { best[e] = ov; bk[e] = ok; }
-        }
-    }
-    if (ksplit) {                                 // quarters are in ascending k: "greater, or equal and smaller k" again
-        if (rsub == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sh_v[wv][lane][e] = best[e]; sh_k[wv][lane][e] = bk[e]; }
-        }
-        __syncthreads();
-        if (wv != 0) return;
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
+        for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float ov = sh_v[q][lane & (LPR - 1)][e];
-                const int ok = sh_k[q][lane & (LPR - 1)][e];
+                const float ov = __shfl_xor(best[e], off, 64);
+                const int ok = __shfl_xor(bk[e], off, 64);
                 if (ov > best[e] || (ov == best[e] && ok < bk[e])) { best[e] = ov; bk[e] = ok; }
             }
-    }
-    if (colv && rsub == 0) {
-        *reinterpret_cast<float4 *>(out + w * ldo + cq) = make_float4(best[0], best[1], best[2], best[3]);
-        if (arg) *reinterpret_cast<int4 *>(arg + w * ldo + cq) = make_int4(bk[0], bk[1], bk[2], bk[3]);
+        }
+        if (ksplit) {                             // quarters are in ascending k: "greater, or equal and smaller k" again
+            if (rsub == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sh_v[wv][lane][e] = best[e]; sh_k[wv][lane][e] = bk[e]; }
+            }
+            __syncthreads();
+            if (wv == 0) {
+#pragma unroll
+                for (int q = 1; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ov = sh_v[q][lane & (LPR - 1)][e];
+                        const int ok = sh_k[q][lane & (LPR - 1)][e];
+                        if (ov > best[e] || (ov == best[e] && ok < bk[e])) { best[e] = ov; bk[e] = ok; }
+                    }
+            }
+            __syncthreads();                      // the slots are free for the next group
+        }
+        if (colv && rsub == 0 && (!ksplit || wv == 0)) {
+            *reinterpret_cast<float4 *>(out + w * ldo + cq) = make_float4(best[0], best[1], best[2], best[3]);
+            if (arg) *reinterpret_cast<int4 *>(arg + w * ldo + cq) = make_int4(bk[0], bk[1], bk[2], bk[3]);
+        }
     }
 }
 
@@ -1444,43 +1459,48 @@ bool coef_tail_ok(const pn2_bn_coef_tail *t, const double *red) {
 }  // namespace
 
 int pn2_fwd_res(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
-                int64_t P, int K, int N, double *stats, hipStream_t s);      // mlp_res.hip
+                int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s);      // mlp_res.hip
 // mlp_wide.hip: register-stationary kernels for the wide layers; *rows_done = the leading rows they covered (whole tiles)
 int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
-                 int64_t P, int K, int N, double *stats, hipStream_t s, int64_t *rows_done);
+                 int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s, int64_t *rows_done);
 int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev, const float *prev_affine,
-                   float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, hipStream_t s, int64_t *rows_done);
+                   float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, LazyCoef lc, hipStream_t s, int64_t *rows_done);
 int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *X, int ldx, const float *x_affine, float *dW, int lddw, float *dbias,
-                   int64_t P, int M, int N, hipStream_t s);
+                   int64_t P, int M, int N, LazyCoef lc, hipStream_t s);
 
 extern "C" {
 
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
-                    int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin, pn2_stream_t stream) {
+                    int ldy, int64_t P, int K, int N, double *stats, const pn2_bn_finalize_tail *fin, const pn2_bn_lazy *in_lazy,
+                    pn2_stream_t stream) {
     PN2_CHECK_ARG(X && W && bias && Y && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && fin_tail_ok(fin, stats));
     PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= round4(K) && ldw >= K && ldy % 4 == 0 && ldy >= round4(N));
+    PN2_CHECK_ARG(lazy_bn_ok(in_lazy, in_affine, K) && (in_lazy == nullptr || in_affine != nullptr));
+    LazyBn lz = make_lazy_bn(in_lazy);                                  // realised by the FIRST launch below; later ones read the block
     if (fin == nullptr) {                                               // wide layer: W stays in registers (mlp_wide.hip)
         int64_t done = 0;
-        const int rc = pn2_wide_fwd(X, ldx, in_affine, W, ldw, bias, Y, ldy, P, K, N, stats, pn2_s(stream), &done);
+        const int rc = pn2_wide_fwd(X, ldx, in_affine, W, ldw, bias, Y, ldy, P, K, N, stats, lz, pn2_s(stream), &done);
         if (rc != PN2_EUNSUPPORTED) {
             if (rc != PN2_OK || done == P) return rc;
             X += done * ldx; Y += done * ldy; P -= done;                // ragged tail: the streamed kernel below
+            lz = LazyBn{};
         }
     }
     if (fin == nullptr && pn2_res_supported(P, N, K) && ldy >= N) {      // narrow, long layer: W stays in LDS (mlp_res.hip)
         const int64_t P_full = P & ~(int64_t)31;                        // whole 32-row slabs there, a ragged tail below
-        const int rc = pn2_fwd_res(X, ldx, in_affine, W, ldw, bias, Y, ldy, P_full, K, N, stats, pn2_s(stream));
+        const int rc = pn2_fwd_res(X, ldx, in_affine, W, ldw, bias, Y, ldy, P_full, K, N, stats, lz, pn2_s(stream));
         if (rc != PN2_EUNSUPPORTED) {                                   // (unsupported: W plus eight staging buffers exceed LDS)
             if (rc != PN2_OK || P_full == P) return rc;
             X += P_full * ldx; Y += P_full * ldy; P -= P_full;
+            lz = LazyBn{};
         }
     }
     const int K4 = round4(K);
     EpiFwd epi{Y, ldy, bias, stats, make_fin_tail(fin, P)};
     const BMat bm = make_bmat(W, ldw, K, K);
-    if (in_affine) return dispatch_nt<false>(LoadBnRelu{X, ldx, in_affine, zero_page_dev()}, bm, P, K4, N, epi, pn2_s(stream));
+    if (in_affine) return dispatch_nt<false>(LoadBnRelu{X, ldx, in_affine, zero_page_dev(), lz}, bm, P, K4, N, epi, pn2_s(stream));
     return dispatch_nt<false>(LoadPlain{X, ldx, zero_page_dev()}, bm, P, K4, N, epi, pn2_s(stream));
 }
 
@@ -1498,34 +1518,34 @@ int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, c
 }
 
 int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int K, int C, float *out, int ldo,
-                    int32_t *arg, pn2_stream_t stream) {
-    PN2_CHECK_ARG(Y && affine && out && G > 0 && K > 0 && C > 0);
+                    int32_t *arg, const pn2_bn_lazy *lazy, pn2_stream_t stream) {
+    PN2_CHECK_ARG(Y && affine && out && G > 0 && K > 0 && C > 0 && lazy_bn_ok(lazy, affine, C));
     const int ld = (C + 3) & ~3;
     PN2_CHECK_ARG(ldy % 4 == 0 && ldo % 4 == 0 && ldy >= ld && ldo >= ld);      // float4 rows; pad columns are written (0)
+    const LazyBn lz = make_lazy_bn(lazy);
     const int cg = ld / 4;
     int lpr_log2 = 0;
     while ((1 << lpr_log2) < cg && lpr_log2 < 6) ++lpr_log2;
     const int rpw = 64 >> lpr_log2;
     const unsigned gx = (unsigned)pn2_cdiv(cg, 1 << lpr_log2);
     const int64_t waves = K == 1 ? pn2_cdiv(G, rpw) : G;
+    // bounded grid: eight workgroups per CU in all (full occupancy for this light kernel), each walking its groups
+    int64_t cap = (int64_t)pn2_num_cus() * 8 / gx;
+    if (cap < 1) cap = 1;
+    if (cap > 65535) cap = 65535;
     if (K >= 32 && G * gx <= 4096 && G <= 65535) {      // too few groups to fill the chip with one wave each: split K
-        hipLaunchKernelGGL(bn_relu_max_kernel<true>, dim3(gx, (unsigned)G), dim3(256), 0, pn2_s(stream), Y, ldy, affine, ld, G, K,
-                           lpr_log2, 1, out, ldo, arg);
+        hipLaunchKernelGGL(bn_relu_max_kernel<true>, dim3(gx, (unsigned)(G < cap ? G : cap)), dim3(256), 0, pn2_s(stream), Y, ldy, affine, ld,
+                           G, K, lpr_log2, 1, out, ldo, arg, lz);
         return pn2_launch_status();
     }
-    // grid.y is limited to 65535 blocks of four waves: issue slabs
-    const int64_t slab = 65535LL * 4;
-    for (int64_t done = 0; done < waves; done += slab) {
-        const int64_t take = waves - done < slab ? waves - done : slab;
-        const int64_t g0 = K == 1 ? done * rpw : done;
-        const dim3 grid(gx, (unsigned)pn2_cdiv(take, 4));
-        if (K == 1)
-            hipLaunchKernelGGL(bn_relu_max_kernel<false>, grid, dim3(256), 0, pn2_s(stream), Y + g0 * ldy, ldy, affine, ld,
-                               G - g0, K, lpr_log2, 0, out + g0 * ldo, ldo, arg ? arg + g0 * ldo : nullptr);
-        else
-            hipLaunchKernelGGL(bn_relu_max_kernel<true>, grid, dim3(256), 0, pn2_s(stream), Y + g0 * K * ldy, ldy, affine, ld,
-                               G - g0, K, lpr_log2, 0, out + g0 * ldo, ldo, arg ? arg + g0 * ldo : nullptr);
-    }
+    int64_t gy = pn2_cdiv(waves, 4);
+    if (gy > cap) gy = cap;
+    if (K == 1)
+        hipLaunchKernelGGL(bn_relu_max_kernel<false>, dim3(gx, (unsigned)gy), dim3(256), 0, pn2_s(stream), Y, ldy, affine, ld, G, K,
+                           lpr_log2, 0, out, ldo, arg, lz);
+    else
+        hipLaunchKernelGGL(bn_relu_max_kernel<true>, dim3(gx, (unsigned)gy), dim3(256), 0, pn2_s(stream), Y, ldy, affine, ld, G, K,
+                           lpr_log2, 0, out, ldo, arg, lz);
     return pn2_launch_status();
 }
 
@@ -1567,9 +1587,11 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
 
 int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
                       const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
-                      double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail, pn2_stream_t stream) {
+                      double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail, const pn2_bn_coef_lazy *coef_lazy,
+                      pn2_stream_t stream) {
     PN2_CHECK_ARG(Y && coef && W && dXout && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && coef_tail_ok(prev_tail, prev_red) &&
-                  (prev_tail == nullptr || prev_Y != nullptr));
+                  (prev_tail == nullptr || prev_Y != nullptr) && lazy_coef_ok(coef_lazy, coef, K));
+    LazyCoef lc = make_lazy_coef(coef_lazy);                            // realised by the FIRST launch below
     const CoefTail ct = make_coef_tail(prev_tail, P);
     PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
     PN2_CHECK_ARG(ldw >= N && ldy % 4 == 0 && ldy >= round4(K) && ldxo % 4 == 0 && ldxo >= round4(N));
@@ -1580,9 +1602,10 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     if (prev_tail == nullptr && prev_Y != nullptr) {                    // wide layer: W stays in registers (mlp_wide.hip)
         int64_t done = 0;
         const int rc = pn2_wide_dgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, W, ldw, prev_Y, ld_prev, prev_affine, dXout, ldxo,
-                                      prev_red, P, K, N, s, &done);
+                                      prev_red, P, K, N, lc, s, &done);
         if (rc != PN2_EUNSUPPORTED) {
             if (rc != PN2_OK || done == P) return rc;
+            lc = LazyCoef{};
             // ragged tail (whole pooling groups: the tile height divides Kpool or is a multiple of it)
             if (dZ) dZ += done * ldz;
             else { dZp += (done / Kpool) * ldo; arg += (done / Kpool) * ldo; }
@@ -1591,14 +1614,14 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     }
     if (dZ) {
         PN2_CHECK_ARG(ldz % 4 == 0 && ldz >= K4);
-        LoadDyDense ld{dZ, ldz, Y, ldy, coef, ldc, zero_page_dev()};
+        LoadDyDense ld{dZ, ldz, Y, ldy, coef, ldc, zero_page_dev(), lc};
         if (prev_Y)
             return dispatch_nt<true>(ld, bm, P, K4, N,
                                      EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s);
         return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= K4);
-    LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev(), pow2_shift(Kpool)};
+    LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev(), pow2_shift(Kpool), lc};
     if (prev_Y)
         return dispatch_nt<true>(ld, bm, P, K4, N,
                                  EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s);
@@ -1607,33 +1630,34 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
 
 int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
-                      pn2_stream_t stream) {
-    PN2_CHECK_ARG(Y && coef && X && dW && P > 0 && P < (1LL << 31) && M > 0 && N > 0);
+                      const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream) {
+    PN2_CHECK_ARG(Y && coef && X && dW && P > 0 && P < (1LL << 31) && M > 0 && N > 0 && lazy_coef_ok(coef_lazy, coef, M));
+    const LazyCoef lc = make_lazy_coef(coef_lazy);
     PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
     PN2_CHECK_ARG(ldy % 4 == 0 && ldy >= round4(M) && ldx % 4 == 0 && ldx >= round4(N) && lddw >= N);
     const int ldc = round4(M);
     hipStream_t s = pn2_s(stream);
     PN2_CHECK_ARG(dZ ? (ldz % 4 == 0 && ldz >= round4(M)) : (ldo % 4 == 0 && ldo >= round4(M)));
     {                                                                   // wide layer: all of dW resident in one workgroup (mlp_wide.hip)
-        const int rc = pn2_wide_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, dbias, P, M, N, s);
+        const int rc = pn2_wide_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, dbias, P, M, N, lc, s);
         if (rc != PN2_EUNSUPPORTED) return rc;
     }
     if (dZ) {
         static const int skinny = pn2_env_int("PN2_WGRAD_SKINNY", 1);
         if (skinny && x_affine == nullptr && N <= 16 && P >= 4096) {     // first layers: stream dZ / Y once, no MFMA
             switch ((N + 3) / 4) {
-                case 1: return launch_skinny<1>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
-                case 2: return launch_skinny<2>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
-                case 3: return launch_skinny<3>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
-                default: return launch_skinny<4>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s);
+                case 1: return launch_skinny<1>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s, lc);
+                case 2: return launch_skinny<2>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s, lc);
+                case 3: return launch_skinny<3>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s, lc);
+                default: return launch_skinny<4>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s, lc);
             }
         }
-        LoadDyDense dy{dZ, ldz, Y, ldy, coef, ldc, zero_page_dev()};
+        LoadDyDense dy{dZ, ldz, Y, ldy, coef, ldc, zero_page_dev(), lc};
         if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
         return dispatch_tn(dy, LoadPlain{X, ldx, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= round4(M));
-    LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev(), pow2_shift(Kpool)};
+    LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev(), pow2_shift(Kpool), lc};
     if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
     return dispatch_tn(dy, LoadPlain{X, ldx, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
 }

@@ -72,6 +72,8 @@ struct LoadPlain {          // X as stored
     __device__ __forceinline__ const float *tab_src() const { return nullptr; }
     const float *X; int ldx; const float *zp;
     static constexpr int kRegs = 4;
+    __device__ __forceinline__ void prologue() const {}
+    LoadPlain without_lazy() const { return *this; }
     template <int IT> struct Raw { float4 x[IT]; };
     struct Params {};
     template <int IT>
@@ -90,6 +92,9 @@ struct LoadPlain {          // X as stored
 
 struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
     const float *X; int ldx; const float *aff; const float *zp;
+    LazyBn lz;              // consumer-side BatchNorm: `aff` is filled from the producer's sums by the kernel's prologue (bn_tail.h)
+    __device__ __forceinline__ void prologue() const { lazy_bn_prologue(lz); }
+    LoadBnRelu without_lazy() const { LoadBnRelu o = *this; o.lz = LazyBn{}; return o; }
     static constexpr int kRegs = 4;
     static constexpr int kTab = 0;          // its constants ride in the prefetched Raw registers
     __device__ __forceinline__ const float *tab_src() const { return nullptr; }
@@ -127,6 +132,7 @@ struct LoadBnRelu {         // relu(bn(Y_prev)) formed from the pre-BN tensor
 // constant rows are fetched ONCE (params(), hoisted in front of the position loop) instead of with every stage.
 struct LoadBnReluFixed {
     const float *X; int ldx; const float *aff; const float *zp;
+    __device__ __forceinline__ void prologue() const {}
     template <int IT> struct Raw { float4 x[IT]; };
     struct Params { float4 mu, sc, be; };
     template <int IT>
@@ -190,6 +196,9 @@ __device__ __forceinline__ float4 dy_from(const float4 dz, const float4 y, const
 
 struct LoadDyDense {
     const float *dZ; int ldz; const float *Y; int ldy; const float *coef; int ldc; const float *zp;
+    LazyCoef lc;            // consumer-side BatchNorm backward: `coef` is filled from the reductions by the kernel's prologue
+    __device__ __forceinline__ void prologue() const { lazy_coef_prologue(lc); }
+    LoadDyDense without_lazy() const { LoadDyDense o = *this; o.lc = LazyCoef{}; return o; }
     static constexpr int kRegs = 8;
     template <int IT> struct Raw { float4 dz[IT], y[IT]; };
     typedef DyParams Params;
@@ -220,6 +229,9 @@ struct LoadDyDense {
 struct LoadDyPooled {
     const float *dZp; int ldo; const int32_t *arg; int Kp;
     const float *Y; int ldy; const float *coef; int ldc; const float *zp; int kshift;   // kshift: log2(Kp) or -1
+    LazyCoef lc;
+    __device__ __forceinline__ void prologue() const { lazy_coef_prologue(lc); }
+    LoadDyPooled without_lazy() const { LoadDyPooled o = *this; o.lc = LazyCoef{}; return o; }
     static constexpr int kRegs = 13;
     template <int IT> struct Raw { float4 go[IT], y[IT]; int4 a[IT]; int kk[IT]; };
     typedef DyParams Params;

@@ -118,6 +118,7 @@ struct ResDy {
     const float *dZp; const int32_t *arg; int ldo; int kshift;   // pooled: [G, ldo], log2(Kp)
     const float *Y; int ld;                            // Y (and dZ) row pitch
     const float *coef;
+    LazyCoef lc;                                       // consumer-side BatchNorm backward: `coef` is filled by the prologue
 };
 
 // POOL: 0 dense dZ; 1 pooled with Kp a multiple of 64 (the tile lies in ONE group: one (dZp, arg) quad per thread and
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
     const int G = gridDim.x;
 
+    lazy_coef_prologue(dy.lc);                                     // consumer-side BatchNorm backward (bn_tail.h)
     // ---- one-time: W^T, coefficient table
     for (int i = t; i < Co * Ci; i += 512) {
         const int co = i / Ci, ci = i - co * Ci;
@@ -506,6 +508,7 @@ struct ResPool {
     float2 *rec;              // [G][ldp] records {extreme y, its row (int bits)}
     const float *gamma;       // BatchNorm weight of this layer: its sign picks maximum or minimum
     int ldp, U;               // U = slabs per group (Kp / 32; 1 for Kp = 16: two groups per slab)
+    LazyBn lz;                // consumer-side BatchNorm: the input's affine block is filled by the prologue (with or without pooling)
 };
 
 template <int K_T, int N_T, bool ACT, int POOL>      // POOL: 0 none, 1 groups of whole slabs (Kp % 32 == 0), 2 Kp == 16
@@ -520,6 +523,7 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
     float *Ab = atab + 3 * K + wave * (32 * LDA);                  // this wave's staging buffer [32][LDA]
 
+    lazy_bn_prologue(pool.lz);                                     // consumer-side BatchNorm (bn_tail.h)
     for (int i = t; i < N * QK; i += blockDim.x) {
         const int n = i / QK, q = i - n * QK;
         const float *src = W + (int64_t)n * ldw + 4 * q;
@@ -805,8 +809,9 @@ extern "C" int pn2_bwd_res_supported(int64_t P, int C_out, int C_in, int Kpool, 
 
 // Called by pn2_conv1x1_fwd (mlp.hip) for supported shapes when no fused BatchNorm tail is requested; P % 32 == 0.
 int pn2_fwd_res(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
-                int64_t P, int K, int N, double *stats, hipStream_t s) {
-    const ResPool none{};
+                int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s) {
+    ResPool none{};
+    none.lz = lz;
     if (in_affine) return dispatch_fwd_res<true, 0>(K, N, X, ldx, in_affine, W, ldw, bias, Y, ldy, P, stats, none, s);
     return dispatch_fwd_res<false, 0>(K, N, X, ldx, nullptr, W, ldw, bias, Y, ldy, P, stats, none, s);
 }
@@ -815,29 +820,33 @@ namespace {
 // out[g,c] = relu(bn(v)) with v the recorded maximum where the folded scale is >= 0 and the minimum where it is negative; arg
 // = the row that attained it.  Pad columns (c >= C) get the zero pad of the affine block like pn2_bn_relu_max writes them.
 __global__ __launch_bounds__(256) void bn_pool_select_kernel(const float2 *__restrict__ rec, int ldp, const float *__restrict__ aff, int lda,
-                                                             int64_t G, int C, float *__restrict__ out, int ldo, int32_t *__restrict__ arg) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                             int64_t G, int C, float *__restrict__ out, int ldo, int32_t *__restrict__ arg,
+                                                             LazyBn lz) {
+    lazy_bn_prologue(lz);                                          // consumer-side BatchNorm (bounded grid: paid once per workgroup)
     const int qpr = C >> 2;
-    if (i >= G * qpr) return;
-    const int64_t g = i / qpr;
-    const int c = (int)(i - g * qpr) * 4;
+    const int64_t n = G * qpr;
     Affine a(aff, lda);
-    const float4 mu = ld4(a.mean + c), sc = ld4(a.scale + c), be = ld4(a.beta + c);
-    const float4 r01 = ld4(reinterpret_cast<const float *>(rec + g * ldp + c)), r23 = ld4(reinterpret_cast<const float *>(rec + g * ldp + c + 2));
-    float4 o;
-    o.x = fmaxf(bn_act(r01.x, mu.x, sc.x, be.x), 0.f);
-    o.y = fmaxf(bn_act(r01.z, mu.y, sc.y, be.y), 0.f);
-    o.z = fmaxf(bn_act(r23.x, mu.z, sc.z, be.z), 0.f);
-    o.w = fmaxf(bn_act(r23.z, mu.w, sc.w, be.w), 0.f);
-    *reinterpret_cast<float4 *>(out + g * ldo + c) = o;
-    *reinterpret_cast<int4 *>(arg + g * ldo + c) = make_int4(__float_as_int(r01.y), __float_as_int(r01.w), __float_as_int(r23.y), __float_as_int(r23.w));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / qpr;
+        const int c = (int)(i - g * qpr) * 4;
+        const float4 mu = ld4(a.mean + c), sc = ld4(a.scale + c), be = ld4(a.beta + c);
+        const float4 r01 = ld4(reinterpret_cast<const float *>(rec + g * ldp + c)), r23 = ld4(reinterpret_cast<const float *>(rec + g * ldp + c + 2));
+        float4 o;
+        o.x = fmaxf(bn_act(r01.x, mu.x, sc.x, be.x), 0.f);
+        o.y = fmaxf(bn_act(r01.z, mu.y, sc.y, be.y), 0.f);
+        o.z = fmaxf(bn_act(r23.x, mu.z, sc.z, be.z), 0.f);
+        o.w = fmaxf(bn_act(r23.z, mu.w, sc.w, be.w), 0.f);
+        *reinterpret_cast<float4 *>(out + g * ldo + c) = o;
+        *reinterpret_cast<int4 *>(arg + g * ldo + c) = make_int4(__float_as_int(r01.y), __float_as_int(r01.w), __float_as_int(r23.y), __float_as_int(r23.w));
+    }
 }
 }  // namespace
 
 extern "C" int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
                                     int ldy, int64_t P, int K, int N, double *stats, int Kpool, const float *gamma, float *pool_ws,
-                                    pn2_stream_t stream) {
+                                    const pn2_bn_lazy *in_lazy, pn2_stream_t stream) {
     PN2_CHECK_ARG(X && in_affine && W && bias && Y && stats && gamma && pool_ws && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && Kpool > 0);
+    PN2_CHECK_ARG(lazy_bn_ok(in_lazy, in_affine, K));
     PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= K && ldw >= K && ldy % 4 == 0 && ldy >= N);
     if (!pn2_res_supported(P, N, K) || P % 32 != 0 || P % Kpool != 0 || !(Kpool == 16 || Kpool % 32 == 0)) return PN2_EUNSUPPORTED;
     PN2_CHECK_ARG((reinterpret_cast<uintptr_t>(pool_ws) & 15) == 0);
@@ -845,26 +854,32 @@ extern "C" int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_aff
     pool.rec = reinterpret_cast<float2 *>(pool_ws);
     pool.gamma = gamma;
     pool.ldp = N; pool.U = Kpool == 16 ? 1 : Kpool / 32;
+    pool.lz = make_lazy_bn(in_lazy);
     if (Kpool == 16) return dispatch_fwd_res<true, 2>(K, N, X, ldx, in_affine, W, ldw, bias, Y, ldy, P, stats, pool, pn2_s(stream));
     return dispatch_fwd_res<true, 1>(K, N, X, ldx, in_affine, W, ldw, bias, Y, ldy, P, stats, pool, pn2_s(stream));
 }
 
 extern "C" int pn2_bn_pool_select(const float *pool_ws, const float *affine, int64_t G, int C, float *out, int ldo, int32_t *arg,
-                                  pn2_stream_t stream) {
+                                  const pn2_bn_lazy *lazy, pn2_stream_t stream) {
+    PN2_CHECK_ARG(lazy_bn_ok(lazy, affine, C));
     // ldo: pitch of out AND of arg (out may be a column slice of a wider matrix: the concatenated MSG output)
     PN2_CHECK_ARG(pool_ws && affine && out && arg && G > 0 && C > 0 && C % 32 == 0 && ldo >= C && ldo % 4 == 0 &&
                   (reinterpret_cast<uintptr_t>(pool_ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
     const int64_t n = G * (C >> 2);
-    hipLaunchKernelGGL(bn_pool_select_kernel, dim3((unsigned)pn2_cdiv(n, 256)), dim3(256), 0, pn2_s(stream),
-                       reinterpret_cast<const float2 *>(pool_ws), C, affine, C, G, C, out, ldo, arg);
+    int64_t blocks = pn2_cdiv(n, 256);
+    const int64_t cap = (int64_t)pn2_num_cus() * 8;                 // bounded grid (see the kernel)
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(bn_pool_select_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream),
+                       reinterpret_cast<const float2 *>(pool_ws), C, affine, C, G, C, out, ldo, arg, make_lazy_bn(lazy));
     return pn2_launch_status();
 }
 
 extern "C" int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y,
                                int ldy, const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev,
                                const float *prev_affine, float *dXout, int ldxo, double *prev_red, float *dW, int lddw,
-                               int64_t P, int C_out, int C_in, pn2_stream_t stream) {
+                               int64_t P, int C_out, int C_in, const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream) {
     PN2_CHECK_ARG(Y && coef && W && prev_Y && dXout && dW && P > 0 && P < (1LL << 31) && res_shape_ok(C_out, C_in));
+    PN2_CHECK_ARG(lazy_coef_ok(coef_lazy, coef, C_out));
     PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0));
     PN2_CHECK_ARG(ldw >= C_in && lddw >= C_in && ldy % 4 == 0 && ldy >= C_out && ld_prev % 4 == 0 && ld_prev >= C_in && ldxo >= C_in);
     PN2_CHECK_ARG(prev_affine != nullptr || prev_red == nullptr);
@@ -878,10 +893,11 @@ extern "C" int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int l
     const int64_t ld_max = std::max(std::max((int64_t)ldy, (int64_t)ld_prev), std::max((int64_t)ldxo, dZ ? (int64_t)ldz : (int64_t)ldo));
     if (P * ld_max >= (1LL << 32)) { tiles = 0; P_full = 0; }
     if (tiles > 0) {
-        ResDy dy{dZ, dZp, arg, ldo, kshift, Y, ldy, coef};
+        ResDy dy{dZ, dZp, arg, ldo, kshift, Y, ldy, coef, make_lazy_coef(coef_lazy)};
         rc = dispatch_bwd_res(dZ ? 0 : Kpool, prev_affine != nullptr, C_out, C_in, dy, prev_Y, ld_prev, prev_affine, W, ldw, tiles, dXout, ldxo,
                               prev_red, dW, lddw, s);
         if (rc == PN2_EUNSUPPORTED) { rc = PN2_OK; tiles = 0; P_full = 0; }    // no weight-resident kernel for this pair: all rows below
+        else coef_lazy = nullptr;                                              // the block is filled: the tail launches read it
     }
     if (rc != PN2_OK || P_full == P) return rc;
     // ragged tail (< 64 rows), or a pair without a resident kernel: the streamed kernels, on offset pointers; everything
@@ -892,8 +908,8 @@ extern "C" int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int l
     const float *dZpt = dZ ? nullptr : dZp + g_off;
     const int32_t *argt = dZ ? nullptr : arg + g_off;
     rc = pn2_conv1x1_dgrad(dZt, ldz, dZpt, ldo, argt, Kpool, Y + P_full * ldy, ldy, coef, W, ldw, prev_affine ? prev_Y + P_full * ld_prev : nullptr,
-                           ld_prev, prev_affine, dXout + P_full * ldxo, ldxo, prev_red, tail, C_out, C_in, nullptr, stream);
+                           ld_prev, prev_affine, dXout + P_full * ldxo, ldxo, prev_red, tail, C_out, C_in, nullptr, coef_lazy, stream);
     if (rc != PN2_OK) return rc;
     return pn2_conv1x1_wgrad(dZt, ldz, dZpt, ldo, argt, Kpool, Y + P_full * ldy, ldy, coef, prev_Y + P_full * ld_prev, ld_prev, prev_affine,
-                             dW, lddw, nullptr, tail, C_out, C_in, stream);
+                             dW, lddw, nullptr, tail, C_out, C_in, nullptr, stream);
 }

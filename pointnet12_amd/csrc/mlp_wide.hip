@@ -36,6 +36,8 @@ struct RegwArgs {
     const float *prevY; int ldp; const float *prev_aff;            // EPI_MASK: previous layer's pre-BN output and affine block (pitch N4)
     double *red;                                                   // EPI_FWD: stats; EPI_MASK: prev_red (replicated, may be null)
     int64_t tiles; int K; int N;
+    LazyBn lz;                                                     // MODE_BNRELU: `tab` is filled by the prologue (consumer-side BatchNorm)
+    LazyCoef lc;                                                   // dgrad: `tab` (the coefficient block) likewise
 };
 
 extern __shared__ __attribute__((aligned(16))) float wide_lds[];
@@ -69,6 +71,8 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
     const int cb = wave % NCB, rs = wave / NCB;
     const int n = cb * 32 + l31;                                    // this lane's output column
     const int N = g.N, K = g.K;
+    if (MODE == MODE_BNRELU) lazy_bn_prologue(g.lz);                // consumer-side BatchNorm (bn_tail.h): before `tab` is copied
+    if (DY) lazy_coef_prologue(g.lc);
 
     // ---- one-time: this lane's slice of W, the B operand of every MFMA it issues: w[4 kb + e] = W(n, k = 8 kb + 4 lh + e)
     float w[KP / 2];
@@ -304,7 +308,9 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
                     e0 = a.mean[nl]; e1 = a.scale[nl]; e2 = a.beta[nl]; e3 = a.invstd[nl];
                     if (!(n < N4)) e1 = e2 = 0.f;
                 }
-                constexpr int PVB = LATE_E ? 8 : 16;                     // prevY values in flight per batch (LATE_E: register budget)
+                constexpr int PVB = 16;                                  // prevY values in flight per batch (8, requested in two dependent
+                                                                         // rounds, cost the 196 -> 128 launch 174 -> 213 us: four exposed
+                                                                         // round trips per tile instead of two)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -315,7 +321,6 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
                             pv[r - rb] = n < N4 ? pb[offp] : 0.f;
                             offp += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldp;
                         }
-                        if (LATE_E) asm volatile("" ::: "memory");       // the second batch is requested after the first was used
 #pragma unroll
                         for (int r = rb; r < rb + PVB; ++r) {
                             const float y = pv[r - rb];
@@ -383,11 +388,12 @@ inline int wide_env(const char *name, int dflt) {
 #define PN2_WIDE_MIN_ROWS_DEFAULT 65536
 
 int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
-                 int64_t P, int K, int N, double *stats, hipStream_t s, int64_t *rows_done) {
+                 int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s, int64_t *rows_done) {
     static const int on = wide_env("PN2_WIDE", 1), min_rows = wide_env("PN2_WIDE_MIN_ROWS", PN2_WIDE_MIN_ROWS_DEFAULT);
     *rows_done = 0;
     if (!on || P < min_rows || ldx != ((K + 3) & ~3)) return PN2_EUNSUPPORTED;
     RegwArgs g{};
+    g.lz = lz;
     g.A = X; g.lda = ldx; g.tab = in_affine; g.W = W; g.ldw = ldw; g.bias = bias; g.Out = Y; g.ldout = ldy; g.red = stats;
     g.K = K; g.N = N;
 #define WIDE_FWD(KK, NN, NCB, RS, TM, MINROWS)                                                                           \
@@ -410,12 +416,13 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
 
 int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev, const float *prev_affine,
-                   float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, hipStream_t s, int64_t *rows_done) {
+                   float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, LazyCoef lc, hipStream_t s, int64_t *rows_done) {
     static const int on = wide_env("PN2_WIDE", 1), min_rows = wide_env("PN2_WIDE_MIN_ROWS", PN2_WIDE_MIN_ROWS_DEFAULT);
     *rows_done = 0;
     if (!on || P < min_rows || ldy != ((K + 3) & ~3) || prev_Y == nullptr) return PN2_EUNSUPPORTED;
     if (!dZ && (Kpool <= 0 || P % Kpool != 0)) return PN2_EUNSUPPORTED;
     RegwArgs g{};
+    g.lc = lc;
     g.A = Y; g.lda = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.kshift = 0; g.tab = coef;
     g.W = W; g.ldw = ldw; g.Out = dXout; g.ldout = ldxo; g.prevY = prev_Y; g.ldp = ld_prev; g.prev_aff = prev_affine; g.red = prev_red;
     g.K = K; g.N = N;
@@ -459,6 +466,7 @@ struct WgradArgs {
     const float *X; int ldx; const float *x_aff;                   // layer input [P, ldx]; its affine block (pitch N4) or null
     float *dW; int lddw; float *dbias;
     int64_t P; int64_t rows_per_wg; int M; int N;
+    LazyCoef lc;                                                   // `coef` is filled by the prologue (a layer without a data gradient)
 };
 
 template <int MM, int NN, int TNW, int DYM, bool XACT, int PKP, int BP, bool BIAS>
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
     constexpr int M = MM, N = NN, M4 = (M + 3) & ~3, N4 = (N + 3) & ~3;
     constexpr int QA = M4 / 4, QB = N4 / 4;                        // quads per row that exist in memory
 
+    lazy_coef_prologue(g.lc);
     // ---- one-time: tables (zero beyond the real channels), zero pad columns of both chunk buffers
     for (int i = t; i < 4 * MB * 32; i += NT) { const int r = i / (MB * 32), c = i - r * (MB * 32); ctab[i] = c < M4 ? g.coef[r * M4 + c] : 0.f; }
     if (XACT)
@@ -661,14 +670,14 @@ int launch_wgrad_full(WgradArgs g, hipStream_t s) {
 // 128 x 128 dense; the input is always a BatchNorm + ReLU of the previous layer's output here
 int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *X, int ldx, const float *x_affine, float *dW, int lddw, float *dbias,
-                   int64_t P, int M, int N, hipStream_t s) {
+                   int64_t P, int M, int N, LazyCoef lc, hipStream_t s) {
     static const int on = wide_env("PN2_WIDE", 1) && wide_env("PN2_WIDE_WGRAD", 1);
     static const int min_rows = wide_env("PN2_WIDE_WGRAD_MIN_ROWS", 131072);
     if (!on || P < min_rows || x_affine == nullptr || ldy != ((M + 3) & ~3) || ldx != ((N + 3) & ~3)) return PN2_EUNSUPPORTED;
     if (!dZ && (Kpool <= 0 || P % Kpool != 0)) return PN2_EUNSUPPORTED;
     WgradArgs g{};
     g.Y = Y; g.ldy = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.coef = coef; g.X = X; g.ldx = ldx;
-    g.x_aff = x_affine; g.dW = dW; g.lddw = lddw; g.dbias = dbias; g.P = P; g.M = M; g.N = N;
+    g.x_aff = x_affine; g.dW = dW; g.lddw = lddw; g.dbias = dbias; g.P = P; g.M = M; g.N = N; g.lc = lc;
 #define WIDE_WGRAD(MM, NN, TNW, PKP, BP)                                                                                 \
     if (M == MM && N == NN && (PKP == 0 ? dZ != nullptr : (dZ == nullptr && Kpool == PKP)))                             \
         return launch_wgrad_full<MM, NN, TNW, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, true, PKP, BP>(g, s);

@@ -500,6 +500,11 @@ _DIRECT_GRADS = False
 # B=16 9.257 vs 9.245 ms, B=1 2.29 vs 2.33 ms; SSG 3.833 vs 3.827 ms) -- the last workgroup's ticket + device-scope
 # reads cost the same ~5 us as the dependent launch they replace -- so the stand-alone launches stay the default.
 FUSED_BN_TAILS = os.environ.get("PN2_FUSED_BN_TAILS", "0") == "1"
+# Consumer-side BatchNorm (round 4, ABI 8): the statistics -> affine block step and the reductions -> coefficients step run as a
+# prologue of the first kernel that READS the block (every workgroup recomputes it from the producer's finished fp64 sums) instead
+# of pn2_bn_finalize / pn2_bn_bwd_coef launches of their own -- 50 hops of ~5 us on the dependency chain of an MSG-SemSeg step, 44
+# of SSG's.  Same fp64 arithmetic per channel: bit-identical blocks.  0: the stand-alone launches (A/B runs).
+LAZY_BN = os.environ.get("PN2_LAZY_BN", "1") == "1"
 # the last layer of a pooled MLP records the per-group extrema in its GEMM epilogue (pn2_conv1x1_fwd_pool); 0: A/B runs
 POOL_IN_EPILOGUE = os.environ.get("PN2_POOL_EPILOGUE", "1") == "1"
 # narrow first layers: gather + first conv in one launch (pn2_group_conv_fwd); 0: pn2_group then the GEMM (A/B runs)
@@ -590,6 +595,12 @@ class _SharedMLP(torch.autograd.Function):
         gather = geom is not None and len(geom) > 5 and bool(geom[5])      # (xyz, new_xyz, idx, xyz_first, None, True)
         gathered = None
         w_pads = {}
+        lazy_on = training and LAZY_BN and not FUSED_BN_TAILS
+        lazy_prev = None                   # pn2_bn_lazy of the previous layer's block: realised by the next launch that reads it
+        keep = []                          # (ctypes structures must outlive the calls that take their address)
+
+        def in_lazy():
+            return None if lazy_prev is None else ctypes.byref(lazy_prev)
         for l in range(L):
             w, b, gamma, beta, rmean, rvar, nbt = flat[7 * l:7 * l + 7]
             co, ci = chans[l + 1], chans[l]
@@ -623,7 +634,7 @@ class _SharedMLP(torch.autograd.Function):
                     feat = torch.nn.functional.pad(feat, (0, ldd - gD))
                 zf = _empty_rows(gB * gN, co, dev)
                 _check(lib.pn2_conv1x1_fwd(_p(feat), ldd, None, wf_ptr, wf_ld, _p(b), _p(zf), zf.shape[1], gB * gN, gD, co,
-                                           None, None, st), "pn2_conv1x1_fwd")
+                                           None, None, None, st), "pn2_conv1x1_fwd")
                 _check(lib.pn2_group_affine_fwd(_p(zf), zf.shape[1], _p(g_xyz), _p(g_new), _p(g_idx), wx_ptr, ci, gB, gN, gS,
                                                 gK, co, _p(y), y.shape[1], _p(st_l), fin, st), "pn2_group_affine_fwd")
             elif (l == L - 1 and pool and training and fin is None and x_aff is not None and POOL_IN_EPILOGUE and P % 32 == 0 and
@@ -632,11 +643,11 @@ class _SharedMLP(torch.autograd.Function):
                 # pooled output needs no second pass over Y (unsupported shapes: the plain launch + pn2_bn_relu_max below)
                 pool_ws = torch.empty(2 * (P // pool) * co, device=dev, dtype=torch.float32)
                 rc = lib.pn2_conv1x1_fwd_pool(_p(x), ldx, _p(x_aff), _p(_contig_weight(w)), ci, _p(b), _p(y), y.shape[1], P, ci, co,
-                                              _p(st_l), pool, _p(gamma), _p(pool_ws), st)
+                                              _p(st_l), pool, _p(gamma), _p(pool_ws), in_lazy(), st)
                 if rc == _lib.PN2_EUNSUPPORTED:
                     pool_ws = None
                     _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(_contig_weight(w)), ci, _p(b), _p(y), y.shape[1], P, ci,
-                                               co, _p(st_l), fin, st), "pn2_conv1x1_fwd")
+                                               co, _p(st_l), fin, in_lazy(), st), "pn2_conv1x1_fwd")
                 else:
                     _check(rc, "pn2_conv1x1_fwd_pool")
             else:
@@ -644,8 +655,13 @@ class _SharedMLP(torch.autograd.Function):
                 if w_ld != ci:
                     w_pads[l] = w_rd                            # the data-gradient GEMM of the backward reads it too
                 _check(lib.pn2_conv1x1_fwd(_p(x), ldx, _p(x_aff), _p(w_rd), w_ld, _p(b), _p(y), y.shape[1], P, ci,
-                                           co, _p(st_l), fin, st), "pn2_conv1x1_fwd")
-            if fin is None:
+                                           co, _p(st_l), fin, in_lazy(), st), "pn2_conv1x1_fwd")
+            lazy_prev = None                                    # (whatever block the launch above read has been filled)
+            if fin is None and lazy_on:
+                # this layer's statistics become its affine block inside the next launch that reads the block
+                lazy_prev = _lib.BnLazy(_p(st_l), _p(gamma), _p(beta), eps, mom, _p(rmean), _p(rvar), _p(nbt), _p(aff), P, co)
+                keep.append(lazy_prev)
+            elif fin is None:
                 _check(lib.pn2_bn_finalize(_p(st_l), P, co, _p(gamma), _p(beta), eps, mom, int(training),
                                            _p(rmean), _p(rvar), _p(nbt), _p(aff), st), "pn2_bn_finalize")
             Ys.append(y)
@@ -664,9 +680,9 @@ class _SharedMLP(torch.autograd.Function):
         # the argmax shares the output's pitch inside the kernels (arg + g * ldo + c): its own buffer, same pitch
         arg = torch.empty(G, ldo, device=dev, dtype=torch.int32) if pool else None
         if pool_ws is not None:
-            _check(lib.pn2_bn_pool_select(_p(pool_ws), _p(affs[-1]), G, cl, _p(out), ldo, _p(arg), st), "pn2_bn_pool_select")
+            _check(lib.pn2_bn_pool_select(_p(pool_ws), _p(affs[-1]), G, cl, _p(out), ldo, _p(arg), in_lazy(), st), "pn2_bn_pool_select")
         else:
-            _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), ldo, _p(arg), st),
+            _check(lib.pn2_bn_relu_max(_p(Ys[-1]), Ys[-1].shape[1], _p(affs[-1]), G, K, cl, _p(out), ldo, _p(arg), in_lazy(), st),
                    "pn2_bn_relu_max")
         if training:
             bump_param_generation()             # running statistics were written through raw pointers
@@ -765,7 +781,14 @@ class _SharedMLP(torch.autograd.Function):
             ldy = y.shape[1]
             coef, dgamma, dbeta, dW, dbias = outs[l]
             w_p = flat[7 * l]
-            if not coef_done[l]:
+            # consumer-side BatchNorm backward: the first launch below that reads `coef` fills it from the reductions
+            coef_lazy = None
+            first_layer_special = l == 0 and ctx.geom is not None and ctx.gather is None
+            if not coef_done[l] and training and LAZY_BN and not first_layer_special and P * 4 * max(chans) <= _MALL_CHUNK_BYTES:
+                cl_struct = _lib.BnCoefLazy(_p(red[offs[l]:offs[l + 1]]), _p(gammas[l]), _p(aff), _p(coef), _p(dgamma), _p(dbeta),
+                                            int(direct), P, co)
+                coef_lazy = ctypes.byref(cl_struct)
+            elif not coef_done[l]:
                 _check(lib.pn2_bn_bwd_coef(_p(red[offs[l]:offs[l + 1]]), P, co, _p(gammas[l]), _p(aff), int(training),
                                            _p(coef), _p(dgamma), _p(dbeta), int(direct), st), "pn2_bn_bwd_coef")
             if not direct:
@@ -792,7 +815,7 @@ class _SharedMLP(torch.autograd.Function):
                 c_pool = (_p(dzp), ldo, _p(arg), K) if pooled else (None, 0, None, 0)
                 _check(lib.pn2_conv1x1_bwd(*c_dz, *c_pool, _p(y), ldy, _p(coef), _p(_contig_weight(Ws[l])), ci, _p(x), ldx,
                                            _p(x_aff), _p(dx), dx.shape[1], _p(red[offs[l - 1]:offs[l]]) if l > 0 else None,
-                                           _p(dW), ci, P, co, ci, st), "pn2_conv1x1_bwd")
+                                           _p(dW), ci, P, co, ci, coef_lazy, st), "pn2_conv1x1_bwd")
                 if not direct:
                     grads[7 * l] = dW.view_as(Ws[l])
                 if l > 0:
@@ -829,21 +852,23 @@ class _SharedMLP(torch.autograd.Function):
                     if l > 0:
                         _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, w_ld, c_x, ldx, _p(x_aff), c_dx,
                                                      dx.shape[1], _p(red[offs[l - 1]:offs[l]]), rn, co, ci,
-                                                     coef_tail(l - 1) if chunk == P else None, st), "pn2_conv1x1_dgrad")
+                                                     coef_tail(l - 1) if chunk == P else None, coef_lazy, st), "pn2_conv1x1_dgrad")
                     else:
                         _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, w_ld, None, 0, None, c_dx,
-                                                     ldx, None, rn, co, ci, None, st), "pn2_conv1x1_dgrad")
+                                                     ldx, None, rn, co, ci, None, coef_lazy, st), "pn2_conv1x1_dgrad")
+                    coef_lazy = None                            # filled: the weight gradient below reads it
                 if side is not None and chunk == P:
                     # the weight gradient on the companion stream: ordered behind everything issued so far on this stream (the
                     # coefficients, dZ), joined once at the end of this backward
                     side.wait_stream(main_stream)
                     with torch.cuda.stream(side):
                         _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
-                                                     None if training else _p(dbias), rn, co, ci, _lib.stream()), "pn2_conv1x1_wgrad")
+                                                     None if training else _p(dbias), rn, co, ci, coef_lazy, _lib.stream()), "pn2_conv1x1_wgrad")
                     side_used = True
                 else:
                     _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
-                                                 None if training else _p(dbias), rn, co, ci, st), "pn2_conv1x1_wgrad")
+                                                 None if training else _p(dbias), rn, co, ci, coef_lazy, st), "pn2_conv1x1_wgrad")
+                coef_lazy = None
             if not direct:
                 grads[7 * l] = dW.view_as(Ws[l])
             if l > 0:
@@ -887,7 +912,7 @@ class _SharedMLP(torch.autograd.Function):
         if ldd != D:
             feat = torch.nn.functional.pad(feat, (0, ldd - D)).contiguous()
         _check(lib.pn2_conv1x1_wgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), _p(feat), ldd, None,
-                                     dW.data_ptr() + 4 * f_col, ldw, None, B * N, co, D, st), "pn2_conv1x1_wgrad")
+                                     dW.data_ptr() + 4 * f_col, ldw, None, B * N, co, D, None, st), "pn2_conv1x1_wgrad")
         d_feats = None
         if need_dfeat:
             wf_ptr = _contig_weight(w).data_ptr() + (12 if g_first else 0)      # feature columns of the [co, 3+D] weight
@@ -896,7 +921,7 @@ class _SharedMLP(torch.autograd.Function):
                 wf_ptr, wf_ld = ctx.w_pads["wf"].data_ptr(), ctx.w_pads["wf"].shape[1]
             dF = _empty_rows(B * N, D, dev)
             _check(lib.pn2_conv1x1_dgrad(_p(G), ldc, None, 0, None, 0, _p(G), ldc, _p(ident), wf_ptr, wf_ld, None, 0, None,
-                                         _p(dF), ldd, None, B * N, co, D, None, st), "pn2_conv1x1_dgrad")
+                                         _p(dF), ldd, None, B * N, co, D, None, None, st), "pn2_conv1x1_dgrad")
             d_feats = (dF[:, :D] if ldd != D else dF).reshape(B, N, D)
         return d_feats, (dW.view_as(w) if w_grad is None else None)
 
@@ -916,7 +941,7 @@ class _Conv1x1(torch.autograd.Function):
         ci = weight.numel() // co
         y = _empty_rows(P, co, rows.device)
         _check(lib.pn2_conv1x1_fwd(_p(rows), ldx, None, _p(_contig_weight(weight)), ci, _p(bias), _p(y), y.shape[1], P, ci, co,
-                                   None, None, st), "pn2_conv1x1_fwd")
+                                   None, None, None, st), "pn2_conv1x1_fwd")
         ctx.save_for_backward(rows, weight)
         ctx.params = (weight, bias)             # leaf parameters (no grad_fn): no reference cycle
         ctx.dims = (P, ci, co, ldx, y.shape[1])
@@ -945,13 +970,13 @@ class _Conv1x1(torch.autograd.Function):
             dW = zb[:co * ci].view(co, ci)
             db = zb[co * ci:]
         _check(lib.pn2_conv1x1_wgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(rows), ldx, None, _p(dW), ci,
-                                     _p(db), P, co, ci, st), "pn2_conv1x1_wgrad")
+                                     _p(db), P, co, ci, None, st), "pn2_conv1x1_wgrad")
         d_rows = None
         if ctx.needs_input_grad[0]:
             d_rows = torch.empty(P, ldx, device=dev, dtype=torch.float32)     # pad lanes written (0) by the GEMM
             _check(lib.pn2_conv1x1_dgrad(_p(g), ldy, None, 0, None, 0, _p(g), ldy, _p(ident), _p(_contig_weight(weight)), ci,
                                          None, 0, None,
-                                         _p(d_rows), ldx, None, P, co, ci, None, st), "pn2_conv1x1_dgrad")
+                                         _p(d_rows), ldx, None, P, co, ci, None, None, st), "pn2_conv1x1_dgrad")
         if direct:
             return d_rows, None, None, None
         return d_rows, dW.view_as(weight), db, None

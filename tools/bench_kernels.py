@@ -91,18 +91,18 @@ def main():
             aff = affine(K) if K > 12 else None
 
             def fn():
-                rc = lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), None, st)
+                rc = lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), None, None, st)
                 assert rc == 0
             report("fwd", (P, K, N), timeit(fn, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
             for Kp in (16, 32, 64):              # the same GEMM with the pooling extrema recorded in its epilogue
                 if aff is None or not lib.pn2_res_supported(P, N, K) or N % 32 or K % 32:
                     continue
                 ws = torch.empty(4 * (P // Kp) * N, device=dev)
-                if lib.pn2_conv1x1_fwd_pool(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), Kp, p(bias), p(ws), st) != 0:
+                if lib.pn2_conv1x1_fwd_pool(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), Kp, p(bias), p(ws), None, st) != 0:
                     continue                     # W plus eight staging buffers exceed LDS
 
                 def fnp():
-                    rc = lib.pn2_conv1x1_fwd_pool(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), Kp, p(bias), p(ws), st)
+                    rc = lib.pn2_conv1x1_fwd_pool(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), Kp, p(bias), p(ws), None, st)
                     assert rc == 0
                 report("fwdpool%d" % Kp, (P, K, N), timeit(fnp, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
             del X, Y
@@ -132,7 +132,7 @@ def main():
 
                 def fn():
                     rc = lib.pn2_conv1x1_dgrad(*dz, p(Y), r4(Cl), p(coef), p(Wt), Cp, p(Yp), r4(Cp), p(affp), p(dX), r4(Cp),
-                                               p(red), P, Cl, Cp, None, st)
+                                               p(red), P, Cl, Cp, None, None, st)
                     assert rc == 0
                 report("dgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
             elif which == "bwd":
@@ -142,7 +142,7 @@ def main():
 
                 def fn():
                     rc = lib.pn2_conv1x1_bwd(*dz, p(Y), r4(Cl), p(coef), p(Wt), Cp, p(Yp), r4(Cp), p(affp), p(dX), r4(Cp), p(red),
-                                             p(dW), Cp, P, Cl, Cp, st)
+                                             p(dW), Cp, P, Cl, Cp, None, st)
                     assert rc == 0
                 report("bwd", (P, Cl, Cp, Kp), timeit(fn, args.reps), 4.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
             else:
@@ -150,7 +150,7 @@ def main():
 
                 def fn():
                     rc = lib.pn2_conv1x1_wgrad(*dz, p(Y), r4(Cl), p(coef), p(Yp), r4(Cp), p(affp) if Cp >= 16 else None, p(dW), Cp,
-                                               None, P, Cl, Cp, st)
+                                               None, P, Cl, Cp, None, st)
                     assert rc == 0
                 report("wgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + P * Cp))
 

@@ -13,7 +13,7 @@ for P, K, N in [(1048576, 96, 128), (262144, 196, 256), (1048576, 64, 96)]:
     Y = torch.empty(P, N, device=dev); stats = torch.zeros(8 * 2 * N, device=dev, dtype=torch.float64)
     aff = torch.ones(4 * K, device=dev)
     for _ in range(3):
-        lib.pn2_conv1x1_fwd(p(X), K, p(aff), p(W), K, p(b), p(Y), N, P, K, N, p(stats), None, st)
+        lib.pn2_conv1x1_fwd(p(X), K, p(aff), p(W), K, p(b), p(Y), N, P, K, N, p(stats), None, None, st)
     buf = (ctypes.c_ulonglong * (8 * 512))()
     raw.pn2_debug_stamps(buf, 8 * 512)
     a = np.array(buf, dtype=np.float64).reshape(512, 8)

@@ -45,7 +45,7 @@ for P, Cl, Cp, Kp in [(1048576, 128, 96, 128), (1048576, 96, 64, 0), (524288, 12
         dZ = rnd(P, Cl); dz = (p(dZ), Cl, None, 0, None, 0)
     dX = torch.empty(P, Cp, device=dev); red = torch.zeros(16 * Cp, device=dev, dtype=torch.float64); dW = torch.zeros(Cl, Cp, device=dev)
     for _ in range(3):
-        assert lib.pn2_conv1x1_bwd(*dz, p(Y), Cl, p(coef), p(Wt), Cp, p(Yp), Cp, p(affp), p(dX), Cp, p(red), p(dW), Cp, P, Cl, Cp, st) == 0
+        assert lib.pn2_conv1x1_bwd(*dz, p(Y), Cl, p(coef), p(Wt), Cp, p(Yp), Cp, p(affp), p(dX), Cp, p(red), p(dW), Cp, P, Cl, Cp, None, st) == 0
     print("bwd", (P, Cl, Cp, Kp))
     dump(["finish", "fetch", "barrier1", "compute", "barrier2", "", "", ""])
     del Y, Yp, dX
@@ -53,6 +53,6 @@ for P, K, N in [(1048576, 96, 128), (1048576, 64, 96)]:
     X = rnd(P, K); W = rnd(N, K); b = rnd(N); Y = torch.empty(P, N, device=dev)
     stats = torch.zeros(16 * N, device=dev, dtype=torch.float64); aff = affine(K)
     for _ in range(3):
-        assert lib.pn2_conv1x1_fwd(p(X), K, p(aff), p(W), K, p(b), p(Y), N, P, K, N, p(stats), None, st) == 0
+        assert lib.pn2_conv1x1_fwd(p(X), K, p(aff), p(W), K, p(b), p(Y), N, P, K, N, p(stats), None, None, st) == 0
     print("fwd", (P, K, N))
     dump(["transform", "fetch", "mfma", "epilogue(last)", "epilogue", "", "", ""])
