@@ -1462,7 +1462,8 @@ int pn2_fwd_res(const float *X, int ldx, const float *in_affine, const float *W,
                 int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s);      // mlp_res.hip
 // mlp_wide.hip: register-stationary kernels for the wide layers; *rows_done = the leading rows they covered (whole tiles)
 int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
-                 int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s, int64_t *rows_done);
+                 int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s, int64_t *rows_done, int Kpool = 0,
+                 const float *pool_gamma = nullptr, float *pool_ws = nullptr);
 int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev, const float *prev_affine,
                    float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, LazyCoef lc, hipStream_t s, int64_t *rows_done);

@@ -20,6 +20,11 @@
 #include "mlp_loaders.h"
 #include <algorithm>
 
+// mlp_wide.hip: the register-stationary forward (with the pooling extrema in its epilogue when Kpool > 0)
+int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
+                 int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s, int64_t *rows_done, int Kpool,
+                 const float *pool_gamma, float *pool_ws);
+
 namespace {
 
 constexpr int RES_BM = 64;
@@ -848,8 +853,14 @@ extern "C" int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_aff
     PN2_CHECK_ARG(X && in_affine && W && bias && Y && stats && gamma && pool_ws && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && Kpool > 0);
     PN2_CHECK_ARG(lazy_bn_ok(in_lazy, in_affine, K));
     PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= K && ldw >= K && ldy % 4 == 0 && ldy >= N);
-    if (!pn2_res_supported(P, N, K) || P % 32 != 0 || P % Kpool != 0 || !(Kpool == 16 || Kpool % 32 == 0)) return PN2_EUNSUPPORTED;
     PN2_CHECK_ARG((reinterpret_cast<uintptr_t>(pool_ws) & 15) == 0);
+    if (P % Kpool == 0 && ldy == N && N % 32 == 0) {                 // wide last layers (128 / 196 -> 256): the register-stationary forward
+        int64_t done = 0;
+        const int rc = pn2_wide_fwd(X, ldx, in_affine, W, ldw, bias, Y, ldy, P, K, N, stats, make_lazy_bn(in_lazy), pn2_s(stream), &done,
+                                    Kpool, gamma, pool_ws);
+        if (rc != PN2_EUNSUPPORTED) return rc;
+    }
+    if (!pn2_res_supported(P, N, K) || P % 32 != 0 || P % Kpool != 0 || !(Kpool == 16 || Kpool % 32 == 0)) return PN2_EUNSUPPORTED;
     ResPool pool;
     pool.rec = reinterpret_cast<float2 *>(pool_ws);
     pool.gamma = gamma;

@@ -36,6 +36,7 @@ struct RegwArgs {
     const float *prevY; int ldp; const float *prev_aff;            // EPI_MASK: previous layer's pre-BN output and affine block (pitch N4)
     double *red;                                                   // EPI_FWD: stats; EPI_MASK: prev_red (replicated, may be null)
     int64_t tiles; int K; int N;
+    float2 *pool_rec; const float *pool_gamma; int pool_ld;        // EPI_FWD with PKP > 0: per-group extrema records [G, pool_ld]
     LazyBn lz;                                                     // MODE_BNRELU: `tab` is filled by the prologue (consumer-side BatchNorm)
     LazyCoef lc;                                                   // dgrad: `tab` (the coefficient block) likewise
 };
@@ -127,11 +128,23 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
     const int N4 = (N + 3) & ~3;
     float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;                   // EPI_FWD: bias; EPI_MASK: mean, scale, beta, invstd of column n
     if (EPI == EPI_FWD) e0 = n < N ? g.bias[n] : 0.f;
+    // FPOOL: this forward feeds a max over groups of FPOOL consecutive rows (the last layer of a set-abstraction MLP): the
+    // epilogue also records, per group and channel, the extreme pre-BN value -- the largest, or the smallest where this
+    // layer's BatchNorm weight is negative (sign bit flipped: e1) -- with the first row attaining it, exactly as the
+    // weight-resident forward does (mlp_res.hip, ResPool); pn2_bn_pool_select turns the records into max_k relu(bn(y_k)).
+    constexpr int FPOOL = EPI == EPI_FWD ? PKP : 0;
+    static_assert(FPOOL == 0 || (RS == 1 && BM % FPOOL == 0 && FPOOL % 32 == 0), "forward pooling: whole groups inside a wave's tile");
+    if (FPOOL > 0) e1 = __int_as_float((n < N && g.pool_gamma[n] < 0.f) ? (int)0x80000000 : 0);
     // LATE_E: the 196-deep dense data gradient holds 100 weight registers next to two accumulator tiles and four staging
     // items; with the four epilogue constants resident as well it spilled six loop-invariant registers (28 bytes of scratch,
     // reloaded once per tile).  There the constants are fetched per tile instead, beside the prevY requests of the epilogue
     // (same cache lines for every tile: L1 hits that return under the wait those requests need anyway).
     constexpr bool LATE_E = EPI == EPI_MASK && KP == 200;
+#ifndef PN2_OPAQUE_TQ_ALL
+    constexpr bool OPAQUE_TQ = false;
+#else
+    constexpr bool OPAQUE_TQ = true;
+#endif
     if (EPI == EPI_MASK && !LATE_E && n < N4) {
         Affine a(g.prev_aff, N4);
         e0 = a.mean[n]; e1 = a.scale[n]; e2 = a.beta[n]; e3 = a.invstd[n];
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
             __syncthreads();                                        // chunk c is in `cur`; every wave is done with `nxt`
             // LATE_E (register budget): the lane's staging offsets are re-derived inside every chunk instead of living in
             // registers across the whole tile loop (one of them was spilled)
-            if (LATE_E) asm volatile("" : "+v"(tq));
+            if (LATE_E || OPAQUE_TQ || FPOOL > 0) asm volatile("" : "+v"(tq));
             const int kbs = QT(c) / 2;                              // 8-wide k blocks of this chunk (static after unrolling)
             const bool last = c == NCH - 1;
             const int64_t t1 = last ? tile + G : tile;              // the chunk staged during this one ...
@@ -287,6 +300,12 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
             if (EPI == EPI_FWD) {
                 float *yb = g.Out + row_off(row0, g.ldout);
                 unsigned off = lo;
+                constexpr int GPT = FPOOL > 0 ? BM / (FPOOL > 0 ? FPOOL : 1) : 1, BPG = FPOOL > 0 ? FPOOL / 32 : TM;
+                const int sg = __float_as_int(e1);
+                float mv[GPT];
+                int mk[GPT];
+#pragma unroll
+                for (int gq = 0; gq < GPT; ++gq) { mv[gq] = -INFINITY; mk[gq] = 0; }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -295,8 +314,30 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
                         if (n < N4) PN2_STREAM_STORE(y, yb + off);      // pad columns receive exact zeros (w = bias = 0)
                         s0 += y;
                         s1 = __builtin_fmaf(y, y, s1);
+                        if (FPOOL > 0) {
+                            // ascending block, ascending register = ascending row for this lane: a strict > keeps the first row
+                            const int gq = i / BPG;
+                            const float yp = __int_as_float(__float_as_int(y) ^ sg);
+                            const int row = (i - gq * BPG) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            mk[gq] = yp > mv[gq] ? row : mk[gq];
+                            mv[gq] = fmaxf(mv[gq], yp);
+                        }
                         off += ((r & 3) == 3 ? (r == 15 ? 5u : 5u) : 1u) * (unsigned)g.ldout;   // rows (r&3) + 8 (r>>2): +1 +1 +1 +5
                     }
+                if (FPOOL > 0) {
+#pragma unroll
+                    for (int gq = 0; gq < GPT; ++gq) {
+                        const float ov = __shfl_xor(mv[gq], 32, 64);   // the two half-waves hold disjoint rows of the column
+                        const int ok = __shfl_xor(mk[gq], 32, 64);
+                        const bool take = ov > mv[gq] || (ov == mv[gq] && ok < mk[gq]);
+                        const float v = take ? ov : mv[gq];
+                        const int k = take ? ok : mk[gq];
+                        // unconditional 8-byte stores, the same number every tile (both half-waves write the same record)
+                        if (n < N4)
+                            g.pool_rec[(int64_t)((unsigned)tile * GPT + gq) * g.pool_ld + lo] =
+                                make_float2(__int_as_float(__float_as_int(v) ^ sg), __int_as_float(k));
+                    }
+                }
             } else if (EPI == EPI_MASK) {
                 const float *pb = g.prevY + row_off(row0, g.ldp);
                 float *xb = g.Out + row_off(row0, g.ldout);
@@ -388,12 +429,31 @@ inline int wide_env(const char *name, int dflt) {
 #define PN2_WIDE_MIN_ROWS_DEFAULT 65536
 
 int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
-                 int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s, int64_t *rows_done) {
+                 int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s, int64_t *rows_done, int Kpool,
+                 const float *pool_gamma, float *pool_ws) {
     static const int on = wide_env("PN2_WIDE", 1), min_rows = wide_env("PN2_WIDE_MIN_ROWS", PN2_WIDE_MIN_ROWS_DEFAULT);
     *rows_done = 0;
     if (!on || P < min_rows || ldx != ((K + 3) & ~3)) return PN2_EUNSUPPORTED;
     RegwArgs g{};
     g.lz = lz;
+    g.pool_rec = reinterpret_cast<float2 *>(pool_ws); g.pool_gamma = pool_gamma; g.pool_ld = N;
+    if (Kpool > 0) {
+        // the last layer of a pooled MLP: whole tiles only (a pooled launch has no streamed tail), needs an input affine block
+        static const int pool_on = wide_env("PN2_WIDE_POOL", 1);
+        if (!pool_on || !in_affine || !pool_gamma || !pool_ws || P % 128 != 0) return PN2_EUNSUPPORTED;
+#define WIDE_FWD_POOL(KK, NN, NCB, TM, PKP)                                                                              \
+        if (K == KK && N == NN && Kpool == PKP) {                                                                        \
+            static_assert(32 * TM == 128, "pooled forward: 128-row tiles");                                              \
+            g.tiles = P / 128;                                                                                           \
+            *rows_done = P;                                                                                              \
+            return launch_regw<((KK + 3) & ~3), NCB, 1, TM, 64, MODE_BNRELU, EPI_FWD, false, PKP>(g, s);                  \
+        }
+        WIDE_FWD_POOL(128, 256, 8, 4, 64)         // sa2 of MSG (K = 64), PointNet2ClsMsg
+        WIDE_FWD_POOL(128, 256, 8, 4, 128)
+        WIDE_FWD_POOL(196, 256, 8, 4, 128)        // sa2 of MSG (K = 128)
+#undef WIDE_FWD_POOL
+        return PN2_EUNSUPPORTED;
+    }
     g.A = X; g.lda = ldx; g.tab = in_affine; g.W = W; g.ldw = ldw; g.bias = bias; g.Out = Y; g.ldout = ldy; g.red = stats;
     g.K = K; g.N = N;
 #define WIDE_FWD(KK, NN, NCB, RS, TM, MINROWS)                                                                           \

@@ -638,7 +638,7 @@ class _SharedMLP(torch.autograd.Function):
                 _check(lib.pn2_group_affine_fwd(_p(zf), zf.shape[1], _p(g_xyz), _p(g_new), _p(g_idx), wx_ptr, ci, gB, gN, gS,
                                                 gK, co, _p(y), y.shape[1], _p(st_l), fin, st), "pn2_group_affine_fwd")
             elif (l == L - 1 and pool and training and fin is None and x_aff is not None and POOL_IN_EPILOGUE and P % 32 == 0 and
-                  (pool == 16 or pool % 32 == 0) and lib.pn2_res_supported(P, co, ci)):
+                  (pool == 16 or pool % 32 == 0) and co % 32 == 0 and y.shape[1] == co):
                 # last layer of a pooled MLP: the weight-resident kernel also records the per-group extrema of y, so the
                 # pooled output needs no second pass over Y (unsupported shapes: the plain launch + pn2_bn_relu_max below)
                 pool_ws = torch.empty(2 * (P // pool) * co, device=dev, dtype=torch.float32)

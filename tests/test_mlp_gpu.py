@@ -205,7 +205,10 @@ def test_plain_conv1x1_bias_and_weight_gradients(dev, P, ci, co):
 
 
 @pytest.mark.parametrize("P,pool,chans", [(65536, 16, [64, 96, 128]), (65536, 32, [32, 32, 64]), (131072, 64, [32, 64, 128]),
-                                          (65536, 128, [64, 64, 96]), (32768 + 64, 64, [32, 64, 64])])
+                                          (65536, 128, [64, 64, 96]), (32768 + 64, 64, [32, 64, 64]),
+                                          # round 4: the register-stationary forward records the extrema too (sa2 of MSG-SemSeg:
+                                          # 128 -> 256 on groups of 64, 196 -> 256 on groups of 128)
+                                          (131072, 64, [64, 128, 256]), (131072, 128, [64, 196, 256]), (65536, 128, [64, 128, 256])])
 def test_pool_in_gemm_epilogue_equals_the_pooling_pass(dev, P, pool, chans):
     """pn2_conv1x1_fwd_pool + pn2_bn_pool_select (extrema of y recorded by the weight-resident GEMM's epilogue, BN + ReLU applied to
     the maximum where the folded scale is >= 0 and to the minimum where it is negative) against pn2_bn_relu_max over Y: the
