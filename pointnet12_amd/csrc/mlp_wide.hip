@@ -140,11 +140,8 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
     // reloaded once per tile).  There the constants are fetched per tile instead, beside the prevY requests of the epilogue
     // (same cache lines for every tile: L1 hits that return under the wait those requests need anyway).
     constexpr bool LATE_E = EPI == EPI_MASK && KP == 200;
-#ifndef PN2_OPAQUE_TQ_ALL
-    constexpr bool OPAQUE_TQ = false;
-#else
-    constexpr bool OPAQUE_TQ = true;
-#endif
+    // (re-deriving the offsets in EVERY instantiation frees 12 .. 28 registers but measured 3 - 5 % slower on the forward
+    // layers -- 162 -> 170, 231 -> 238, 80.6 -> 83.7 us -- so only the two register-bound cases take it)
     if (EPI == EPI_MASK && !LATE_E && n < N4) {
         Affine a(g.prev_aff, N4);
         e0 = a.mean[n]; e1 = a.scale[n]; e2 = a.beta[n]; e3 = a.invstd[n];
@@ -235,7 +232,7 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
             __syncthreads();                                        // chunk c is in `cur`; every wave is done with `nxt`
             // LATE_E (register budget): the lane's staging offsets are re-derived inside every chunk instead of living in
             // registers across the whole tile loop (one of them was spilled)
-            if (LATE_E || OPAQUE_TQ || FPOOL > 0) asm volatile("" : "+v"(tq));
+            if (LATE_E || FPOOL > 0) asm volatile("" : "+v"(tq));
             const int kbs = QT(c) / 2;                              // 8-wide k blocks of this chunk (static after unrolling)
             const bool last = c == NCH - 1;
             const int64_t t1 = last ? tile + G : tile;              // the chunk staged during this one ...
@@ -436,6 +433,8 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
     if (!on || P < min_rows || ldx != ((K + 3) & ~3)) return PN2_EUNSUPPORTED;
     RegwArgs g{};
     g.lz = lz;
+    g.A = X; g.lda = ldx; g.tab = in_affine; g.W = W; g.ldw = ldw; g.bias = bias; g.Out = Y; g.ldout = ldy; g.red = stats;
+    g.K = K; g.N = N;
     g.pool_rec = reinterpret_cast<float2 *>(pool_ws); g.pool_gamma = pool_gamma; g.pool_ld = N;
     if (Kpool > 0) {
         // the last layer of a pooled MLP: whole tiles only (a pooled launch has no streamed tail), needs an input affine block
@@ -454,8 +453,6 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
 #undef WIDE_FWD_POOL
         return PN2_EUNSUPPORTED;
     }
-    g.A = X; g.lda = ldx; g.tab = in_affine; g.W = W; g.ldw = ldw; g.bias = bias; g.Out = Y; g.ldout = ldy; g.red = stats;
-    g.K = K; g.N = N;
 #define WIDE_FWD(KK, NN, NCB, RS, TM, MINROWS)                                                                           \
     if (K == KK && N == NN && P >= MINROWS) {                                                                            \
         constexpr int BM = 32 * TM * RS;                                                                                 \
