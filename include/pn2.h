@@ -98,12 +98,6 @@ typedef struct pn2_bn_coef_lazy {
 
 int pn2_version(void);
 const char *pn2_error_string(int code);
-/* Share num / den (<= 1) of the compute units that the persistent launches issued AFTER this call size their grids by, until the
- * next call (process-wide, host-side state: set it around the launches of one branch and back to 1 / 1).  The scales of a
- * multi-scale set abstraction (model/pointnet_util.py:241-259) are independent chains of dependent launches; with shares in
- * proportion to their work they run side by side on disjoint CUs and each chain's fixed costs (weight loads, launch gaps,
- * atomic tails) hide under the other chains' work.  Results do not depend on it. */
-int pn2_set_cu_share(int num, int den);
 
 /* ------------------------------------------------------------------ geometry (index-exact) */
 

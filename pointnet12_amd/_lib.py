@@ -17,7 +17,6 @@ _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_
 SIGNATURES = {
     "pn2_version": (_i, []),
     "pn2_error_string": (ctypes.c_char_p, [_i]),
-    "pn2_set_cu_share": (_i, [_i, _i]),
     "pn2_fps_workspace_bytes": (_i64, [_i, _i, _i]),
     "pn2_fps": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
@@ -125,7 +124,7 @@ class _Timed:
     def __getattr__(self, name):
         fn = getattr(_raw, name)
         if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes",
-                                                   "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_bwd_res_supported", "pn2_set_cu_share",
+                                                   "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_bwd_res_supported",
                                                    "pn2_ball_query_workspace_bytes"):
             return fn
 

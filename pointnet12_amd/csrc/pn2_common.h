@@ -40,8 +40,7 @@ static inline int pn2_device_slot() {
 
 // Compute units of the CURRENT device (a CPX partition or a CU-masked queue reports its own count); cached per device:
 // a process may drive several GPUs (one rank per GPU is the supported layout, but nothing here assumes it).
-extern int pn2_cu_share_num, pn2_cu_share_den;   // api.hip: pn2_set_cu_share (1 / 1 = the whole chip)
-static inline int pn2_num_cus_all() {
+static inline int pn2_num_cus() {
     static int cus[PN2_MAX_DEVICES] = {0};
     const int slot = pn2_device_slot();
     if (cus[slot] == 0) {
@@ -52,14 +51,6 @@ static inline int pn2_num_cus_all() {
         cus[slot] = n > 0 ? n : 256;
     }
     return cus[slot];
-}
-// What the launchers size their persistent grids by: the CUs of the device, scaled by the share the caller set for the launches
-// of this branch (independent branches of a step -- the scales of a multi-scale set abstraction -- then run SIDE BY SIDE on
-// disjoint parts of the chip instead of one full-chip kernel after the other).
-static inline int pn2_num_cus() {
-    const int all = pn2_num_cus_all();
-    const int part = (int)((int64_t)all * pn2_cu_share_num / pn2_cu_share_den);
-    return part > 0 ? part : 1;
 }
 
 // Kernels that use more than 64 KiB of dynamic LDS raise the function attribute once PER DEVICE (the attribute belongs to the

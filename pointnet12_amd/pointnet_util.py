@@ -259,40 +259,6 @@ def index_points(points, idx, _checked=True):
 MSG_SCALE_STREAMS = os.environ.get("PN2_MSG_STREAMS", "1") == "1"     # measured: 10.36 -> 9.90 ms/step (MSG-SemSeg)
 MSG_LAST_SCALE_ON_MAIN = os.environ.get("PN2_MSG_MAIN_LAST", "1") == "1"
 _scale_stream_pool = {}
-# Round 4 experiment: every scale of a multi-scale stage sizes its persistent launches by a SHARE of the compute units in
-# proportion to its work (pn2_set_cu_share), so the scale branches run side by side instead of one full-chip kernel after the
-# other and each chain's fixed costs hide under the other chains' work.  0 = off.
-MSG_CU_SHARE = os.environ.get("PN2_MSG_CU_SHARE", "0") == "1"
-_CU_SHARE = [(1, 1)]
-
-
-@contextlib.contextmanager
-def _cu_share(num, den):
-    lib = _lib.load()
-    prev = _CU_SHARE[0]
-    _CU_SHARE[0] = (int(num), int(den))
-    _check(lib.pn2_set_cu_share(int(num), int(den)), "pn2_set_cu_share")
-    try:
-        yield
-    finally:
-        _CU_SHARE[0] = prev
-        lib.pn2_set_cu_share(*prev)
-
-
-def _scale_shares(P_list, chans_list):
-    """CU shares (numerators over 256) of the scales of one stage from a two-term cost model per layer: matrix time at ~0.55 of
-    the fp32 MFMA peak or stream time at ~4 TB/s, whichever is longer, plus a fixed cost per launch."""
-    t = []
-    for P, ch in zip(P_list, chans_list):
-        tot = 0.0
-        for ci, co in zip(ch[:-1], ch[1:]):
-            tot += max(2.0 * P * ci * co / (0.55 * 157e12), 4.0 * P * (ci + co) / 4.0e12) + 8e-6
-        t.append(tot)
-    total = sum(t)
-    nums = [max(16, int(round(256 * x / total))) for x in t]
-    while sum(nums) > 256:
-        nums[nums.index(max(nums))] -= 1
-    return nums
 
 
 def _scale_streams(device, n):
@@ -721,7 +687,6 @@ class _SharedMLP(torch.autograd.Function):
         if training:
             bump_param_generation()             # running statistics were written through raw pointers
         ctx.meta = (chans, pool, bool(training), P)
-        ctx.share = _CU_SHARE[0]
         ctx.geom = None if geom is None else (g_xyz, g_new, g_idx, bool(g_first), g_inv)   # index/coordinate tensors: no cycle
         ctx.gather = (gB, gN, gD) if gather else None
         if gather:
@@ -737,13 +702,6 @@ class _SharedMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        if ctx.share != (1, 1):                    # the branch's share of the chip, as in its forward
-            with _cu_share(*ctx.share):
-                return _SharedMLP._backward(ctx, grad_out)
-        return _SharedMLP._backward(ctx, grad_out)
-
-    @staticmethod
-    def _backward(ctx, grad_out):
         lib, st = _lib.load(), _lib.stream()
         chans, pool, training, P = ctx.meta
         saved = ctx.saved_tensors
@@ -1380,10 +1338,6 @@ class PointNetSetAbstractionMsg(nn.Module):
         if not _recording() and self.training and MSG_CONCAT_IN_PLACE and all(w % 4 == 0 for w in widths):
             big = torch.empty(B * S, sum(widths), device=xyz.device, dtype=torch.float32)
         col = 0
-        shares = None
-        if branch and MSG_CU_SHARE and self.training:
-            shares = _scale_shares([B * S * k for k in self.nsample_list],
-                                   [[c_in] + [c.out_channels for c in convs] for convs in self.conv_blocks])
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             # the last scale stays on the calling stream: one branch fewer (a captured step then has four concurrent
@@ -1402,10 +1356,8 @@ class PointNetSetAbstractionMsg(nn.Module):
                 inv = _group_inverse(idx, N, 0 if pts is None else pts.shape[2], len(self.conv_blocks[i]), self.training)
                 if _recording():
                     continue
-                share_cm = _cu_share(shares[i], 256) if shares is not None else contextlib.nullcontext()
-                with share_cm:
-                    outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
-                                            self.training, inv, None if big is None else (big, col)))   # features first (:247)
+                outs.append(grouped_mlp(xyz, pts, new_xyz, idx, False, self.conv_blocks[i], self.bn_blocks[i],
+                                        self.training, inv, None if big is None else (big, col)))   # features first (:247)
             col += widths[i]
         if branch:
             for i, (st, o) in enumerate(zip(streams, outs)):
