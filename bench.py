@@ -602,7 +602,9 @@ def main():
         # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes), per launch.
         # The file carries the digest of the kernel sources it was collected with: a stale file is not quoted.
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.workload)))
+        # one file per measured configuration: <workload> for the 4096-point configs, <workload>_n<points> for the dense scans
+        pmc_key = args.workload if n_points == 4096 else "%s_n%d" % (args.workload, n_points)
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % pmc_key)))
         pmc_doc, pmc_name, pmc_fresh = None, None, False
         if cands:
             pmc_name = os.path.basename(cands[-1])

@@ -360,7 +360,7 @@ int pn2_three_interp_bwd_seg(const float *grad_out, int ld, int col0, const int3
 int pn2_group_affine_bwd_seg(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
                              const float *new_xyz, const int32_t *members, const int32_t *owners, int B, int N, int S,
                              int K, int C, float *G, int ldg, float *dWx, int ldwx, float *dwx_scratch,
-                             pn2_stream_t stream);
+                             const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
 
 /* ---- the loss either side of the path ---------------------------------------
  * Replaces F.nll_loss(pred, target) of semseg.py:143 (weight == NULL) and the class-weighted form of

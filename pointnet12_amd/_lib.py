@@ -55,7 +55,7 @@ SIGNATURES = {
     "pn2_invert_index": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_three_interp_bwd_seg": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pn2_group_affine_bwd_seg": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i,
-                                         _vp, _vp]),
+                                         _vp, _vp, _vp]),
     "pn2_nll_loss_workspace_bytes": (_i64, [_i64]),
     "pn2_nll_loss_fwd": (_i, [_vp, _i, _vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp]),
     "pn2_nll_loss_bwd": (_i, [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp]),

@@ -14,6 +14,7 @@
 // KITTI-shaped cloud has targets with hundreds of members next to targets with none: one-wave-per-target gathers ran
 // 2x SLOWER than the atomics), and ~10x fewer atomics than the element-wise scatter.
 #include "pn2_common.h"
+#include "bn_tail.h"
 #include <stdlib.h>
 
 namespace {
@@ -254,8 +255,9 @@ __global__ __launch_bounds__(256) void group_affine_bwd_seg_kernel(const float *
                                                                    int C, int lpr_log2, int chunk, int chunks_per_cloud,
                                                                    int64_t chunks, float *__restrict__ G, int ldg,
                                                                    float *__restrict__ dWx, int ldwx,
-                                                                   float *__restrict__ rep) {
+                                                                   float *__restrict__ rep, LazyCoef lc) {
     __shared__ float red[256 * 12];
+    lazy_coef_prologue(lc);                            // consumer-side BatchNorm backward (bn_tail.h): `coef` filled here
     const int t = threadIdx.x, lane = t & 63;
     const int LPR = 1 << lpr_log2, GPW = 64 >> lpr_log2;
     const int sub = lane & (LPR - 1);
@@ -413,9 +415,9 @@ int pn2_three_interp_bwd_seg(const float *grad_out, int ld, int col0, const int3
 int pn2_group_affine_bwd_seg(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *xyz,
                              const float *new_xyz, const int32_t *members, const int32_t *owners, int B, int N, int S,
                              int K, int C, float *G, int ldg, float *dWx, int ldwx, float *dwx_scratch,
-                             pn2_stream_t stream) {
+                             const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream) {
     PN2_CHECK_ARG(dZ && Y && coef && xyz && new_xyz && members && owners && G && dWx && B > 0 && N > 0 && S > 0 && K > 0 &&
-                  C > 0 && C <= 256);
+                  C > 0 && C <= 256 && lazy_coef_ok(coef_lazy, coef, C));
     PN2_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && ldg % 4 == 0 && ldg >= ((C + 3) & ~3) && ldwx >= 3);
     int lpr_log2 = 0;
     while ((4 << lpr_log2) < C && lpr_log2 < 6) ++lpr_log2;
@@ -426,7 +428,8 @@ int pn2_group_affine_bwd_seg(const float *dZ, int ldz, const float *Y, int ldy, 
     int64_t blocks = pn2_cdiv(pn2_cdiv(chunks, 64 >> lpr_log2), 4);
     if (blocks > 1024) blocks = 1024;                  // every workgroup ends with 3*C atomics for dWx
     hipLaunchKernelGGL(group_affine_bwd_seg_kernel, dim3((unsigned)blocks), dim3(256), 0, pn2_s(stream), dZ, ldz, Y, ldy, coef,
-                       C4, xyz, new_xyz, members, owners, N, S, K, C, lpr_log2, chunk, cpc, chunks, G, ldg, dWx, ldwx, dwx_scratch);
+                       C4, xyz, new_xyz, members, owners, N, S, K, C, lpr_log2, chunk, cpc, chunks, G, ldg, dWx, ldwx, dwx_scratch,
+                       make_lazy_coef(coef_lazy));
     if (dwx_scratch)
         hipLaunchKernelGGL(dwx_fold_kernel, dim3(1), dim3(256), 0, pn2_s(stream), dwx_scratch, C, C4, dWx, ldwx);
     return pn2_launch_status();

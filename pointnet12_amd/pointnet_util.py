@@ -784,7 +784,9 @@ class _SharedMLP(torch.autograd.Function):
             # consumer-side BatchNorm backward: the first launch below that reads `coef` fills it from the reductions
             coef_lazy = None
             first_layer_special = l == 0 and ctx.geom is not None and ctx.gather is None
-            if not coef_done[l] and training and LAZY_BN and not first_layer_special and P * 4 * max(chans) <= _MALL_CHUNK_BYTES:
+            # (the factorised first layer: its segmented scatter kernel is the consumer; the atomics form is not)
+            seg_ok = not first_layer_special or (ctx.geom[4] is not None and co <= 256)
+            if not coef_done[l] and training and LAZY_BN and seg_ok:
                 cl_struct = _lib.BnCoefLazy(_p(red[offs[l]:offs[l + 1]]), _p(gammas[l]), _p(aff), _p(coef), _p(dgamma), _p(dbeta),
                                             int(direct), P, co)
                 coef_lazy = ctypes.byref(cl_struct)
@@ -795,7 +797,7 @@ class _SharedMLP(torch.autograd.Function):
                 grads[7 * l + 1], grads[7 * l + 2], grads[7 * l + 3] = dbias, dgamma, dbeta
             if l == 0 and ctx.geom is not None and ctx.gather is None:
                 d_rows, dW0 = _SharedMLP._first_layer_bwd(ctx, rows, Ws[0], dZ, y, coef, co, ctx.needs_input_grad[0],
-                                                          w_p.grad if direct else None)
+                                                          w_p.grad if direct else None, coef_lazy)
                 grads[0] = dW0
                 continue
             x = rows if l == 0 else Ys[l - 1]
@@ -885,7 +887,7 @@ class _SharedMLP(torch.autograd.Function):
         return (d_rows, None, None, None, None, None, None) + tuple(grads)
 
     @staticmethod
-    def _first_layer_bwd(ctx, feats, w, dZ, y, coef, co, need_dfeat, w_grad):
+    def _first_layer_bwd(ctx, feats, w, dZ, y, coef, co, need_dfeat, w_grad, coef_lazy=None):
         """Backward of the factorised first layer: scatter dY to the source points, then two small GEMMs.
         ``w_grad``: None (return dW) or the [co, 3+D] gradient tensor to accumulate into (returns None)."""
         lib, st = _lib.load(), _lib.stream()
@@ -903,7 +905,7 @@ class _SharedMLP(torch.autograd.Function):
             scratch = _zeros_small(4 * _lib.DWX_REPLICAS * 3 * ldc, dev) if DWX_REPLICAS_SCRATCH else None
             _check(lib.pn2_group_affine_bwd_seg(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new),
                                                 _p(g_inv[0]), _p(g_inv[1]), B, N, S, K, co, _p(G), ldc,
-                                                dW.data_ptr() + 4 * x_col, ldw, _p(scratch), st), "pn2_group_affine_bwd_seg")
+                                                dW.data_ptr() + 4 * x_col, ldw, _p(scratch), coef_lazy, st), "pn2_group_affine_bwd_seg")
         else:
             _check(lib.pn2_group_affine_bwd(_p(dZ), dZ.shape[1], _p(y), y.shape[1], _p(coef), _p(g_xyz), _p(g_new),
                                             _p(g_idx), B, N, S, K, co, _p(G), ldc, dW.data_ptr() + 4 * x_col, ldw, st),

@@ -505,8 +505,7 @@ def test_consumer_side_batchnorm_matches_standalone_launches(dev, kind, direct, 
     n_bn = sum(1 for k in ba if k.endswith("num_batches_tracked"))
     assert na.count("pn2_bn_finalize") == 2 * n_bn and na.count("pn2_bn_bwd_coef") == 2 * n_bn
     assert nb.count("pn2_bn_finalize") == 0
-    # what is left of pn2_bn_bwd_coef: the factorised first layers (their scatter kernel is not a lazy consumer yet)
-    assert nb.count("pn2_bn_bwd_coef") <= 2 * (2 if kind == "msg" else 3), nb.count("pn2_bn_bwd_coef")
+    assert nb.count("pn2_bn_bwd_coef") == 0           # every first consumer of a coefficient block fills it itself
     assert np.allclose(la, lb, rtol=0, atol=2e-5), (la, lb)
     assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
     assert float((ga - gb).abs().max()) <= 2e-2 * float(ga.abs().max())

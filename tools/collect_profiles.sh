@@ -1,40 +1,78 @@
-# Collect the judged evidence of a state of the tree on the GPU box:  bash tools/collect_profiles.sh <tag>
+# Collect the judged evidence of a state of the tree on the GPU box:  bash tools/collect_profiles.sh <tag> [quick]
 # Writes gpurun_out/<tag>/*; copy what should be kept into profiles/ (rNN_<tag>_*).
+# Every rocprofv3 command puts python3 itself behind `--` (no wrapper hop: the profiler's preloaded library has already
+# initialised the GPU), and counters are collected in passes of their own (--pmc with --kernel-trace only).
 set -u
 TAG=${1:-vx}
+QUICK=${2:-}
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+CFG5_MSG="--workload msg --points 65536 --batch 8 --npoint-scale 16"
+CFG5_SSG="--workload ssg --points 65536 --batch 8"
+
+pmc() {   # pmc <name> <bench args...>: FETCH_SIZE / WRITE_SIZE passes of 3 + 2 eager steps -> $O/pmc_traffic_<name>.json
+  local name=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o t -- python3 bench.py "$@" --no-graph --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_${name}_$c.err
+  done
+  python3 tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) 5 > $O/pmc_traffic_$name.json
+  rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+}
+stats() { # stats <name> <env or empty> <bench args...>: rocprofv3 --kernel-trace --stats -> $O/prof_<name>_kernel_stats.csv
+  local name=$1; shift
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o t -- python3 $R/bench.py "$@" --no-cpu-baseline > /dev/null 2> $O/prof_$name.err )
+  f=$(find $O/prof_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $O/prof_${name}_kernel_stats.csv
+  rm -rf $O/prof_$name
+}
+
+# 1. counters first: the bench lines below then quote digest-matched traffic (bench.py reads profiles/r*_pmc_traffic_<key>.json)
+pmc msg
+pmc ssg --workload ssg
+pmc sa --workload sa
+pmc ssg_n65536 $CFG5_SSG
+pmc msg_n65536 $CFG5_MSG
+mkdir -p $R/profiles
+for k in msg ssg sa ssg_n65536 msg_n65536; do cp $O/pmc_traffic_$k.json $R/profiles/${TAG}_pmc_traffic_$k.json; done
+
+# 2. the bench lines (default command first: exactly what the driver runs)
 python3 bench.py > $O/bench_msg.json 2> $O/bench_msg.err
 python3 bench.py --workload ssg > $O/bench_ssg.json 2> $O/bench_ssg.err
 python3 bench.py --workload sa > $O/bench_sa.json 2> $O/bench_sa.err
-python3 bench.py --workload msg --points 65536 --batch 8 --npoint-scale 16 --steps 5 --warmup 2 > $O/cfg5_msg.json 2> $O/cfg5_msg.err
-python3 bench.py --workload ssg --points 65536 --batch 8 --steps 10 --warmup 3 > $O/cfg5_ssg.json 2> $O/cfg5_ssg.err
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_msg -o t -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $O/prof_msg.err
-PN2_MSG_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_msg_serial -o t -- python3 $R/bench.py --no-graph --no-cpu-baseline --no-roofline > /dev/null 2> $O/prof_msg_serial.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ssg -o t -- python3 $R/bench.py --workload ssg --no-cpu-baseline > /dev/null 2> $O/prof_ssg.err
-cd $R
-for d in prof_msg prof_msg_serial prof_ssg; do
-  f=$(find $O/$d -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv
-  rm -rf $O/$d
-done
-python3 tools/bench_kernels.py all > $O/kernel_microbench.txt 2>/dev/null
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o t -- python3 bench.py --no-graph --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_$c.err
-done
-python3 tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) 5 > $O/pmc_traffic_msg.json
-rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o t -- python3 bench.py --workload ssg --no-graph --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_ssg_$c.err
-done
-python3 tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) 5 > $O/pmc_traffic_ssg.json
-rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-python3 tools/bench_infer.py > $O/infer_single_cloud.jsonl 2> $O/infer.err
-python3 tools/bench_fps.py > $O/fps_probe.txt 2> $O/fps.err
+python3 bench.py $CFG5_MSG --steps 5 --warmup 2 > $O/cfg5_msg.json 2> $O/cfg5_msg.err
+python3 bench.py $CFG5_SSG --steps 10 --warmup 3 > $O/cfg5_ssg.json 2> $O/cfg5_ssg.err
 
-python3 tools/bench_ball.py > $O/ball_query_cfg5.txt 2> $O/ball.err
-python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/tests_gpu.txt
+# 3. rocprofv3 --kernel-trace --stats of the same commands (graph replay; serial launches; the stand-alone BatchNorm launches for A/B)
+stats msg
+PN2_MSG_STREAMS=0 stats msg_serial --no-graph --no-roofline
+stats ssg --workload ssg
+stats ssg_serial --workload ssg --no-graph --no-roofline
+PN2_LAZY_BN=0 stats ssg_serial_standalone_bn --workload ssg --no-graph --no-roofline
+PN2_LAZY_BN=0 PN2_MSG_STREAMS=0 stats msg_serial_standalone_bn --no-graph --no-roofline
+stats sa --workload sa
+stats cfg5_ssg $CFG5_SSG --steps 10 --warmup 3
+stats cfg5_msg $CFG5_MSG --steps 5 --warmup 2
+
+# 4. A/B lines of the round's switches (same box, back to back, twice)
+: > $O/ab_switches.txt
+for rep in 1 2; do
+  for v in "PN2_LAZY_BN=0" "PN2_LAZY_BN=1" "PN2_WIDE_POOL=0" "PN2_WIDE_POOL=1"; do
+    for w in msg ssg; do
+      env $v python3 bench.py --workload $w --no-cpu-baseline --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], d['ms_per_step'])" $v $w >> $O/ab_switches.txt
+    done
+  done
+done
+
+tools/exp/mfma_peak > $O/mfma_peak.txt 2>&1
+if [ -z "$QUICK" ]; then
+  python3 tools/bench_kernels.py all > $O/kernel_microbench.txt 2>/dev/null
+  python3 tools/bench_infer.py > $O/infer_single_cloud.jsonl 2> $O/infer.err
+  python3 tools/bench_fps.py > $O/fps_probe.txt 2> $O/fps.err
+  python3 tools/bench_ball.py > $O/ball_query_cfg5.txt 2> $O/ball.err
+  python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/tests_gpu.txt
+  cp gpurun_out/parity_stages.json $O/parity_stages.json 2>/dev/null
+  cp gpurun_out/parity_fullsize.json $O/parity_fullsize.json 2>/dev/null
+fi
 ls -la $O
