@@ -436,6 +436,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-launch table of the instrumented pass on stderr")
     ap.add_argument("--no-comm-stream", action="store_true", help="issue the gradient all-reduce on the step's own stream")
+    ap.add_argument("--no-two-bucket", action="store_true",
+                    help="one all-reduce of the whole bucket behind the step instead of early (under sa1's backward) + late")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute each batch's FPS/ball-query/3-NN inside its own step instead of one step ahead")
@@ -518,6 +520,14 @@ def main():
         comm_ok = parallel.verify_comm_stream(bucket)
         if comm_ok:
             bucket.use_comm_stream()         # the all-reduce on its own stream, under the next replay's geometry branch
+    two_bucket, two_detail = False, None
+    if bucket.comm is not None and not args.no_two_bucket and args.workload in ("msg", "ssg") and not args.no_graph:
+        # early bucket (everything but sa1) all-reduced UNDER sa1's backward, behind an event recorded inside the graph; the
+        # mechanism is checked on this device first (a wait that binds to an older record would reduce unfinished gradients)
+        two_bucket, two_detail = parallel.verify_in_graph_record(dev)
+        if two_bucket:
+            bucket.use_two_buckets(list(net.sa1.parameters()))
+            bucket.arm(net.sa1)
     compute = make_step(args.workload, net, pts, labels, bucket)     # zero grads + forward + loss + backward
     if not args.no_graph:
         from pointnet12_amd.graph import GraphedStep
@@ -659,10 +669,15 @@ def main():
             "config": {"workload": WORKLOADS[args.workload], "clouds_per_gpu": batch, "points_per_cloud": n_points,
                        "channels": 9, "global_batch": batch * world, "parallelism": "dp%d" % world,
                        "allreduce_stream": "comm" if bucket.comm is not None else "step",
-                       "allreduce": "one flat fp32 bucket, RCCL AVG, issued behind the graph replay" +
-                                    (" on a comm stream (verified against the step-stream result on this process group)"
-                                     if bucket.comm is not None else " on the step's stream"),
+                       "allreduce": ("two buckets, RCCL AVG on a comm stream: everything but sa1 behind an event recorded inside the "
+                                     "graph where those gradients are final (under sa1's backward), sa1's behind the step" if two_bucket
+                                     else "one flat fp32 bucket, RCCL AVG, issued behind the graph replay" +
+                                     (" on a comm stream (verified against the step-stream result on this process group)"
+                                      if bucket.comm is not None else " on the step's stream")),
                        "comm_stream_verified": comm_ok,
+                       "two_bucket": ({"late_bytes": 4 * bucket.n_late, "early_bytes": bucket.nbytes - 4 * bucket.n_late,
+                                       "in_graph_record_verified": two_detail} if two_bucket else
+                                      {"off": True, "in_graph_record_check": two_detail}),
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
                        "geometry": "in-step" if (args.no_graph or args.no_prefetch)
                        else "next batch's FPS/ball-query/3-NN prefetched on a side stream inside the same graph",

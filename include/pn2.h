@@ -303,6 +303,17 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
 
+/* pn2_conv1x1_dgrad followed by pn2_conv1x1_wgrad of ONE layer (same dZ / pooled pair, Y, coef; X = the layer's input, i.e.
+ * prev_Y wherever there is a previous layer, with x_affine = prev_affine) as one call: on the few-row and mid-size layers
+ * (sa3 / sa4 / FP stacks, P up to 64 k rows) both kernel bodies share ONE launch -- the first workgroups of the grid compute
+ * dX, the rest dW -- so neither leaves half of the chip idle and the chain is one launch shorter; elsewhere the two
+ * launches are issued one after the other.  Results are those of the two separate calls. */
+int pn2_conv1x1_bwd_pair(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y,
+                         int ldy, const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev,
+                         const float *prev_affine, float *dXout, int ldxo, double *prev_red, const float *X, int ldx,
+                         const float *x_affine, float *dW, int lddw, int64_t P, int C_out, int C_in,
+                         const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
+
 /* Fused backward of one layer for the narrow, long layers (csrc/mlp_res.hip): dgrad AND wgrad in ONE pass over dZ / Y /
  * prev_Y -- autograd of model/pointnet_util.py:197,254,312 for conv + BatchNorm + ReLU.  dY is formed once per row
  * (as in pn2_conv1x1_dgrad), dXout = (dY W) masked by the previous layer's ReLU with its two BatchNorm-backward

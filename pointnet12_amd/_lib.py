@@ -47,6 +47,8 @@ SIGNATURES = {
                                _i64, _i, _i, _vp, _vp, _vp]),
     "pn2_conv1x1_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
                                _i64, _i, _i, _vp, _vp]),
+    "pn2_conv1x1_bwd_pair": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
+                                  _i64, _i, _i, _vp, _vp]),
     "pn2_res_supported": (_i, [_i64, _i, _i]),
     "pn2_bwd_res_supported": (_i, [_i64, _i, _i, _i, _i]),
     "pn2_conv1x1_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,

@@ -177,6 +177,10 @@ struct NtLds {
                                                       : (kStage > kReduce ? kStage : kReduce);
 };
 
+// Block coordinates as the kernel BODIES see them: the real blockIdx / gridDim for a plain launch, a slice of a one-dimensional
+// grid when two bodies share one launch (bwd_pair_kernel below).
+struct Bid3 { int x, y, z, gx, gy, gz; };
+
 // ACCS: independent partial accumulators per 32x32 output tile.  The four MFMAs that consume one ds_read_b128 (k-lanes x, y, z,
 // w) and the next k block's all accumulate into the SAME tile: one dependent chain per tile, and a dependent
 // v_mfma_f32_32x32x2_f32 issues only every ~130 cycles (64 when independent).  Kernels whose waves hold one or two tiles and run
@@ -184,7 +188,7 @@ struct NtLds {
 // 33 us whether the k-steps were 32 or 64 deep, one or three in flight).  ACCS = 4 gives every k-lane its own accumulator; the
 // partials are summed once per tile (48 v_add per tile and wave).
 template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi, int ACCS = 1, bool ROT = false>
-__global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, int n_lo) {
+__device__ __forceinline__ void gemm_nt_body(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, int n_lo, const Bid3 bid) {
     constexpr int KS = 4 / (WR * WC);                // waves sharing one wave tile: they split every k-step between them
     static_assert(WR * WC * KS == 4 && (KS == 1 || KS == 2), "four waves");
     static_assert((BK / 8) % KS == 0, "k-step must split evenly over the K-sharing waves");
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     const int kh = wave / (WR * WC);                 // which share of the k-step this wave multiplies (KS == 1: 0)
     const int wr = (wave % (WR * WC)) / WC, wc = wave % WC;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int n0 = n_lo + blockIdx.y * BN;           // n_lo > 0: this launch covers the output columns from n_lo on
+    const int n0 = n_lo + bid.y * BN;           // n_lo > 0: this launch covers the output columns from n_lo on
     const int64_t tiles_m = (P + BM - 1) / BM;
     aload.prologue();                                 // consumer-side BatchNorm: fill the block this loader reads (bn_tail.h)
     if (ALoad::kTab > 0) {                            // per-channel loader constants: global -> LDS once
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
     // launched together, the workgroups of a few-row product otherwise read the SAME column block of X and W at the same
     // time, whose cache lines -- one per row, a row pitch apart -- sit on very few L2 channels when the pitch is a multiple
     // of a few KB (K = 512, 1536, ...).
-    const int krot = ROT ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)nk) : 0;
+    const int krot = ROT ? (int)((bid.x * 7u + bid.y * 3u) % (unsigned)nk) : 0;
     auto kmap = [&](int ks_) { const int v = ks_ + krot; return ROT ? (v >= nk ? v - nk : v) : ks_; };
     const int lrow = t / TPR, lkq = (t % TPR) * 4;    // loader coordinates
     const int brow = t / TPRB, bcq = (t % TPRB) * 4;  // B loader coordinates (row of the LDS layout, first of 4 columns)
@@ -271,12 +275,12 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
         }
     };
 
-    int64_t tile = blockIdx.x, ptile = blockIdx.x;   // current step and prefetch cursor over (tile, ks)
+    int64_t tile = bid.x, ptile = bid.x;   // current step and prefetch cursor over (tile, ks)
     int ks = 0, pks = 0;
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
         fetch(ra[d], rb[d], ptile, pks);             // beyond the last tile every lane is predicated off (m >= P)
-        if (++pks == nk) { pks = 0; ptile += gridDim.x; }
+        if (++pks == nk) { pks = 0; ptile += bid.gx; }
     }
     // The first k-step of a tile takes its operands from `fa` / `fb`: already transformed, in registers.  They are
     // produced BEFORE the previous tile's epilogue issues its global stores (gfx9 has one vmcnt for loads and stores
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
                         *reinterpret_cast<float4 *>(&Bb[(brow + i * RPLB) * LDBS + bcq]) = rb[d][i];
             }
             fetch(ra[d], rb[d], ptile, pks);
-            if (++pks == nk) { pks = 0; ptile += gridDim.x; }
+            if (++pks == nk) { pks = 0; ptile += bid.gx; }
             STAMP(0)
             __syncthreads();
             STAMP(1)
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             }
 
             // ---- epilogue: accumulators -> LDS image [BM][LDC] (aliases the operand buffers) -> rows
-            if (PF) prefinish(tile + gridDim.x);           // next tile's first operands: consumed before any store goes out
+            if (PF) prefinish(tile + bid.gx);           // next tile's first operands: consumed before any store goes out
             constexpr int EP_IT = (BM + RPP - 1) / RPP;
             typename Epi::Pre pre[EP_IT];
             const bool ecol = en < ((N + 3) & ~3) && erow < RPP;    // (NTHREADS % CG) threads have no row when BN = 96
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             STAMP(6)
             __syncthreads();                               // image consumed before the next tile's operands land
             STAMP(7)
-            tile += gridDim.x;
+            tile += bid.gx;
         }
     }
     STAMP_FLUSH
@@ -471,9 +475,36 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BM
             }
             if (n0 + t < N) epi.flush(n0 + t, N, a0, a1);
         }
-        if (epi.ticket() != nullptr && tail_is_last_block(epi.ticket(), gridDim.x * gridDim.y)) epi.tail(N);
+        if (epi.ticket() != nullptr && tail_is_last_block(epi.ticket(), bid.gx * bid.gy)) epi.tail(N);
     }
 }
+
+template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, class ALoad, class Epi, int ACCS = 1, bool ROT = false>
+__global__ __launch_bounds__(NTHREADS, MINB) void gemm_nt_kernel(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, int n_lo) {
+    gemm_nt_body<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi, ACCS, ROT>(aload, bm, P, K4, N, epi, n_lo,
+                                                                                  Bid3{(int)blockIdx.x, (int)blockIdx.y, 0, (int)gridDim.x, (int)gridDim.y, 1});
+}
+
+// ----------------------------------------------------------------------------- dgrad + wgrad of one layer in ONE launch
+// The few-row and mid-size layers (sa3 / sa4 / FP stacks: P = 1 k .. 64 k rows) run their data gradient and their weight
+// gradient as two dependent-looking launches that do not depend on each other, each a ~25 us kernel that leaves half of the chip
+// idle (64 .. 256 workgroups of one wave per SIMD).  Forking the weight gradient onto a side stream costs the graph executor
+// more than the overlap returns (measured twice: SSG 2.75 -> 2.89 ms).  Here the two kernel BODIES share one launch instead:
+// the first blocks of a one-dimensional grid run the NT body (dX), the rest the TN body (dW) -- no fork, no join, one launch
+// less on the chain, and the chip is filled by both.  pn2_conv1x1_bwd_pair posts the weight-gradient half as a pending job;
+// the dgrad dispatch picks it up in the one leaf that has a pair instantiation (64 x 128 x 16 tiles) and reports back.
+struct PairJob {
+    bool active, taken;
+    const float *X; int ldx; const float *x_aff;
+    float *dW; int lddw; int M, N;
+};
+static thread_local PairJob g_pair_job = {false, false, nullptr, 0, nullptr, nullptr, 0, 0, 0};
+
+template <int BM, int BN, int BK, int WR, int WC, bool VEC, class ALoad, class Epi>
+bool launch_bwd_pair(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, unsigned nt_gx, unsigned nt_gy, int *rc);
+
+template <class A, class B> struct pn2_same { static constexpr bool v = false; };
+template <class A> struct pn2_same<A, A> { static constexpr bool v = true; };
 
 template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, int ACCS = 1, bool ROT = false, class ALoad, class Epi>
 int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, int n_lo = 0, int n_hi = 0) {
@@ -482,6 +513,17 @@ int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream
     int64_t cap = (int64_t)pn2_num_cus() * MINB / tiles_n;  // MINB resident workgroups per CU in total
     if (cap < 1) cap = 1;
     unsigned gx = (unsigned)(tiles_m < cap ? tiles_m : cap);
+    if constexpr (BNN && VEC && BM == 64 && BN == 128 && BK == 16 && WR == 2 && WC == 2 && DEPTH == 1 && ACCS == 1 && !ROT &&
+                  (pn2_same<ALoad, LoadDyDense>::v || pn2_same<ALoad, LoadDyPooled>::v) &&
+                  (pn2_same<Epi, EpiDgradMask>::v || pn2_same<Epi, EpiStore>::v)) {
+        if (g_pair_job.active && !g_pair_job.taken && n_lo == 0 && n_hi == 0) {
+            int rc = PN2_OK;
+            if (launch_bwd_pair<BM, BN, BK, WR, WC, VEC>(aload, bm, P, K4, N, epi, s, gx, tiles_n, &rc)) {
+                g_pair_job.taken = true;
+                return rc;
+            }
+        }
+    }
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi, ACCS, ROT>), dim3(gx, tiles_n), dim3(NTHREADS),
                        (size_t)ALoad::kTab * K4 * sizeof(float), s, aload, bm, P, K4, N, epi, n_lo);
     return pn2_launch_status();
@@ -832,9 +874,9 @@ int dispatch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStre
 // CU: with a single stage in flight that chain runs at global-load latency, see dispatch_nt_vec).
 // ACCS: independent partial accumulators per tile (consecutive position pairs rotate over them), see gemm_nt_kernel.
 template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad, int KS = 1, int TD = 1, int ACCS = 1>
-__global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk,
+__device__ __forceinline__ void gemm_tn_body(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk,
                                                               int M, int N, float *__restrict__ dW, int lddw,
-                                                              float *__restrict__ dbias) {
+                                                              float *__restrict__ dbias, const Bid3 bid) {
     constexpr int WTM = BM / WR, WTN = BN / WC;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_IT = WG_BP * (BM / 4) / NTHREADS, B_IT = WG_BP * (BN / 4) / NTHREADS;
@@ -848,9 +890,9 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
     const int ks = wave / (WR * WC), wt = wave % (WR * WC);
     const int wr = wt / WC, wc = wt % WC;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bid.x * BM, n0 = bid.y * BN;
     dyload.prologue();                                // consumer-side BatchNorm backward (a layer without a data gradient)
-    const int64_t p_begin = (int64_t)blockIdx.z * chunk;
+    const int64_t p_begin = (int64_t)bid.z * chunk;
     const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
     const int arow = t / (BM / 4), acq = (t % (BM / 4)) * 4;      // loader coordinates (fixed per thread)
     const int brow = t / (BN / 4), bcq = (t % (BN / 4)) * 4;
@@ -976,7 +1018,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
             }
         }
 tn_bias:
-    if (dbias != nullptr && blockIdx.y == 0) {      // combine the AR row-threads of each column group in LDS: one atomic per channel
+    if (dbias != nullptr && bid.y == 0) {      // combine the AR row-threads of each column group in LDS: one atomic per channel
         __syncthreads();
         float *sh = As[0];
         *reinterpret_cast<float4 *>(&sh[t * 4]) = bsum;
@@ -993,6 +1035,14 @@ tn_bias:
             if (m0 + acq + 3 < M) atomicAdd(dbias + m0 + acq + 3, tot.w);
         }
     }
+}
+
+template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, class DyLoad, class XLoad, int KS = 1, int TD = 1, int ACCS = 1>
+__global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, XLoad xload, int64_t P, int64_t chunk,
+                                                              int M, int N, float *__restrict__ dW, int lddw,
+                                                              float *__restrict__ dbias) {
+    gemm_tn_body<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad, KS, TD, ACCS>(dyload, xload, P, chunk, M, N, dW, lddw, dbias,
+                                                                           Bid3{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z});
 }
 
 // Weight gradient of a FIRST layer, dW[M, N <= 16] += sum_p dY[p, m] * X[p, n] (X = the grouped input rows, 3+D = 9..12
@@ -1116,6 +1166,53 @@ int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, in
     hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad, KS, TD, ACCS>), dim3(tm, tn, (unsigned)split), dim3(NTHREADS), 0, s,
                        dyload, xload, P, chunk, M, N, dW, lddw, dbias);
     return pn2_launch_status();
+}
+
+template <int BM, int BN, int BK, int WR, int WC, bool VEC, class ALoad, class Epi, class XLoad>
+__global__ __launch_bounds__(NTHREADS, 2) void bwd_pair_kernel(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, int nt_gx, int nt_gy,
+                                                              XLoad xload, int64_t chunk, int tn_M, int tn_N, float *__restrict__ dW,
+                                                              int lddw, int tn_gx, int tn_gy, int tn_gz) {
+    const int b = (int)blockIdx.x, nt_blocks = nt_gx * nt_gy;
+    if (b < nt_blocks) {                                   // (workgroup-uniform: the two bodies never meet)
+        gemm_nt_body<BM, BN, BK, WR, WC, 2, 1, true, VEC, ALoad, Epi, 1, false>(aload, bm, P, K4, N, epi, 0,
+                                                                              Bid3{b % nt_gx, b / nt_gx, 0, nt_gx, nt_gy, 1});
+    } else {
+        const int c = b - nt_blocks;
+        gemm_tn_body<64, 64, 32, 2, 2, 2, ALoad, XLoad, 1, 2, 4>(aload, xload, P, chunk, tn_M, tn_N, dW, lddw, nullptr,
+                                                                 Bid3{c % tn_gx, (c / tn_gx) % tn_gy, c / (tn_gx * tn_gy), tn_gx, tn_gy, tn_gz});
+    }
+}
+
+template <int BM, int BN, int BK, int WR, int WC, bool VEC, class ALoad, class Epi>
+bool launch_bwd_pair(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, unsigned nt_gx, unsigned nt_gy, int *rc) {
+    const PairJob &j = g_pair_job;
+    constexpr bool masked = pn2_same<Epi, EpiDgradMask>::v;
+    if (masked != (j.x_aff != nullptr)) return false;      // the weight gradient's X loader follows the data gradient's epilogue
+    // the split over P of launch_tn<64, 64, 32, 2, 2, 2, 1, 2, 4> (the few-row weight-gradient configuration)
+    constexpr int WG_BP = 32;
+    const unsigned tm = (unsigned)pn2_cdiv(j.M, 64), tn = (unsigned)pn2_cdiv(j.N, 64);
+    static const int splitdiv = pn2_env_int("PN2_TN_SPLITDIV", 1);
+    int64_t want = (int64_t)pn2_num_cus() * 2 / ((int64_t)tm * tn) / splitdiv;
+    if (want < 1) want = 1;
+    const int64_t max_split = pn2_cdiv(P, 8 * WG_BP);
+    int64_t split = want < max_split ? want : max_split;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    const int64_t chunk = pn2_cdiv(pn2_cdiv(P, split), WG_BP) * WG_BP;
+    split = pn2_cdiv(P, chunk);
+    const unsigned total = nt_gx * nt_gy + tm * tn * (unsigned)split;
+    const size_t dyn = (size_t)ALoad::kTab * K4 * sizeof(float);
+    if constexpr (masked) {
+        const LoadBnReluFixed xl{j.X, j.ldx, j.x_aff, zero_page_dev()};
+        hipLaunchKernelGGL((bwd_pair_kernel<BM, BN, BK, WR, WC, VEC, ALoad, Epi, LoadBnReluFixed>), dim3(total), dim3(NTHREADS), dyn, s, aload, bm, P,
+                           K4, N, epi, (int)nt_gx, (int)nt_gy, xl, chunk, j.M, j.N, j.dW, j.lddw, (int)tm, (int)tn, (int)split);
+    } else {
+        const LoadPlain xl{j.X, j.ldx, zero_page_dev()};
+        hipLaunchKernelGGL((bwd_pair_kernel<BM, BN, BK, WR, WC, VEC, ALoad, Epi, LoadPlain>), dim3(total), dim3(NTHREADS), dyn, s, aload, bm, P, K4,
+                           N, epi, (int)nt_gx, (int)nt_gy, xl, chunk, j.M, j.N, j.dW, j.lddw, (int)tm, (int)tn, (int)split);
+    }
+    *rc = pn2_launch_status();
+    return true;
 }
 
 template <class DyLoad, class XLoad>
@@ -1661,6 +1758,26 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     LoadDyPooled dy{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev(), pow2_shift(Kpool), lc};
     if (x_affine) return dispatch_tn(dy, LoadBnReluFixed{X, ldx, x_affine, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
     return dispatch_tn(dy, LoadPlain{X, ldx, zero_page_dev()}, P, M, N, dW, lddw, dbias, s);
+}
+
+int pn2_conv1x1_bwd_pair(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
+                         const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev, const float *prev_affine,
+                         float *dXout, int ldxo, double *prev_red, const float *X, int ldx, const float *x_affine, float *dW, int lddw,
+                         int64_t P, int C_out, int C_in, const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream) {
+    PN2_CHECK_ARG(X && dW && C_out > 0 && C_in > 0 && ldx % 4 == 0 && ldx >= round4(C_in) && lddw >= C_in);
+    static const int on = pn2_env_int("PN2_BWD_PAIR", 1), small_p = pn2_env_int("PN2_TN_SMALLP", 65536);
+    static const int tn_cfg = pn2_env_int("PN2_TN_CFG", 0), tdepth = pn2_env_int("PN2_TN_SMALL_DEPTH", 2);
+    const int M = C_out, N = C_in;
+    // the weight-gradient half rides in the data gradient's launch only where dispatch_tn would take its few-row configuration
+    const bool tn_small = N > 32 && M > 32 && !(M <= 64 && N <= 64) && tn_cfg == 0 && tdepth == 2 &&
+                          (P <= small_p || (P <= 2 * (int64_t)small_p && (int64_t)M * N <= 16384));
+    g_pair_job = PairJob{on && tn_small, false, X, ldx, x_affine, dW, lddw, M, N};
+    const int rc = pn2_conv1x1_dgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, W, ldw, prev_Y, ld_prev, prev_affine, dXout, ldxo, prev_red, P,
+                                     C_out, C_in, nullptr, coef_lazy, stream);
+    const bool taken = g_pair_job.taken;
+    g_pair_job.active = false;
+    if (rc != PN2_OK || taken) return rc;
+    return pn2_conv1x1_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, nullptr, P, C_out, C_in, nullptr, stream);
 }
 
 }  // extern "C"

@@ -13,7 +13,10 @@
 //     barrier interval costs 1 000 - 1 500 cycles of matrix-pipe idle when both waves of a SIMD stage at the same time, so the
 //     staging of chunk c + 1 is spread between the MFMA groups of chunk c and the intervals are long);
 //   * LDS holds nothing but two activation chunks: 70 KB, whatever K and N are.
-// The chip holds ~2.0 GHz under this load (GRBM_GUI_ACTIVE / 8 / time), i.e. ~131 TF is the ceiling these kernels see.
+// Ceiling: 157.3 TF.  (Round 3 read ~2.0 GHz from GRBM_GUI_ACTIVE / 8 / time under these kernels and called 131 TF the
+// practical ceiling; round 4's barrier-free pure-MFMA loop on the same pool holds 2.39 GHz and delivers 154.6 TF with or without
+// a workgroup barrier every 64 MFMAs -- tools/exp/mfma_peak.hip, profiles/r04_mfma_peak.txt -- so whatever clock these kernels
+// hold is a property of their own mix of LDS, memory and matrix work, not a ceiling.)
 //
 // Whole BM-row tiles only; the entry points of mlp.hip hand a ragged tail to the streamed kernels.
 #include "mlp_loaders.h"

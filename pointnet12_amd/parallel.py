@@ -57,7 +57,15 @@ class _ExternalEvent:
             raise RuntimeError("%s failed with HIP error %d" % (what, rc))
 
     def record(self, stream):
-        self._check(self._hip.hipEventRecord(self._ev, self._ct.c_void_p(stream.cuda_stream)), "hipEventRecord")
+        """Record on ``stream``.  Under stream capture this becomes an EXTERNAL event-record node of the graph
+        (``hipEventRecordWithFlags(..., hipEventRecordExternal)``): every replay records the event where the node sits, and a
+        stream outside the graph can wait for that point of the replay with an ordinary ``hipStreamWaitEvent``."""
+        if torch.cuda.is_current_stream_capturing():
+            if not hasattr(self._hip, "hipEventRecordWithFlags"):
+                raise RuntimeError("this HIP runtime has no hipEventRecordWithFlags: no in-graph event records")
+            self._check(self._hip.hipEventRecordWithFlags(self._ev, self._ct.c_void_p(stream.cuda_stream), 1), "hipEventRecordWithFlags")
+        else:
+            self._check(self._hip.hipEventRecord(self._ev, self._ct.c_void_p(stream.cuda_stream)), "hipEventRecord")
 
     def wait(self, stream):
         external = 1 if torch.cuda.is_current_stream_capturing() else 0          # hipEventWaitExternal
@@ -98,6 +106,8 @@ class FlatGradBucket:
             pointnet_util.set_direct_grad_accumulation(True)
         self.comm = None          # dedicated stream of the collective (use_comm_stream)
         self.reduced = None       # event: the last all-reduce has finished
+        self.n_late = 0           # two-bucket protocol: flat[:n_late] = the gradients the backward produces LAST
+        self.early_ready = None   # event recorded inside the step where flat[n_late:] is final
 
     def use_comm_stream(self):
         """Issue the all-reduce on a stream of its own.  The step that follows only has to wait where it first touches the
@@ -109,6 +119,49 @@ class FlatGradBucket:
             self.reduced = _ExternalEvent(self.flat.device)
             self.reduced.record(self.comm)
         return self
+
+    def use_two_buckets(self, late_params):
+        """Two-bucket protocol (VERDICT r3 #7b): the gradients of ``late_params`` -- the stage the backward reaches last, sa1 --
+        form a small LATE bucket, everything else the EARLY bucket.  The step calls ``mark_early_ready()`` where the early
+        gradients are final (a tensor hook on sa1's output: autograd has accumulated its gradient, i.e. every later stage's
+        backward has been issued); the early all-reduce then runs on the comm stream UNDER sa1's backward, and only the late
+        bucket (a few hundred KB) is reduced behind the step.  ``late_params`` must be a prefix of the bucket (the first stage of
+        the network is: parameters are laid out in ``module.parameters()`` order).  Needs the comm stream on the GPU; on CPU
+        (gloo tests) the two collectives simply run one after the other -- the arithmetic is what is checked there."""
+        late = {id(p) for p in late_params if p.requires_grad}
+        k = 0
+        while k < len(self.params) and id(self.params[k]) in late:
+            k += 1
+        if k == 0 or k != len(late):
+            raise ValueError("late_params must be a non-empty PREFIX of the bucket's parameters")
+        n = sum(p.numel() for p in self.params[:k])
+        if n >= self.flat.numel():
+            raise ValueError("nothing left for the early bucket")
+        self.n_late = n
+        if self.flat.is_cuda:
+            if self.comm is None:
+                self.use_comm_stream()
+            self.early_ready = _ExternalEvent(self.flat.device)
+            self.early_ready.record(self.comm)
+        return self
+
+    def mark_early_ready(self):
+        """Called by the step where every gradient outside the late bucket is final (no-op without the two-bucket protocol)."""
+        if self.early_ready is not None:
+            self.early_ready.record(torch.cuda.current_stream(self.flat.device))
+
+    def arm(self, first_stage):
+        """Wire ``mark_early_ready`` into a network: a forward hook on its first stage (``net.sa1``) puts a tensor hook on the
+        stage's feature output; autograd runs it when that tensor's gradient is complete, right before the stage's own
+        backward.  Returns the hook handle."""
+        def fwd_hook(_mod, _inp, out):
+            feat = out[-1] if isinstance(out, tuple) else out
+            if feat.requires_grad and self.n_late:
+                def on_grad(g):
+                    self.mark_early_ready()
+                    return g
+                feat.register_hook(on_grad)
+        return first_stage.register_forward_hook(fwd_hook)
 
     def wait_reduced(self):
         """The calling stream waits for the last all-reduce (no-op without a comm stream)."""
@@ -143,16 +196,41 @@ class FlatGradBucket:
         return marks
 
     def _all_reduce(self, group, marks=None):
+        def reduce_(t):
+            if dist.get_backend(group) == "gloo":          # gloo has no AVG
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                t.div_(dist.get_world_size(group))
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+
         def collective():
             if marks:
                 marks[0].record()
-            if dist.get_backend(group) == "gloo":          # gloo has no AVG
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-                self.flat.div_(dist.get_world_size(group))
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+            reduce_(self.flat)
             if marks:
                 marks[1].record()
+        if self.n_late:                                    # two buckets: early under the tail of the backward, late behind the step
+            early, late = self.flat[self.n_late:], self.flat[:self.n_late]
+            if self.comm is None:                          # (CPU / no comm stream: same arithmetic, no overlap)
+                if marks:
+                    marks[0].record()
+                reduce_(early)
+                reduce_(late)
+                if marks:
+                    marks[1].record()
+                return
+            self.early_ready.wait(self.comm)               # the point INSIDE the step where the early gradients are final
+            with torch.cuda.stream(self.comm):
+                if marks:
+                    marks[0].record()
+                reduce_(early)
+            self.comm.wait_stream(torch.cuda.current_stream(self.flat.device))     # the whole step: sa1's gradients
+            with torch.cuda.stream(self.comm):
+                reduce_(late)
+                if marks:
+                    marks[1].record()
+                self.reduced.record(self.comm)
+            return
         if self.comm is None:
             collective()
             return
@@ -194,6 +272,45 @@ def verify_comm_stream(bucket, group=None):
     verdict = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
     dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
     return bool(verdict.item())
+
+
+def verify_in_graph_record(device, replays=3, spin_cycles=40_000_000):
+    """Does an event recorded INSIDE a captured graph (external record node) order a stream OUTSIDE of it, replay after replay?
+    The two-bucket protocol rests on exactly that: graph = [clear flags, spin, flag0 = 1, RECORD, spin, flag1 = 1]; after every
+    launch a second stream waits for the event and snapshots the flags.  Correct: the snapshot sees flag0 = 1 in EVERY replay
+    (it waited for this replay's record, not for an older one), and flag1 = 0 at least once (it did not wait for the whole
+    graph).  Returns (ok, detail)."""
+    dev = torch.device(device)
+    try:
+        ev = _ExternalEvent(dev)
+        side = torch.cuda.Stream(device=dev)
+        work = torch.cuda.Stream(device=dev)
+        flags = torch.zeros(2, device=dev)
+        ev.record(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(work):
+            with torch.cuda.graph(graph, stream=work):
+                flags.zero_()
+                torch.cuda._sleep(spin_cycles)
+                flags[0:1].fill_(1.0)
+                ev.record(torch.cuda.current_stream(dev))
+                torch.cuda._sleep(spin_cycles)
+                flags[1:2].fill_(1.0)
+        torch.cuda.synchronize(dev)
+        seen = []
+        for _ in range(replays):
+            with torch.cuda.stream(work):
+                graph.replay()
+            ev.wait(side)
+            with torch.cuda.stream(side):
+                snap = flags.clone()
+            torch.cuda.synchronize(dev)
+            seen.append((float(snap[0]), float(snap[1])))
+        ok = all(a == 1.0 for a, _ in seen) and any(b == 0.0 for _, b in seen)
+        return ok, seen
+    except Exception as e:                    # (no hipEventRecordWithFlags, capture refused ...)
+        return False, repr(e)
 
 
 def broadcast_module(module, src=0, group=None):

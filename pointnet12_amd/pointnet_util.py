@@ -505,6 +505,8 @@ FUSED_BN_TAILS = os.environ.get("PN2_FUSED_BN_TAILS", "0") == "1"
 # of pn2_bn_finalize / pn2_bn_bwd_coef launches of their own -- 50 hops of ~5 us on the dependency chain of an MSG-SemSeg step, 44
 # of SSG's.  Same fp64 arithmetic per channel: bit-identical blocks.  0: the stand-alone launches (A/B runs).
 LAZY_BN = os.environ.get("PN2_LAZY_BN", "1") == "1"
+# dgrad + wgrad of a layer as one call / one launch on the few-row and mid-size layers (pn2_conv1x1_bwd_pair); 0: A/B runs
+BWD_PAIR = os.environ.get("PN2_BWD_PAIR_CALL", "1") == "1"
 # the last layer of a pooled MLP records the per-group extrema in its GEMM epilogue (pn2_conv1x1_fwd_pool); 0: A/B runs
 POOL_IN_EPILOGUE = os.environ.get("PN2_POOL_EPILOGUE", "1") == "1"
 # narrow first layers: gather + first conv in one launch (pn2_group_conv_fwd); 0: pn2_group then the GEMM (A/B runs)
@@ -849,6 +851,15 @@ class _SharedMLP(torch.autograd.Function):
                     else (None, 0, None, 0)
                 c_y = y.data_ptr() + 4 * r0 * ldy
                 c_x = x.data_ptr() + 4 * r0 * ldx
+                if need_dx and BWD_PAIR and training and chunk == P and side is None and not FUSED_BN_TAILS:
+                    # data gradient and weight gradient of this layer as ONE call: on the few-row / mid-size layers both kernel
+                    # bodies share one launch (pn2_conv1x1_bwd_pair); elsewhere the library issues the two launches itself
+                    prev = (c_x, ldx, _p(x_aff), dx.data_ptr(), dx.shape[1], _p(red[offs[l - 1]:offs[l]])) if l > 0 else \
+                        (None, 0, None, dx.data_ptr(), ldx, None)
+                    _check(lib.pn2_conv1x1_bwd_pair(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, w_ld, *prev, c_x, ldx, _p(x_aff), _p(dW), ci,
+                                                    rn, co, ci, coef_lazy, st), "pn2_conv1x1_bwd_pair")
+                    coef_lazy = None
+                    continue
                 if need_dx:
                     c_dx = dx.data_ptr() + 4 * r0 * dx.shape[1]
                     if l > 0:

@@ -204,6 +204,50 @@ def test_plain_conv1x1_bias_and_weight_gradients(dev, P, ci, co):
         assert float((a - r).abs().max()) <= tol, (name, float((a - r).abs().max()), tol)
 
 
+@pytest.mark.parametrize("P,pool,chans", [(2048, 128, [256, 256, 512, 1024]), (8192, 0, [576, 256, 128]), (16384, 0, [320, 256, 128]),
+                                          (4096, 32, [259, 256, 256, 512]), (65536, 0, [128, 128, 128])])
+def test_dgrad_and_wgrad_in_one_launch_equal_the_two_launches(dev, P, pool, chans, monkeypatch):
+    """pn2_conv1x1_bwd_pair (round 4): data gradient and weight gradient of a few-row / mid-size layer as ONE call -- one launch
+    whose first workgroups run the NT body and the rest the TN body -- against pn2_conv1x1_dgrad followed by
+    pn2_conv1x1_wgrad: the same two kernel bodies on the same operands, so the same gradients up to the order of the fp32
+    weight-gradient atomics and the fp64 reduction atomics."""
+    gen = torch.Generator().manual_seed(P + pool)
+    c_in = chans[0]
+    ld = (c_in + 3) & ~3
+    rows = torch.zeros(P, ld)
+    rows[:, :c_in] = torch.randn(P, c_in, generator=gen) * 2 + 0.5
+    convs = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])])
+    bns = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]])
+    for bn in bns:
+        bn.weight.data.uniform_(0.5, 1.5, generator=gen)
+        bn.bias.data.uniform_(-0.5, 0.5, generator=gen)
+    convs.to(dev), bns.to(dev)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(U, "BWD_PAIR", flag)
+        for p in list(convs.parameters()) + list(bns.parameters()):
+            p.grad = None
+        for bn in bns:
+            bn.reset_running_stats()
+        x = rows.to(dev).requires_grad_(True)
+        with _lib.call_profile() as calls:
+            out = U.shared_mlp(x, c_in, convs, bns, pool, True)
+            gw = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+            (out * gw).sum().backward()
+            torch.cuda.synchronize()
+            names = [c[0] for c in calls]
+        res[flag] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())], names)
+    assert "pn2_conv1x1_bwd_pair" in res[True][3] and "pn2_conv1x1_bwd_pair" not in res[False][3]
+    assert res[False][3].count("pn2_conv1x1_wgrad") > res[True][3].count("pn2_conv1x1_wgrad")
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip([res[True][1]] + res[True][2], [res[False][1]] + res[False][2]):
+        scale = float(b.abs().max())
+        if scale == 0.0:
+            assert float(a.abs().max()) == 0.0
+            continue
+        assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+
+
 @pytest.mark.parametrize("P,pool,chans", [(65536, 16, [64, 96, 128]), (65536, 32, [32, 32, 64]), (131072, 64, [32, 64, 128]),
                                           (65536, 128, [64, 64, 96]), (32768 + 64, 64, [32, 64, 64]),
                                           # round 4: the register-stationary forward records the extrema too (sa2 of MSG-SemSeg:

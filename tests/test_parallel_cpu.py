@@ -68,6 +68,49 @@ def test_two_rank_bucket_matches_per_replica_mean():
     assert torch.allclose(flats[0], ref, rtol=1e-6, atol=1e-7)
 
 
+def _two_bucket_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    for two in (False, True):
+        model = _make_model()
+        bucket = parallel.FlatGradBucket(model)
+        if two:
+            bucket.use_two_buckets(list(model[0].parameters()))          # the first stage's parameters: the late bucket
+            assert bucket.n_late == 5 * 8 + 8 and bucket.early_ready is None   # host tensors: no event, no comm stream
+            h = bucket.arm(model[0])
+        x = torch.randn(4, 5, 16, generator=torch.Generator().manual_seed(100))
+        lo, hi = parallel.shard_range(4, rank, world)
+        bucket.zero()
+        model(x[lo:hi]).square().mean().backward()
+        bucket.all_reduce()
+        res.append(bucket.flat.clone())
+        if two:
+            h.remove()
+            try:
+                bucket.use_two_buckets(list(model[3].parameters()))      # not a prefix of the bucket
+                res.append("no error")
+            except ValueError:
+                pass
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_two_bucket_all_reduce_equals_one_bucket_over_two_gloo_ranks():
+    """The two-bucket protocol (early = everything but the first stage, late = the first stage) gives the one-bucket result bit
+    for bit -- the same elementwise reduction in two pieces -- on both ranks; a late set that is not a prefix is refused."""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_two_bucket_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    for r in range(world):
+        assert len(res[r]) == 2
+        assert torch.equal(res[r][0], res[r][1])
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_bucket_aliases_grads():
     model = _make_model()
     bucket = parallel.FlatGradBucket(model)

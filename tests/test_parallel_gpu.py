@@ -95,6 +95,69 @@ print("RCCL-COMM-STREAM-OK")
 """
 
 
+CHILD_TWO = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from pointnet12_amd import parallel, pointnet2 as M, synthetic as syn
+from pointnet12_amd.graph import GraphedStep
+from pointnet12_amd.loss import nll_loss
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+ok, seen = parallel.verify_in_graph_record(dev)
+assert ok, seen                                     # an event recorded inside a replayed graph orders an outside stream
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+pts, lab = syn.kitti_batch(0, 2, 1024)
+pts, lab = torch.from_numpy(pts).to(dev), torch.from_numpy(lab).to(dev)
+res = []
+for two in (False, True):
+    torch.manual_seed(0)
+    net = M.PointNet2SemSegMsg(13, 6).to(dev).train()
+    net.drop1.p = 0.0
+    bucket = parallel.FlatGradBucket(net, direct=True).use_comm_stream()
+    if two:
+        bucket.use_two_buckets(list(net.sa1.parameters()))
+        bucket.arm(net.sa1)
+        assert 0 < bucket.n_late < bucket.flat.numel() // 8
+
+    def step():
+        bucket.wait_reduced()
+        bucket.zero()
+        lp = net(pts)
+        loss = nll_loss(lp.reshape(-1, 13), lab.reshape(-1))
+        loss.backward()
+        return loss
+
+    torch.manual_seed(1)
+    graphed = GraphedStep(step, dev, warmup=2, geometry_fn=lambda: net.features(pts))
+    torch.manual_seed(7)
+    for it in range(4):                             # back to back, no host synchronisation between replay and collective
+        graphed()
+        assert bucket.all_reduce_timed() is not None
+    bucket.wait_reduced()
+    torch.cuda.synchronize()
+    res.append(bucket.flat.clone())
+a, b = res
+assert bool(torch.isfinite(b).all()) and float(b.abs().max()) > 0
+# one rank: AVG is the identity, so both protocols must hand back the step's own gradients (same seeds, same replays)
+assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()), float((a - b).abs().max()) / float(a.abs().max())
+assert abs(float(a.norm()) - float(b.norm())) <= 5e-3 * float(a.norm())
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL-TWO-BUCKET-OK")
+"""
+
+
+def test_one_rank_two_bucket_all_reduce_under_graph_replay(dev):
+    """The two-bucket protocol with one forced rank: the in-graph event record is checked first (parallel.verify_in_graph_record),
+    then four replayed MSG steps with the early all-reduce waiting for that event and the late one for the step must leave
+    the gradients of the one-bucket run (up to the atomics-order noise of two separate runs)."""
+    env = dict(os.environ, PN2_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29536",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", CHILD_TWO % ROOT], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0 and "RCCL-TWO-BUCKET-OK" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
 def test_one_rank_rccl_all_reduce_on_comm_stream_under_graph_replay(dev):
     """FlatGradBucket.use_comm_stream(): the collective on its own stream, the captured step waiting for it through an
     (external) event in front of bucket.zero() -- replayed back to back with no host synchronisation in between."""
