@@ -309,7 +309,13 @@ def verify_in_graph_record(device, replays=3, spin_cycles=40_000_000):
             seen.append((float(snap[0]), float(snap[1])))
         ok = all(a == 1.0 for a, _ in seen) and any(b == 0.0 for _, b in seen)
         return ok, seen
-    except Exception as e:                    # (no hipEventRecordWithFlags, capture refused ...)
+    except Exception as e:                    # (no hipEventRecordWithFlags, the record refused under capture ...)
+        try:
+            torch.cuda.synchronize(dev)
+            if _ExternalEvent._hip is not None:
+                _ExternalEvent._hip.hipGetLastError()      # the refused call must not surface as the NEXT launch's status
+        except Exception:
+            pass
         return False, repr(e)
 
 
