@@ -518,7 +518,13 @@ int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream
                   (pn2_same<Epi, EpiDgradMask>::v || pn2_same<Epi, EpiStore>::v)) {
         if (g_pair_job.active && !g_pair_job.taken && n_lo == 0 && n_hi == 0) {
             int rc = PN2_OK;
-            if (launch_bwd_pair<BM, BN, BK, WR, WC, VEC>(aload, bm, P, K4, N, epi, s, gx, tiles_n, &rc)) {
+            // both halves must be RESIDENT together (two workgroups of 70 KB fit a CU): one per CU for each body -- with the
+            // persistent NT grid at its usual three per CU its blocks, dispatched first, took every slot and the TN half ran
+            // behind them (first version: SSG 2.65 -> 2.60 ms only)
+            int64_t cap1 = (int64_t)pn2_num_cus() / tiles_n;
+            if (cap1 < 1) cap1 = 1;
+            const unsigned gx1 = (unsigned)(tiles_m < cap1 ? tiles_m : cap1);
+            if (launch_bwd_pair<BM, BN, BK, WR, WC, VEC>(aload, bm, P, K4, N, epi, s, gx1, tiles_n, &rc)) {
                 g_pair_job.taken = true;
                 return rc;
             }
@@ -1192,7 +1198,7 @@ bool launch_bwd_pair(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hi
     constexpr int WG_BP = 32;
     const unsigned tm = (unsigned)pn2_cdiv(j.M, 64), tn = (unsigned)pn2_cdiv(j.N, 64);
     static const int splitdiv = pn2_env_int("PN2_TN_SPLITDIV", 1);
-    int64_t want = (int64_t)pn2_num_cus() * 2 / ((int64_t)tm * tn) / splitdiv;
+    int64_t want = (int64_t)pn2_num_cus() / ((int64_t)tm * tn) / splitdiv;          // one TN workgroup per CU beside one NT workgroup
     if (want < 1) want = 1;
     const int64_t max_split = pn2_cdiv(P, 8 * WG_BP);
     int64_t split = want < max_split ? want : max_split;

@@ -21,7 +21,8 @@ FWD = [(1048576, 9, 64), (1048576, 64, 96), (1048576, 96, 128), (524288, 64, 64)
        (65536, 137, 128), (8192, 576, 256), (8192, 256, 128), (8192, 320, 128), (2048, 515, 256), (2048, 256, 512), (2048, 512, 1024), (2048, 1536, 256),
        (2048, 256, 256)]
 # backward shapes: (P, C_l, C_{l-1}, pooled K or 0)
-BWD = [(1048576, 64, 9, 0), (524288, 64, 9, 0), (262144, 32, 9, 0), (1048576, 128, 96, 128), (1048576, 96, 64, 0), (262144, 256, 196, 128), (262144, 196, 128, 0), (262144, 128, 323, 0),
+BWD = [(16384, 256, 320, 0), (16384, 128, 256, 0), (4096, 256, 384, 0), (4096, 256, 256, 0), (1024, 256, 768, 0), (8192, 512, 256, 32), (8192, 256, 256, 0),
+       (1048576, 64, 9, 0), (524288, 64, 9, 0), (262144, 32, 9, 0), (1048576, 128, 96, 128), (1048576, 96, 64, 0), (262144, 256, 196, 128), (262144, 196, 128, 0), (262144, 128, 323, 0),
        (524288, 128, 64, 64), (524288, 64, 64, 0), (131072, 256, 128, 64), (65536, 128, 128, 0),
        (131072, 128, 128, 0), (65536, 128, 137, 0), (262144, 64, 32, 32), (262144, 32, 32, 0), (524288, 64, 32, 32), (524288, 32, 32, 0), (32768, 256, 256, 0), (32768, 256, 320, 0),
        (8192, 128, 256, 0), (8192, 256, 576, 0), (8192, 128, 320, 0), (2048, 256, 256, 0), (2048, 256, 1536, 0), (2048, 1024, 512, 128), (2048, 512, 256, 0),
@@ -107,11 +108,13 @@ def main():
                 report("fwdpool%d" % Kp, (P, K, N), timeit(fnp, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
             del X, Y
 
-    for which in ("dgrad", "wgrad", "bwd"):
+    for which in ("dgrad", "wgrad", "bwd", "pair"):
         if args.which not in (which, "all"):
             continue
         for P, Cl, Cp, Kp in BWD:
             if which == "bwd" and not lib.pn2_res_supported(P, Cl, Cp):
+                continue
+            if which == "pair" and (P > 131072 or Cp < 64):
                 continue
             Y, Yp = rnd(P, r4(Cl)), rnd(P, r4(Cp))
             coef, affp = affine(Cl), affine(Cp)
@@ -135,6 +138,16 @@ def main():
                                                p(red), P, Cl, Cp, None, None, st)
                     assert rc == 0
                 report("dgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
+            elif which == "pair":              # dgrad + wgrad as one call (one launch where the pair kernel takes the shape)
+                dX = torch.empty(P, r4(Cp), device=dev)
+                red = torch.zeros(8 * 2 * Cp, device=dev, dtype=torch.float64)
+                dW = torch.zeros(Cl, Cp, device=dev)
+
+                def fn():
+                    rc = lib.pn2_conv1x1_bwd_pair(*dz, p(Y), r4(Cl), p(coef), p(Wt), Cp, p(Yp), r4(Cp), p(affp), p(dX), r4(Cp), p(red),
+                                                  p(Yp), r4(Cp), p(affp), p(dW), Cp, P, Cl, Cp, None, st)
+                    assert rc == 0
+                report("pair", (P, Cl, Cp, Kp), timeit(fn, args.reps), 4.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
             elif which == "bwd":
                 dX = torch.empty(P, r4(Cp), device=dev)
                 red = torch.zeros(8 * 2 * Cp, device=dev, dtype=torch.float64)
