@@ -35,7 +35,8 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 # C-ABI GEMM entry point -> kernel families of tools/pmc_traffic.py that serve it
-GEMM_FAMILIES = {"pn2_conv1x1_wgrad": ["gemm_tn_kernel", "wgrad_skinny_kernel", "wgrad_full_kernel"],
+GEMM_FAMILIES = {"pn2_conv1x1_bwd_pair": ["bwd_pair_kernel"],
+                 "pn2_conv1x1_wgrad": ["gemm_tn_kernel", "wgrad_skinny_kernel", "wgrad_full_kernel"],
                  "pn2_conv1x1_dgrad": ["gemm_nt_kernel<dgrad>", "regw_nt_kernel<dgrad>", "fewrow_nt_kernel<dgrad>"],
                  "pn2_conv1x1_bwd": ["gemm_bwd_fused_kernel"],
                  "pn2_conv1x1_fwd": ["gemm_nt_kernel<fwd>", "fwd_res_kernel", "regw_nt_kernel<fwd>", "fewrow_nt_kernel<fwd>"]}
@@ -61,6 +62,11 @@ def algorithmic_work(name, a):
         P, M, N = a[15], a[16], a[17]
         dense = a[0] is not None
         return 2.0 * P * M * N, 4.0 * (P * M * (2 if dense else 1) + P * N + M * N)
+    if name == "pn2_conv1x1_bwd_pair":       # dgrad + wgrad of one layer behind ONE grid: each body reads its own operands
+        P, Co, Ci = a[22], a[23], a[24]
+        dense, masked = a[0] is not None, a[11] is not None
+        dy = P * Co * (2 if dense else 1)
+        return 4.0 * P * Co * Ci, 4.0 * (dy + P * Ci * (2 if masked else 1) + Ci * Co) + 4.0 * (dy + P * Ci + Co * Ci)
     if name == "pn2_conv1x1_bwd":            # fused dgrad + wgrad: dZ|pooled, Y [P,Co], prev_Y [P,Ci] read once, dX [P,Ci] written
         P, Co, Ci = a[19], a[20], a[21]
         dense = a[0] is not None
@@ -580,7 +586,16 @@ def main():
                     name = "pn2_conv1x1_fwd"
                 if name == "pn2_ball_query_ws":        # the same query (same leading arguments) with caller scratch
                     name = "pn2_ball_query"
-                fl, by = algorithmic_work(name, a)
+                split = name == "pn2_conv1x1_bwd_pair_split"     # the pair entry point ran as dgrad + wgrad launches: booked half / half
+                fl, by = algorithmic_work("pn2_conv1x1_bwd_pair" if split else name, a)
+                if split:
+                    for half in ("pn2_conv1x1_dgrad", "pn2_conv1x1_wgrad"):
+                        d = agg.setdefault(half, [0.0, 0, 0.0, 0.0])
+                        d[0] += ms / 2
+                        d[1] += 1
+                        d[2] += fl / 2
+                        d[3] += by / 2
+                    continue
                 if args.detail and i >= len(calls) - ncall:
                     dims = [x for x in a if isinstance(x, int) and 0 < x < (1 << 31)][:8]
                     print("%-22s %8.1f us %7.2f TF %8.1f GB/s  %s" % (name, ms * 1e3, fl / ms / 1e9 if ms else 0,

@@ -37,6 +37,7 @@ extern "C" {
 #define PN2_DWX_REPLICAS 32   /* copies of the dWx partial block in pn2_group_affine_bwd_seg's scratch */
 
 #define PN2_OK 0
+#define PN2_OK_SPLIT 1            /* pn2_conv1x1_bwd_pair only: done, but issued as two launches (not an error) */
 #define PN2_EINVAL (-1)     /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define PN2_ELAUNCH (-2)    /* hipLaunch / hipMemsetAsync failed */
 #define PN2_EUNSUPPORTED (-3)
@@ -307,7 +308,8 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
  * prev_Y wherever there is a previous layer, with x_affine = prev_affine) as one call: on the few-row and mid-size layers
  * (sa3 / sa4 / FP stacks, P up to 64 k rows) both kernel bodies share ONE launch -- the first workgroups of the grid compute
  * dX, the rest dW -- so neither leaves half of the chip idle and the chain is one launch shorter; elsewhere the two
- * launches are issued one after the other.  Results are those of the two separate calls. */
+ * launches are issued one after the other and the call returns PN2_OK_SPLIT (1) instead of PN2_OK.  Results are those of the
+ * two separate calls. */
 int pn2_conv1x1_bwd_pair(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y,
                          int ldy, const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev,
                          const float *prev_affine, float *dXout, int ldxo, double *prev_red, const float *X, int ldx,

@@ -1783,7 +1783,9 @@ int pn2_conv1x1_bwd_pair(const float *dZ, int ldz, const float *dZp, int ldo, co
     const bool taken = g_pair_job.taken;
     g_pair_job.active = false;
     if (rc != PN2_OK || taken) return rc;
-    return pn2_conv1x1_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, nullptr, P, C_out, C_in, nullptr, stream);
+    const int rc2 = pn2_conv1x1_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, nullptr, P, C_out, C_in, nullptr,
+                                      stream);
+    return rc2 == PN2_OK ? PN2_OK_SPLIT : rc2;             // done, as two launches (callers that account per launch can tell)
 }
 
 }  // extern "C"

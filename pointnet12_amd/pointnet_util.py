@@ -856,8 +856,10 @@ class _SharedMLP(torch.autograd.Function):
                     # bodies share one launch (pn2_conv1x1_bwd_pair); elsewhere the library issues the two launches itself
                     prev = (c_x, ldx, _p(x_aff), dx.data_ptr(), dx.shape[1], _p(red[offs[l - 1]:offs[l]])) if l > 0 else \
                         (None, 0, None, dx.data_ptr(), ldx, None)
-                    _check(lib.pn2_conv1x1_bwd_pair(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, w_ld, *prev, c_x, ldx, _p(x_aff), _p(dW), ci,
-                                                    rn, co, ci, coef_lazy, st), "pn2_conv1x1_bwd_pair")
+                    rc = lib.pn2_conv1x1_bwd_pair(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, w_ld, *prev, c_x, ldx, _p(x_aff), _p(dW), ci,
+                                                  rn, co, ci, coef_lazy, st)
+                    if rc != _lib.PN2_OK_SPLIT:                 # (1: done as two launches -- not an error)
+                        _check(rc, "pn2_conv1x1_bwd_pair")
                     coef_lazy = None
                     continue
                 if need_dx:
