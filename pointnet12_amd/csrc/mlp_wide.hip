@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
             __syncthreads();                                        // chunk c is in `cur`; every wave is done with `nxt`
             // LATE_E (register budget): the lane's staging offsets are re-derived inside every chunk instead of living in
             // registers across the whole tile loop (one of them was spilled)
-            if (LATE_E || FPOOL > 0) asm volatile("" : "+v"(tq));
+            if (LATE_E || (FPOOL > 0 && KP == 200)) asm volatile("" : "+v"(tq));
             const int kbs = QT(c) / 2;                              // 8-wide k blocks of this chunk (static after unrolling)
             const bool last = c == NCH - 1;
             const int64_t t1 = last ? tile + G : tile;              // the chunk staged during this one ...
