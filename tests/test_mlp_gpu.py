@@ -299,10 +299,11 @@ def test_pool_in_gemm_epilogue_equals_the_pooling_pass(dev, P, pool, chans):
     # gradients: identical routing except between rows with EQUAL post-BN value (clamped to 0 by the ReLU -- no gradient --
     # or collapsed by rounding).  The two runs are separate launches: the fp64 statistics atomics land in another order, the
     # affine blocks differ in their last bit, and at 131 072+ rows a pair of rows that ties in one run need not tie in the other
-    # (seen once in round 4: one re-routed entry).  So: everything but a handful of entries within 1e-4 of the scale, and the
-    # tensors as a whole within 5e-3 in L2.
-    for a, b in zip([res[True][1]] + res[True][2], [res[False][1]] + res[False][2]):
-        scale = float(b.abs().max())
-        beyond = int(((a - b).abs() > 1e-4 * scale).sum())
-        assert beyond <= max(8, a.numel() // 10000), (beyond, a.numel(), float((a - b).abs().max()) / scale)
-        assert float((a - b).norm()) <= 5e-3 * float(b.norm()), float((a - b).norm()) / float(b.norm())
+    # (seen in round 4, one run in twelve: one re-routed entry = a rank-one change of every weight gradient below it, 3e-3 of
+    # its largest entry at 65 536 rows).  So: the input gradient within 1e-4 of its scale on all but a handful of ROWS, and
+    # every tensor within 1e-2 in L2.
+    xa, xb = res[True][1], res[False][1]
+    rows_beyond = int(((xa - xb).abs().amax(dim=1) > 1e-4 * float(xb.abs().max())).sum())
+    assert rows_beyond <= 8, rows_beyond
+    for a, b in zip([xa] + res[True][2], [xb] + res[False][2]):
+        assert float((a - b).norm()) <= 1e-2 * float(b.norm()), float((a - b).norm()) / float(b.norm())
