@@ -365,6 +365,15 @@ def farthest_point_sample(xyz, npoint, start=None):
     return _taped(lambda: out)
 
 
+def _sampled_centres(xyz, fps_idx):
+    """new_xyz = index_points(xyz, fps_idx) (pointnet_util.py:125, :238) as part of the GEOMETRY: it depends on the coordinates
+    alone (xyz never carries a gradient), so under a GeometryTape it is recorded with the indices -- the prefetch
+    branch gathers the next batch's centres, and the step's own chain is one launch per sampling stage shorter."""
+    if _tape is not None and _tape.mode == "replay":
+        return _taped(None)
+    return _taped(lambda: index_points(xyz, fps_idx, _checked=False).detach())
+
+
 def query_ball_point(radius, nsample, xyz, new_xyz):
     """-> int64 [B,S,nsample]; pointnet_util.py:87-107 (first nsample in-radius indices, padded with the first)."""
     if _tape is not None and _tape.mode == "replay":
@@ -1291,7 +1300,7 @@ class PointNetSetAbstraction(nn.Module):
         else:
             S, K = self.npoint, self.nsample
             fps_idx = farthest_point_sample(xyz, S, fps_start)
-            new_xyz = index_points(xyz, fps_idx, _checked=False)
+            new_xyz = _sampled_centres(xyz, fps_idx)
             idx = query_ball_point(self.radius, K, xyz, new_xyz)
             inv = _group_inverse(idx, N, 0 if pts is None else pts.shape[2], len(self.mlp_convs), self.training)
             rows = None
@@ -1334,7 +1343,7 @@ class PointNetSetAbstractionMsg(nn.Module):
         pts = None if points is None else _channel_last(points, "points")
         B, N, _ = xyz.shape
         S = self.npoint
-        new_xyz = index_points(xyz, farthest_point_sample(xyz, S, fps_start), _checked=False)
+        new_xyz = _sampled_centres(xyz, farthest_point_sample(xyz, S, fps_start))
         c_in = 3 + (0 if pts is None else pts.shape[2])
         outs = []
         # The scales are independent until the final concatenation: with MSG_SCALE_STREAMS on, each one is issued
