@@ -304,6 +304,16 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
 
+/* pn2_conv1x1_wgrad with caller scratch (ABI 8): where pn2_conv1x1_wgrad_workspace_bytes(P, M, N, pooled) is > 0 and `workspace`
+ * (16-byte aligned, that many bytes, contents irrelevant) is given, the full-tile kernel stores every workgroup's partial dW as
+ * plain stores and a second small launch adds the slabs into dW (one atomic per element instead of one per workgroup and
+ * element).  workspace == NULL or a query result of 0: exactly pn2_conv1x1_wgrad. */
+int64_t pn2_conv1x1_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled);
+int pn2_conv1x1_wgrad_ws(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg,
+                         int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
+                         const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
+                         const pn2_bn_coef_lazy *coef_lazy, float *workspace, pn2_stream_t stream);
+
 /* pn2_conv1x1_dgrad followed by pn2_conv1x1_wgrad of ONE layer (same dZ / pooled pair, Y, coef; X = the layer's input, i.e.
  * prev_Y wherever there is a previous layer, with x_affine = prev_affine) as one call: on the few-row and mid-size layers
  * (sa3 / sa4 / FP stacks, P up to 64 k rows) both kernel bodies share ONE launch -- the first workgroups of the grid compute

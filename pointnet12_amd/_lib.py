@@ -47,6 +47,9 @@ SIGNATURES = {
                                _i64, _i, _i, _vp, _vp, _vp]),
     "pn2_conv1x1_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
                                _i64, _i, _i, _vp, _vp]),
+    "pn2_conv1x1_wgrad_workspace_bytes": (_i64, [_i64, _i, _i, _i]),
+    "pn2_conv1x1_wgrad_ws": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
+                                  _i64, _i, _i, _vp, _vp, _vp]),
     "pn2_conv1x1_bwd_pair": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                                   _i64, _i, _i, _vp, _vp]),
     "pn2_res_supported": (_i, [_i64, _i, _i]),
@@ -127,7 +130,7 @@ class _Timed:
     def __getattr__(self, name):
         fn = getattr(_raw, name)
         if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes",
-                                                   "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_bwd_res_supported",
+                                                   "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_bwd_res_supported", "pn2_conv1x1_wgrad_workspace_bytes",
                                                    "pn2_ball_query_workspace_bytes"):
             return fn
 

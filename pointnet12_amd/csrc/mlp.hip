@@ -1572,7 +1572,8 @@ int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
                    float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, LazyCoef lc, hipStream_t s, int64_t *rows_done);
 int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *X, int ldx, const float *x_affine, float *dW, int lddw, float *dbias,
-                   int64_t P, int M, int N, LazyCoef lc, hipStream_t s);
+                   int64_t P, int M, int N, LazyCoef lc, hipStream_t s, float *workspace = nullptr);
+int64_t pn2_wide_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled);
 
 extern "C" {
 
@@ -1732,9 +1733,21 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
 }
 
+int64_t pn2_conv1x1_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled) { return pn2_wide_wgrad_workspace_bytes(P, M, N, pooled); }
+
+int pn2_conv1x1_wgrad_ws(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
+                         const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
+                         const pn2_bn_coef_lazy *coef_lazy, float *workspace, pn2_stream_t stream);
+
 int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                       const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                       const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream) {
+    return pn2_conv1x1_wgrad_ws(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, dbias, P, M, N, coef_lazy, nullptr, stream);
+}
+
+int pn2_conv1x1_wgrad_ws(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
+                         const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
+                         const pn2_bn_coef_lazy *coef_lazy, float *workspace, pn2_stream_t stream) {
     PN2_CHECK_ARG(Y && coef && X && dW && P > 0 && P < (1LL << 31) && M > 0 && N > 0 && lazy_coef_ok(coef_lazy, coef, M));
     const LazyCoef lc = make_lazy_coef(coef_lazy);
     PN2_CHECK_ARG(dZ != nullptr || (dZp && arg && Kpool > 0 && P < (1LL << 31)));
@@ -1743,7 +1756,9 @@ int pn2_conv1x1_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
     hipStream_t s = pn2_s(stream);
     PN2_CHECK_ARG(dZ ? (ldz % 4 == 0 && ldz >= round4(M)) : (ldo % 4 == 0 && ldo >= round4(M)));
     {                                                                   // wide layer: all of dW resident in one workgroup (mlp_wide.hip)
-        const int rc = pn2_wide_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, dbias, P, M, N, lc, s);
+        // (the workspace is used only if it is as large as the query said it must be: the caller passes what it was told)
+        const int rc = pn2_wide_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, dbias, P, M, N, lc, s,
+                                      pn2_wide_wgrad_workspace_bytes(P, M, N, dZ == nullptr) > 0 ? workspace : nullptr);
         if (rc != PN2_EUNSUPPORTED) return rc;
     }
     if (dZ) {

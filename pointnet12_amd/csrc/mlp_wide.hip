@@ -527,6 +527,7 @@ struct WgradArgs {
     float *dW; int lddw; float *dbias;
     int64_t P; int64_t rows_per_wg; int M; int N;
     LazyCoef lc;                                                   // `coef` is filled by the prologue (a layer without a data gradient)
+    float *ws;                                                     // two-phase flush: partial slabs [workgroup][MB * 32][NB * 32], or null
 };
 
 template <int MM, int NN, int TNW, int DYM, bool XACT, int PKP, int BP, bool BIAS>
@@ -675,13 +676,26 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
 
     // ---- flush: every accumulator register is 2 x 128 contiguous bytes of dW
     const int m_base = mb * 32 + 4 * lh;
+    if (g.ws != nullptr) {
+        // two-phase form (round 4, built to be measured): the workgroup's whole slab leaves as PLAIN stores (padded tile grid: no
+        // predicates), wgrad_reduce_kernel adds the slabs up and issues one atomic per element -- 256x fewer atomics, the same
+        // bytes written once and read once
+        float *slab = g.ws + (size_t)blockIdx.x * (MB * 32) * (NB * 32);
 #pragma unroll
-    for (int j = 0; j < TNW; ++j) {
-        const int n = (nb0 + j) * 32 + l31;
+        for (int j = 0; j < TNW; ++j) {
+            const int n = (nb0 + j) * 32 + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m_base + (r & 3) + 8 * (r >> 2);
-            if (m < M && n < N) atomicAdd(g.dW + (int64_t)m * g.lddw + n, acc[j][r]);
+            for (int r = 0; r < 16; ++r) slab[(m_base + (r & 3) + 8 * (r >> 2)) * (NB * 32) + n] = acc[j][r];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int n = (nb0 + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (r & 3) + 8 * (r >> 2);
+                if (m < M && n < N) atomicAdd(g.dW + (int64_t)m * g.lddw + n, acc[j][r]);
+            }
         }
     }
     if (BIAS && g.dbias != nullptr) {                               // fold the row groups of each channel quad in LDS
@@ -705,6 +719,34 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
     }
 }
 
+// Second phase of the two-phase flush: dW[m, n] += sum over the workgroups' slabs.  grid (element blocks, slab ranges): a
+// thread owns one float4 of one row and a range of slabs (coalesced 16-byte reads, slab pitch apart), then four atomics.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, int slabs, int rows, int ldn, int M, int N,
+                                                           float *__restrict__ dW, int lddw) {
+    const int q = blockIdx.x * 256 + threadIdx.x, qpr = ldn >> 2;
+    if (q >= rows * qpr) return;
+    const int m = q / qpr, n = (q - m * qpr) * 4;
+    const int per = (slabs + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * per, w1 = w0 + per < slabs ? w0 + per : slabs;
+    const size_t pitch = (size_t)rows * ldn;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    const float *p = ws + (size_t)w0 * pitch + (size_t)m * ldn + n;
+    int w = w0;
+    for (; w + 1 < w1; w += 2, p += 2 * pitch) {
+        const float4 u = ld4(p), v = ld4(p + pitch);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (w < w1) { const float4 u = ld4(p); a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+    if (m < M) {
+        float *d = dW + (int64_t)m * lddw + n;
+        if (n < N) atomicAdd(d, a.x + b.x);
+        if (n + 1 < N) atomicAdd(d + 1, a.y + b.y);
+        if (n + 2 < N) atomicAdd(d + 2, a.z + b.z);
+        if (n + 3 < N) atomicAdd(d + 3, a.w + b.w);
+    }
+}
+
 template <int MM, int NN, int TNW, int DYM, bool XACT, int PKP, int BP>
 int launch_wgrad_full(WgradArgs g, hipStream_t s) {
     constexpr int MB = (MM + 31) / 32, NB = (NN + 31) / 32;
@@ -721,6 +763,14 @@ int launch_wgrad_full(WgradArgs g, hipStream_t s) {
     g.rows_per_wg = rows;
     wgs = pn2_cdiv(g.P, rows);
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * NW), lds, s, g);
+    if (g.ws != nullptr) {
+        const int rows_pad = MB * 32, ldn = NB * 32;
+        const unsigned gx = (unsigned)pn2_cdiv((int64_t)rows_pad * (ldn / 4), 256);
+        unsigned gy = (unsigned)(4 * pn2_num_cus() / gx);          // ~4 workgroups per CU in all
+        if (gy < 1) gy = 1;
+        if (gy > (unsigned)wgs) gy = (unsigned)wgs;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, s, g.ws, (int)wgs, rows_pad, ldn, g.M, g.N, g.dW, g.lddw);
+    }
     return pn2_launch_status();
 }
 
@@ -730,14 +780,14 @@ int launch_wgrad_full(WgradArgs g, hipStream_t s) {
 // 128 x 128 dense; the input is always a BatchNorm + ReLU of the previous layer's output here
 int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *X, int ldx, const float *x_affine, float *dW, int lddw, float *dbias,
-                   int64_t P, int M, int N, LazyCoef lc, hipStream_t s) {
+                   int64_t P, int M, int N, LazyCoef lc, hipStream_t s, float *workspace) {
     static const int on = wide_env("PN2_WIDE", 1) && wide_env("PN2_WIDE_WGRAD", 1);
     static const int min_rows = wide_env("PN2_WIDE_WGRAD_MIN_ROWS", 131072);
     if (!on || P < min_rows || x_affine == nullptr || ldy != ((M + 3) & ~3) || ldx != ((N + 3) & ~3)) return PN2_EUNSUPPORTED;
     if (!dZ && (Kpool <= 0 || P % Kpool != 0)) return PN2_EUNSUPPORTED;
     WgradArgs g{};
     g.Y = Y; g.ldy = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.coef = coef; g.X = X; g.ldx = ldx;
-    g.x_aff = x_affine; g.dW = dW; g.lddw = lddw; g.dbias = dbias; g.P = P; g.M = M; g.N = N; g.lc = lc;
+    g.x_aff = x_affine; g.dW = dW; g.lddw = lddw; g.dbias = dbias; g.P = P; g.M = M; g.N = N; g.lc = lc; g.ws = workspace;
 #define WIDE_WGRAD(MM, NN, TNW, PKP, BP)                                                                                 \
     if (M == MM && N == NN && (PKP == 0 ? dZ != nullptr : (dZ == nullptr && Kpool == PKP)))                             \
         return launch_wgrad_full<MM, NN, TNW, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, true, PKP, BP>(g, s);
@@ -750,4 +800,15 @@ int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
     // re-reads on a product this small; instantiation dropped)
 #undef WIDE_WGRAD
     return PN2_EUNSUPPORTED;
+}
+
+// Bytes of caller scratch with which pn2_conv1x1_wgrad flushes dW in two phases (0: this shape keeps the atomic flush, or the
+// two-phase form is switched off: PN2_WGRAD_TWO_PHASE, default by measurement -- see DESIGN.md section 4).
+int64_t pn2_wide_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled) {
+    static const int on = wide_env("PN2_WIDE", 1) && wide_env("PN2_WIDE_WGRAD", 1) && wide_env("PN2_WGRAD_TWO_PHASE", 0);
+    static const int min_rows = wide_env("PN2_WIDE_WGRAD_MIN_ROWS", 131072);
+    if (!on || P < min_rows) return 0;
+    const bool shape = (M == 256 && N == 196 && pooled) || (M == 256 && N == 128 && pooled) || (M == 196 && N == 128 && !pooled);
+    if (!shape) return 0;
+    return (int64_t)pn2_num_cus() * ((M + 31) / 32 * 32) * ((N + 31) / 32 * 32) * (int64_t)sizeof(float);
 }

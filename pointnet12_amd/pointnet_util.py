@@ -890,8 +890,14 @@ class _SharedMLP(torch.autograd.Function):
                                                      None if training else _p(dbias), rn, co, ci, coef_lazy, _lib.stream()), "pn2_conv1x1_wgrad")
                     side_used = True
                 else:
-                    _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
-                                                 None if training else _p(dbias), rn, co, ci, coef_lazy, st), "pn2_conv1x1_wgrad")
+                    ws_bytes = lib.pn2_conv1x1_wgrad_workspace_bytes(rn, co, ci, int(pooled)) if training else 0
+                    if ws_bytes:                                # two-phase dW flush of the full-tile kernel: caller scratch
+                        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+                        _check(lib.pn2_conv1x1_wgrad_ws(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci, None, rn, co, ci,
+                                                        coef_lazy, _p(ws), st), "pn2_conv1x1_wgrad_ws")
+                    else:
+                        _check(lib.pn2_conv1x1_wgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), c_x, ldx, _p(x_aff), _p(dW), ci,
+                                                     None if training else _p(dbias), rn, co, ci, coef_lazy, st), "pn2_conv1x1_wgrad")
                 coef_lazy = None
             if not direct:
                 grads[7 * l] = dW.view_as(Ws[l])

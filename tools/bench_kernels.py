@@ -160,10 +160,16 @@ def main():
                 report("bwd", (P, Cl, Cp, Kp), timeit(fn, args.reps), 4.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
             else:
                 dW = torch.zeros(Cl, Cp, device=dev)
+                wsb = lib.pn2_conv1x1_wgrad_workspace_bytes(P, Cl, Cp, 1 if Kp else 0)      # > 0: two-phase dW flush (PN2_WGRAD_TWO_PHASE=1)
+                ws = torch.empty(wsb, device=dev, dtype=torch.uint8) if wsb else None
 
                 def fn():
-                    rc = lib.pn2_conv1x1_wgrad(*dz, p(Y), r4(Cl), p(coef), p(Yp), r4(Cp), p(affp) if Cp >= 16 else None, p(dW), Cp,
-                                               None, P, Cl, Cp, None, st)
+                    if ws is not None:
+                        rc = lib.pn2_conv1x1_wgrad_ws(*dz, p(Y), r4(Cl), p(coef), p(Yp), r4(Cp), p(affp) if Cp >= 16 else None, p(dW), Cp,
+                                                      None, P, Cl, Cp, None, p(ws), st)
+                    else:
+                        rc = lib.pn2_conv1x1_wgrad(*dz, p(Y), r4(Cl), p(coef), p(Yp), r4(Cp), p(affp) if Cp >= 16 else None, p(dW), Cp,
+                                                   None, P, Cl, Cp, None, st)
                     assert rc == 0
                 report("wgrad", (P, Cl, Cp, Kp), timeit(fn, args.reps), 2.0 * P * Cl * Cp, 4.0 * (dy_bytes + P * Cp))
 
