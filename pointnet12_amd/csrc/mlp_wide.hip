@@ -808,7 +808,10 @@ int64_t pn2_wide_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled) {
     static const int on = wide_env("PN2_WIDE", 1) && wide_env("PN2_WIDE_WGRAD", 1) && wide_env("PN2_WGRAD_TWO_PHASE", 0);
     static const int min_rows = wide_env("PN2_WIDE_WGRAD_MIN_ROWS", 131072);
     if (!on || P < min_rows) return 0;
-    const bool shape = (M == 256 && N == 196 && pooled) || (M == 256 && N == 128 && pooled) || (M == 196 && N == 128 && !pooled);
+    // measured alone on the chip (us, atomic flush -> two-phase): 256 x 196 360.8 -> 340.4, 196 x 128 192.2 -> 193.8, 256 x 128
+    // 105.9 -> 111.3: only the largest product has a tail long enough to pay for the second launch
+    static const int all = wide_env("PN2_WGRAD_TWO_PHASE_ALL", 0);
+    const bool shape = (M == 256 && N == 196 && pooled) || (all && ((M == 256 && N == 128 && pooled) || (M == 196 && N == 128 && !pooled)));
     if (!shape) return 0;
     return (int64_t)pn2_num_cus() * ((M + 31) / 32 * 32) * ((N + 31) / 32 * 32) * (int64_t)sizeof(float);
 }
