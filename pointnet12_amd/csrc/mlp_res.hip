@@ -86,11 +86,15 @@ extern __shared__ __attribute__((aligned(16))) float res_lds[];
 // Diagnostic build only (make STAMP=1): per-phase shader-cycle sums of every wave of the first 64 workgroups of the last
 // resident-kernel launch, read back with pn2_debug_stamps_res().  Never compiled into the shipped library.
 __device__ unsigned long long pn2_res_stamp_buf[64 * 8 * 8];
-#define RSTAMP_DECL unsigned long long rst_t = clock64(), rst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// (slots 6 / 7: shader cycles and 100 MHz ticks over the whole stamped span -- their ratio is the clock the kernel held)
+#define RSTAMP_DECL unsigned long long rst_t = clock64(), rst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long rst_c0 = rst_t, rst_w0 = wall_clock64();
+__device__ unsigned long long pn2_res_abs_buf[64 * 8 * 4];     // 100 MHz ticks: kernel entry, loop start, loop end, exit
+#define RABS(wv, i) if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) pn2_res_abs_buf[(blockIdx.x * 8 + (wv)) * 4 + (i)] = wall_clock64();
 #define RSTAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = clock64(); rst_acc[i] += n_ - rst_t; rst_t = n_; __builtin_amdgcn_sched_barrier(0); }
-#define RSTAMP_FLUSH(wv) if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) { for (int i_ = 0; i_ < 8; ++i_) pn2_res_stamp_buf[(blockIdx.x * 8 + (wv)) * 8 + i_] = rst_acc[i_]; }
+#define RSTAMP_FLUSH(wv) { rst_acc[6] = clock64() - rst_c0; rst_acc[7] = wall_clock64() - rst_w0; if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) { for (int i_ = 0; i_ < 8; ++i_) pn2_res_stamp_buf[(blockIdx.x * 8 + (wv)) * 8 + i_] = rst_acc[i_]; } }
 #else
 #define RSTAMP_DECL
+#define RABS(wv, i)
 #define RSTAMP(i)
 #define RSTAMP_FLUSH(wv)
 #endif
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
     const int G = gridDim.x;
 
+    RABS(wave, 0)
     lazy_coef_prologue(dy.lc);                                     // consumer-side BatchNorm backward (bn_tail.h)
     // ---- one-time: W^T, coefficient table
     for (int i = t; i < Co * Ci; i += 512) {
@@ -240,13 +245,19 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
 #pragma unroll
         for (int i = 0; i < IT_P; ++i) R.p[i] = ld4(Yp + (tp + op[i]));
     };
-    // registers -> LDS: dY of one tile, formed here once per row
+    // registers -> LDS: dY of one tile, formed here once per row.  Where 512 % QD == 0 (C_out = 32, 64, 128) a thread's items
+    // all sit in ONE channel quad: its four coefficient quads are read from the table once per launch (DP_HOIST) instead of
+    // with every item -- they were 16 of the 23 ds_*_b128 a thread issues per tile of the 128 x 96 pair, all eight waves at
+    // the same time with the matrix pipe idle (same-box A/B, round 4: 128 x 96 pooled 603 -> 593 us, 128 x 64 244 -> 236,
+    // 64 x 64 162 -> 158).
+    constexpr bool DP_HOIST = 512 % QD == 0;
+    DyParams dpk;
     auto finish_dy = [&](Regs &R, float *dst, int64_t tile) {
         const unsigned kbase = POOL == 1 ? (unsigned)(tile * RES_BM) & ((1u << dy.kshift) - 1u) : 0u;
 #pragma unroll
         for (int i = 0; i < IT_D; ++i) {
             const int idx = t + 512 * i, row = idx / QD, q = idx - row * QD;
-            const DyParams dp = dy_params_tab(tab, Co, 4 * q, true);
+            const DyParams dp = DP_HOIST ? dpk : dy_params_tab(tab, Co, 4 * q, true);
             float4 dz = R.z[POOLED ? slot(i) : i];
             if (POOLED) {
                 const int4 a = R.a[slot(i)];
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
 
     int64_t tile = blockIdx.x;
     RSTAMP_DECL
+    RABS(wave, 1)
     if (!DBUF) {
         auto step = [&](Regs &R, int64_t tl) {
             finish_dy(R, dYs, tl);
@@ -369,6 +381,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
         fetch_p(rs[0], tile);
         if (DEPTH > 1) { fetch_dy(rs[DEPTH - 1], tile + G); fetch_p(rs[DEPTH - 1], tile + G); }
         __syncthreads();                                           // Wt and tab are in place
+        if (DP_HOIST) dpk = dy_params_tab(tab, Co, 4 * (t % QD), true);
         while (tile < tiles) {
             step(rs[0], tile);
             tile += G;
@@ -384,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
         fetch_dy(R, tile);
         fetch_p(R, tile);
         __syncthreads();                                           // Wt and tab are in place
+        if (DP_HOIST) dpk = dy_params_tab(tab, Co, 4 * (t % QD), true);
         if (tile < tiles) {
             finish_dy(R, dYs, tile);
             write_yp(R);
@@ -412,6 +426,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     }
 
     RSTAMP_FLUSH(wave)
+    RABS(wave, 2)
     // ---- flush: dW partial tiles (tile e holds the rows {CO_T i + e}: 128 contiguous bytes per half-wave), the dX column's
     // two reductions.  (Summing the waves' partials in LDS first and adding one block per workgroup was measured SLOWER:
     // 128x128 at 65 536 rows 84 -> 106 us.)
@@ -431,6 +446,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
             atomicAdd(rep + Ci + ecol, st1);
         }
     }
+    RABS(wave, 3)
 }
 
 inline size_t bwd_res_lds_bytes(int Co, int Ci, bool dbuf) {
@@ -527,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
     float *atab = Ws + N * LDA;                                    // mean, scale, beta rows of the input BatchNorm: 3 * K
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
     float *Ab = atab + 3 * K + wave * (32 * LDA);                  // this wave's staging buffer [32][LDA]
+    RABS(wave, 0)
 
     lazy_bn_prologue(pool.lz);                                     // consumer-side BatchNorm (bn_tail.h)
     for (int i = t; i < N * QK; i += blockDim.x) {
@@ -580,8 +597,19 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
         for (int j = 0; j < N_T; ++j) sgn[POOL ? j : 0] = pool.gamma[32 * j + l31] < 0.f ? (int)0x80000000 : 0;
     }
     __syncthreads();                                               // W image and table complete (the only barrier before the end)
+    // 64 % QK == 0 (K = 32, 64, 128): a lane's items all sit in ONE channel quad; its BatchNorm constants are read from the
+    // table once instead of with every item (3 of the 4 ds_*_b128 of the transform)
+    constexpr bool AT_HOIST = ACT && 64 % QK == 0 && !(K_T == 4 && N_T == 4);
+    float4 hmu, hsc, hbe;
+    if (AT_HOIST) {
+        const int q4 = 4 * (lane % QK);
+        hmu = *reinterpret_cast<const float4 *>(&atab[q4]);
+        hsc = *reinterpret_cast<const float4 *>(&atab[K + q4]);
+        hbe = *reinterpret_cast<const float4 *>(&atab[2 * K + q4]);
+    }
 
     RSTAMP_DECL
+    RABS(wave, 1)
     while (slab < slabs) {
         RSTAMP(4)
         if (!OFFS_LIVE) asm volatile("" : "+v"(lane_op));
@@ -594,10 +622,10 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
             float4 x = rx[i];
             const unsigned oli = OFFS_LIVE ? ol[OFFS_LIVE ? i : 0] : off_l(i);
             if (ACT) {
-                const int q4 = (int)(oli % (unsigned)LDA);
-                const float4 mu = *reinterpret_cast<const float4 *>(&atab[q4]);
-                const float4 sc = *reinterpret_cast<const float4 *>(&atab[K + q4]);
-                const float4 be = *reinterpret_cast<const float4 *>(&atab[2 * K + q4]);
+                const int q4 = AT_HOIST ? 0 : (int)(oli % (unsigned)LDA);
+                const float4 mu = AT_HOIST ? hmu : *reinterpret_cast<const float4 *>(&atab[q4]);
+                const float4 sc = AT_HOIST ? hsc : *reinterpret_cast<const float4 *>(&atab[K + q4]);
+                const float4 be = AT_HOIST ? hbe : *reinterpret_cast<const float4 *>(&atab[2 * K + q4]);
                 x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
                 x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
                 x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
@@ -704,6 +732,7 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
 
     RSTAMP(3)
     RSTAMP_FLUSH(wave)
+    RABS(wave, 2)
     if (stats != nullptr) {                                        // fold the waves in LDS (the W image is dead), one atomic per channel
         __syncthreads();
         double *red = reinterpret_cast<double *>(res_lds);        // [NW][N][2]
@@ -726,6 +755,7 @@ __global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict
             atomicAdd(rep + N + t, a1);
         }
     }
+    RABS(wave, 3)
 }
 
 template <int K_T, int N_T, bool ACT, int POOL>
@@ -787,6 +817,10 @@ static bool res_shape_ok(int C_out, int C_in) {
 }
 
 #ifdef PN2_STAMP
+extern "C" int pn2_debug_stamps_abs(unsigned long long *host_out, int n) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pn2_res_abs_buf), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -2;
+}
 extern "C" int pn2_debug_stamps_res(unsigned long long *host_out, int n) {
     hipDeviceSynchronize();
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pn2_res_stamp_buf), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -2;

@@ -156,21 +156,43 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
     Raw raw;
     const int64_t tiles = g.tiles;
     const int G = gridDim.x;
-    // item i of chunk c: idx = t + NT * i over BM rows x QT(c) quads; row = idx / QT, q = idx % QT
+    // item i of chunk c: idx = t + NT * i over BM rows x QT(c) quads; row = idx / QT, q = idx % QT.
+    // FULL chunks (QT == QV == KC / 4 =: QF, and NT % QF == 0): a thread's items all sit in ONE channel quad lq = t % QF, RPI rows
+    // apart, so every global address is a WAVE-UNIFORM base (tile, item and chunk terms: scalar arithmetic) plus one of three
+    // loop-invariant 32-bit lane offsets, and the LDS address one lane offset plus an immediate.  (Round 4 ablation,
+    // tools/exp/x_wide.sh: with the per-item index arithmetic -- two divisions, two 64-bit multiply-adds and four 64-bit adds
+    // per request, ~25 vector instructions -- the requests alone cost 10 - 25 % of these kernels.)
+    constexpr int QF = KC / 4;
+    static_assert(NT % QF == 0, "a thread's items of a full chunk share one channel quad");
     int tq = t;                                                     // (LATE_E: re-derived per chunk, see the chunk loop)
+    const int lrow = t / QF, lq = t - lrow * QF;
+    const unsigned vq4 = 4u * (unsigned)lq;                         // element offsets, lane part
+    const unsigned voA = (unsigned)lrow * (unsigned)g.lda + vq4;
+    const unsigned voZ = MODE == MODE_DYDENSE ? (unsigned)lrow * (unsigned)g.ldz + vq4 : 0u;
+    const unsigned ldsw = (unsigned)lrow * LDP + vq4;
+    auto is_full = [&](int c) constexpr { return QT(c) == QF && QV(c) == QF; };
     auto fetch_item = [&](int64_t tile, int c, int i) {
         const int qt = QT(c), qv = QV(c);
         const unsigned tl = (unsigned)(tile < tiles ? tile : tiles - 1);      // past the end: re-read the last tile (never used)
-        if (POOLED && (i == A_IT - 1 || zslot(i + 1) != zslot(i))) {
-            // The (dZp, arg) quad of a group is shared by all of the thread's items in that group: it is requested behind
-            // the LAST of them (the items of the chunk being staged still read the previous one), by every thread, from
-            // the row of the group's first item (always inside the tile; the last pass of a chunk may be partly filled).
-            int i0 = i;
-            while (i0 > 0 && zslot(i0 - 1) == zslot(i)) --i0;
-            const int idx0 = tq + NT * i0, row0 = idx0 / qt, q0 = idx0 - row0 * qt;
-            const unsigned grp = (tl * BM + row0) / (unsigned)(PKP > 0 ? PKP : 1);
-            raw.z[POOLED ? zslot(i) : 0] = ld4(g.dZp + row_off(grp, g.ldo) + c * KC + 4 * q0);
-            raw.a[POOLED ? zslot(i) : 0] = ld4i(g.arg + row_off(grp, g.ldo) + c * KC + 4 * q0);
+        if (is_full(c)) {
+            if (POOLED && (i == A_IT - 1 || zslot(i + 1) != zslot(i))) {
+                // The (dZp, arg) quad of a group is shared by all of the thread's items in that group: it is requested behind
+                // the LAST of them (the items of the chunk being staged still read the previous one), by every thread.  The group
+                // is wave-uniform: a tile lies inside one group (BM <= PKP), or the groups are whole multiples of the row step
+                // RPI and the lane's row < RPI never crosses into the next one.
+                int i0 = i;
+                while (i0 > 0 && zslot(i0 - 1) == zslot(i)) --i0;
+                const unsigned grp = (tl * BM + (unsigned)(i0 * RPI)) / (unsigned)(PKP > 0 ? PKP : 1);
+                const size_t go = (size_t)grp * (unsigned)g.ldo + (unsigned)(c * KC);
+                raw.z[POOLED ? zslot(i) : 0] = ld4(g.dZp + go + vq4);
+                raw.a[POOLED ? zslot(i) : 0] = ld4i(g.arg + go + vq4);
+            }
+            if (NT * i >= BM * QF) return;                                   // static: this chunk has fewer items
+            if (NT * (i + 1) > BM * QF && lrow + i * RPI >= BM) return;      // the last, partly filled pass
+            const size_t m = (size_t)tl * BM + (unsigned)(i * RPI);          // uniform
+            raw.y[i] = ld4(g.A + m * (unsigned)g.lda + (unsigned)(c * KC) + voA);
+            if (MODE == MODE_DYDENSE) raw.z[DY ? i : 0] = ld4(g.dZ + m * (unsigned)g.ldz + (unsigned)(c * KC) + voZ);
+            return;
         }
         const int idx = tq + NT * i, row = idx / qt, q = idx - row * qt;
         if (NT * i >= BM * qt) return;                                   // static: this chunk has fewer items
@@ -181,35 +203,56 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
         raw.y[i] = ld4(g.A + row_off(m, g.lda) + k);
         if (MODE == MODE_DYDENSE) raw.z[DY ? i : 0] = ld4(g.dZ + row_off(m, g.ldz) + k);
     };
-    auto stage_item = [&](float *dst, int64_t tile, int c, int i) {
+    // The per-channel constants of a full chunk (BatchNorm mean / scale / beta, or the four BatchNorm-backward coefficient
+    // rows) depend on the chunk alone: fetched from the table once per chunk (HOIST; the memory clobbers that pin the staging
+    // to its k block would otherwise make every item read them again), where the register budget has room for 12 / 16 more.
+    struct Consts { float4 a, b, c, d; };
+    constexpr bool HOIST = MODE != MODE_PLAIN && !(EPI == EPI_MASK && KP == 200);
+    auto chunk_consts = [&](int c) {
+        Consts o;
+        const int k = c * KC + (int)vq4;
+        o.a = *reinterpret_cast<const float4 *>(&tab[k]);
+        o.b = *reinterpret_cast<const float4 *>(&tab[KP + k]);
+        o.c = *reinterpret_cast<const float4 *>(&tab[2 * KP + k]);
+        o.d = NTAB > 3 ? *reinterpret_cast<const float4 *>(&tab[(NTAB > 3 ? 3 : 0) * KP + k]) : o.c;
+        return o;
+    };
+    auto stage_item = [&](float *dst, int64_t tile, int c, int i, const Consts &cc) {
         const int qt = QT(c), qv = QV(c);
-        const int idx = tq + NT * i, row = idx / qt, q = idx - row * qt;
+        const bool full = is_full(c);
+        const int idx = tq + NT * i;
+        const int row = full ? lrow + i * RPI : idx / qt, q = full ? lq : idx - (idx / qt) * qt;
         if (NT * i >= BM * qt) return;                                   // static: this chunk has fewer items
-        if (NT * (i + 1) > BM * qt && idx >= BM * qt) return;            // the last, partly filled pass
+        if (NT * (i + 1) > BM * qt && (full ? row >= BM : idx >= BM * qt)) return;   // the last, partly filled pass
         const int k = c * KC + 4 * q;
         float4 x = raw.y[i];
         if (MODE == MODE_BNRELU) {
-            const float4 mu = *reinterpret_cast<const float4 *>(&tab[k]);
-            const float4 sc = *reinterpret_cast<const float4 *>(&tab[KP + k]);
-            const float4 be = *reinterpret_cast<const float4 *>(&tab[2 * KP + k]);
+            const bool h = HOIST && full;
+            const float4 mu = h ? cc.a : *reinterpret_cast<const float4 *>(&tab[k]);
+            const float4 sc = h ? cc.b : *reinterpret_cast<const float4 *>(&tab[KP + k]);
+            const float4 be = h ? cc.c : *reinterpret_cast<const float4 *>(&tab[2 * KP + k]);
             x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
             x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
             x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
             x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
         }
         if (DY) {
-            const DyParams dp = dy_params_tab(tab, KP, k, true);
+            DyParams dp;
+            if (HOIST && full) { dp.c0 = cc.a; dp.q1 = cc.b; dp.q0 = cc.c; dp.mu = cc.d; }
+            else dp = dy_params_tab(tab, KP, k, true);
             float4 dz = raw.z[POOLED ? zslot(i) : (DY ? i : 0)];
             if (POOLED) {
                 const int4 a = raw.a[POOLED ? zslot(i) : 0];
-                const int kk = (int)(((unsigned)(tile < tiles ? tile : tiles - 1) * BM + row) & (unsigned)(PKP - 1));
+                const unsigned tl = (unsigned)(tile < tiles ? tile : tiles - 1);
+                const int kk = (int)((tl * BM + (unsigned)(i * RPI) + (unsigned)lrow) & (unsigned)(PKP - 1));
                 dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f;
                 dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
             }
             x = dy_from(dz, x, dp);
         }
         if (qv != qt && q >= qv) x = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(&dst[row * LDP + 4 * q]) = x;
+        if (full) *reinterpret_cast<float4 *>(&dst[ldsw + (unsigned)(i * RPI * LDP)]) = x;
+        else *reinterpret_cast<float4 *>(&dst[row * LDP + 4 * q]) = x;
     };
 
     int64_t tile = blockIdx.x;
@@ -217,8 +260,11 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) fetch_item(tile, 0, i);
     __syncthreads();                                                // table complete (and the W regions released)
+    {
+        const Consts c0 = chunk_consts(0);
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) stage_item(cur, tile, 0, i);
+        for (int i = 0; i < A_IT; ++i) stage_item(cur, tile, 0, i, c0);
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         if (NCH > 1) fetch_item(tile, 1, i); else fetch_item(tile + G, 0, i);
@@ -248,6 +294,13 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
             // the LDS / global operations to their k block: without them the compiler hoists every read of the chunk to its
             // top (TM x 8 x 4 registers: spills) and sinks the staging behind the last MFMA, where both waves of a SIMD
             // would do it at the same time with the matrix pipe idle.
+            Consts cc;
+            if (HOIST && is_full(c1)) cc = chunk_consts(c1);       // (the table is read-only after the first barrier)
+            // staging item i of the next chunk rides behind k block slot(i): spread over the chunk's k blocks, so that the
+            // vector work of one item sits in the shadow of eight MFMAs instead of queueing behind the previous item's
+            constexpr int dummy_n = 0; (void)dummy_n;
+            const int n1 = (BM * QT(c1) + NT - 1) / NT;            // items of the chunk being staged (static after unrolling)
+            const int step = kbs / n1 > 0 ? kbs / n1 : 1;
             float4 a[ADB ? 2 : 1][TM];
             if (ADB) {
 #pragma unroll
@@ -266,12 +319,11 @@ __global__ __launch_bounds__(64 * NCB * RS) void regw_nt_kernel(const RegwArgs g
 #pragma unroll
                         for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const float4 *>(ap + i * 32 * LDP + 8 * kb);
                     }
-                    // staging item i of the next chunk rides behind k block i (the last items share the last block)
 #pragma unroll
                     for (int i = 0; i < A_IT; ++i) {
-                        const int slot = i < kbs ? i : kbs - 1;
+                        const int slot = i * step < kbs ? i * step : kbs - 1;
                         if (slot == kb) {
-                            stage_item(nxt, t1, c1, i);
+                            stage_item(nxt, t1, c1, i, cc);
                             fetch_item(t2, c2, i);
                         }
                     }
@@ -572,67 +624,108 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     // Pooled dZ: NT % QA == 0 is required by the host (every item of a thread sits in the same channel quad) and the chunk
     // lies inside one pooling group (BP <= PKP, chunks aligned to BP): one (dZp, arg) quad per thread and chunk.
+    //
+    // Addresses: a chunk's rows start at a WAVE-UNIFORM base (p0: scalar arithmetic); what a lane adds -- row * pitch + 4 q of
+    // its items -- never changes, so it lives in ITA + ITB registers (one each where NT % QA == 0 / NT % QB == 0: the items of a
+    // thread are then whole row steps apart and the step folds into the base) instead of being re-derived per request
+    // (~25 vector instructions each: round-4 ablation, the requests alone were 11 - 19 % of these kernels).
+    constexpr bool A_INV = NT % QA == 0, B_INV = NT % QB == 0;
+    constexpr int RPA = NT / QA, RPB = NT / QB;                    // row steps (A_INV / B_INV)
+    unsigned offA[A_INV ? 1 : ITA], ldsA[A_INV ? 1 : ITA], q4A[A_INV ? 1 : ITA], offB[B_INV ? 1 : ITB], ldsB[B_INV ? 1 : ITB], q4B[B_INV ? 1 : ITB];
+#pragma unroll
+    for (int i = 0; i < (A_INV ? 1 : ITA); ++i) {
+        const int idx = t + NT * i, row = idx / QA, q = idx - row * QA;
+        offA[i] = (unsigned)row * (unsigned)g.ldy + 4u * q;
+        ldsA[i] = (unsigned)row * LDA + 4u * q;
+        q4A[i] = 4u * q;
+    }
+#pragma unroll
+    for (int i = 0; i < (B_INV ? 1 : ITB); ++i) {
+        const int idx = t + NT * i, row = idx / QB, q = idx - row * QB;
+        offB[i] = (unsigned)row * (unsigned)g.ldx + 4u * q;
+        ldsB[i] = (unsigned)row * LDB + 4u * q;
+        q4B[i] = 4u * q;
+    }
+    const unsigned qa4 = 4u * (unsigned)(t % QA);                  // (A_INV: the thread's channel quad)
+    // item i of a chunk: lane part of its global offset / of its LDS offset, and whether its row lies inside `rows` rows
+    auto a_off = [&](int i) { return A_INV ? offA[0] + (unsigned)(i * RPA) * (unsigned)g.ldy : offA[i]; };
+    auto a_lds = [&](int i) { return A_INV ? ldsA[0] + (unsigned)(i * RPA * LDA) : ldsA[i]; };
+    auto a_live = [&](int i, int rows) { return A_INV ? (int)(t / QA) + i * RPA < rows : ldsA[i] < (unsigned)rows * LDA; };
+    auto b_off = [&](int i) { return B_INV ? offB[0] + (unsigned)(i * RPB) * (unsigned)g.ldx : offB[i]; };
+    auto b_lds = [&](int i) { return B_INV ? ldsB[0] + (unsigned)(i * RPB * LDB) : ldsB[i]; };
+    auto b_live = [&](int i, int rows) { return B_INV ? (int)(t / QB) + i * RPB < rows : ldsB[i] < (unsigned)rows * LDB; };
+    auto rows_of = [&](int64_t p0) { const int64_t left = p_end - p0; return (int)(left < 0 ? 0 : (left < BP ? left : BP)); };
     auto fetch = [&](int64_t p0) {
+        const int rows = rows_of(p0);                              // uniform; < BP only in the last chunk of the last workgroup
+        const int64_t pb = rows > 0 ? p0 : p_begin;                // past the end: every item is dead and re-reads a valid row
+        const float *yb = g.Y + (size_t)pb * (unsigned)g.ldy, *zb = g.dZ + (size_t)pb * (unsigned)g.ldy;    // (ldz == ldy: host)
+        const float *xb = g.X + (size_t)pb * (unsigned)g.ldx;
 #pragma unroll
         for (int i = 0; i < ITA; ++i) {
-            const int idx = t + NT * i, row = idx / QA, q = idx - row * QA;
-            const int64_t p = p0 + row;
-            const bool v = row < BP && p < p_end;
-            const int64_t pc = v ? p : p_begin;                    // a dead item re-reads a valid row (zeroed / dumped when staged)
-            raw.y[i] = ld4(g.Y + row_off(pc, g.ldy) + 4 * q);
-            if (!POOLED) raw.z[POOLED ? 0 : i] = ld4(g.dZ + row_off(pc, g.ldz) + 4 * q);
+            const unsigned o = a_live(i, rows) ? a_off(i) : (A_INV ? qa4 : 0u);    // a dead item reads row 0 of the chunk (zeroed / dumped when staged)
+            raw.y[i] = ld4(yb + o);
+            if (!POOLED) raw.z[POOLED ? 0 : i] = ld4(zb + o);
         }
         if (POOLED) {
-            const int q = t % QA;
-            const int64_t grp = (p0 < p_end ? p0 : p_begin) / (PKP > 0 ? PKP : 1);
-            raw.z[0] = ld4(g.dZp + row_off(grp, g.ldo) + 4 * q);
-            raw.a[0] = ld4i(g.arg + row_off(grp, g.ldo) + 4 * q);
+            const size_t go = (size_t)(pb / (PKP > 0 ? PKP : 1)) * (unsigned)g.ldo;
+            raw.z[0] = ld4(g.dZp + go + qa4);
+            raw.a[0] = ld4i(g.arg + go + qa4);
         }
 #pragma unroll
-        for (int i = 0; i < ITB; ++i) {
-            const int idx = t + NT * i, row = idx / QB, q = idx - row * QB;
-            const int64_t p = p0 + row;
-            const bool v = row < BP && p < p_end;
-            raw.x[i] = ld4(g.X + row_off(v ? p : p_begin, g.ldx) + 4 * q);
-        }
+        for (int i = 0; i < ITB; ++i) raw.x[i] = ld4(xb + (b_live(i, rows) ? b_off(i) : 0u));
     };
+    // The BatchNorm-backward coefficient rows of the thread's channel quad never change where A_INV holds: read from the table
+    // once (behind the first barrier), likewise the input's BatchNorm constants where B_INV holds.
+    DyParams dpk;
+    float4 xk_mu, xk_sc, xk_be;
     // (straight-line on purpose: an early return or a uniform branch around the staging would put it into basic blocks of
     // its own, and the scheduler could not slide its VALU work between the MFMAs of the position pairs)
     auto stage_a = [&](float *Ad, int64_t p0, int i) {
-        const int idx = t + NT * i, row = idx / QA, q = idx - row * QA;
-        const DyParams dp = dy_params_tab(ctab, MB * 32, 4 * q, true);
+        const int rows = rows_of(p0);
+        const bool live = a_live(i, rows);
+        const unsigned lo = a_lds(i);
+        const DyParams dp = A_INV ? dpk : dy_params_tab(ctab, MB * 32, (int)q4A[A_INV ? 0 : i], true);
         float4 dz = raw.z[POOLED ? 0 : i];
         if (POOLED) {
             const int4 a = raw.a[0];
-            const int kk = (int)((p0 + row) & (int64_t)(PKP - 1));
+            const int kk = (int)((unsigned)p0 & (unsigned)(PKP - 1)) + (int)(t / QA) + i * RPA;    // the chunk lies inside one group
             dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f;
             dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
         }
         float4 v = dy_from(dz, raw.y[i], dp);
-        if (!(p0 + row < p_end)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>((BP * QA % NT == 0 || row < BP) ? &Ad[row * LDA + 4 * q] : &dump[4 * t]) = v;
+        if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>((BP * QA % NT == 0 || lo < (unsigned)(BP * LDA)) ? &Ad[lo] : &dump[4 * t]) = v;
         if (BIAS) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
     };
     auto stage_b = [&](float *Bd, int64_t p0, int i) {
-        const int idx = t + NT * i, row = idx / QB, q = idx - row * QB;
+        const int rows = rows_of(p0);
+        const bool live = b_live(i, rows);
+        const unsigned lo = b_lds(i);
         float4 x = raw.x[i];
         if (XACT) {
-            const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]);
-            const float4 sc = *reinterpret_cast<const float4 *>(&xtab[NB * 32 + 4 * q]);
-            const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * NB * 32 + 4 * q]);
+            const unsigned q4 = q4B[B_INV ? 0 : i];
+            const float4 mu = B_INV ? xk_mu : *reinterpret_cast<const float4 *>(&xtab[q4]);
+            const float4 sc = B_INV ? xk_sc : *reinterpret_cast<const float4 *>(&xtab[NB * 32 + q4]);
+            const float4 be = B_INV ? xk_be : *reinterpret_cast<const float4 *>(&xtab[2 * NB * 32 + q4]);
             x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
             x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
             x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
             x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
         }
-        if (!(p0 + row < p_end)) x = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>((BP * QB % NT == 0 || row < BP) ? &Bd[row * LDB + 4 * q] : &dump[4 * t]) = x;
+        if (!live) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>((BP * QB % NT == 0 || lo < (unsigned)(BP * LDB)) ? &Bd[lo] : &dump[4 * t]) = x;
     };
 
     float *Ac = As0, *An = As1, *Bc = Bs0, *Bn = Bs1;
     if (p_begin < p_end) {
         fetch(p_begin);
         __syncthreads();                                            // tables and the zeroed buffers
+        if (A_INV) dpk = dy_params_tab(ctab, MB * 32, (int)qa4, true);
+        if (B_INV && XACT) {
+            xk_mu = *reinterpret_cast<const float4 *>(&xtab[q4B[0]]);
+            xk_sc = *reinterpret_cast<const float4 *>(&xtab[NB * 32 + q4B[0]]);
+            xk_be = *reinterpret_cast<const float4 *>(&xtab[2 * NB * 32 + q4B[0]]);
+        }
 #pragma unroll
         for (int i = 0; i < ITA; ++i) stage_a(Ac, p_begin, i);
 #pragma unroll
@@ -785,6 +878,7 @@ int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
     static const int min_rows = wide_env("PN2_WIDE_WGRAD_MIN_ROWS", 131072);
     if (!on || P < min_rows || x_affine == nullptr || ldy != ((M + 3) & ~3) || ldx != ((N + 3) & ~3)) return PN2_EUNSUPPORTED;
     if (!dZ && (Kpool <= 0 || P % Kpool != 0)) return PN2_EUNSUPPORTED;
+    if (dZ && ldz != ldy) return PN2_EUNSUPPORTED;                 // (one lane offset serves Y and dZ)
     WgradArgs g{};
     g.Y = Y; g.ldy = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.coef = coef; g.X = X; g.ldx = ldx;
     g.x_aff = x_affine; g.dW = dW; g.lddw = lddw; g.dbias = dbias; g.P = P; g.M = M; g.N = N; g.lc = lc; g.ws = workspace;

@@ -29,8 +29,22 @@ def dump(names):
         v = v[v.sum(1) > 0]
         if not len(v):
             continue
-        tot = v.sum(1).mean()
-        print("   wave %d  %8.0f cycles: " % (w, tot) + "  ".join("%s %4.1f%%" % (n, 100 * x / tot) for n, x in zip(names, v.mean(0)) if x > 0))
+        tot = v[:, :6].sum(1).mean()
+        ghz = (v[:, 6] / np.maximum(v[:, 7], 1)).mean() * 0.1          # shader cycles per 100 MHz tick
+        print("   wave %d  %8.0f cycles (%.0f us at the %.2f GHz it held): " % (w, tot, v[:, 7].mean() / 100.0, ghz)
+              + "  ".join("%s %4.1f%%" % (n, 100 * x / tot) for n, x in zip(names, v.mean(0)[:6]) if x > 0))
+
+
+def dump_abs():
+    buf = (ctypes.c_ulonglong * (64 * 8 * 4))()
+    raw.pn2_debug_stamps_abs(buf, 64 * 8 * 4)
+    a = np.array(buf, dtype=np.float64).reshape(64, 8, 4) / 100.0          # us
+    t0 = a[:, :, 0].min()
+    a -= t0
+    print("   absolute (us after the first wave's entry; min / median / max over 64 workgroups x 8 waves): entry %.1f/%.1f/%.1f  loop start %.1f/%.1f/%.1f"
+          "  loop end %.1f/%.1f/%.1f  exit %.1f/%.1f/%.1f" % tuple(f(a[:, :, i]) for i in range(4) for f in (np.min, np.median, np.max)))
+    print("   loop end by wave (median over workgroups): " + " ".join("%.1f" % np.median(a[:, w, 2]) for w in range(8)))
+    print("   workgroup exit (max over its waves), sorted: " + " ".join("%.0f" % x for x in np.sort(a[:, :, 3].max(1))))
 
 
 for P, Cl, Cp, Kp in [(1048576, 128, 96, 128), (1048576, 96, 64, 0), (524288, 128, 64, 64), (524288, 64, 64, 0)]:
@@ -48,11 +62,18 @@ for P, Cl, Cp, Kp in [(1048576, 128, 96, 128), (1048576, 96, 64, 0), (524288, 12
         assert lib.pn2_conv1x1_bwd(*dz, p(Y), Cl, p(coef), p(Wt), Cp, p(Yp), Cp, p(affp), p(dX), Cp, p(red), p(dW), Cp, P, Cl, Cp, None, st) == 0
     print("bwd", (P, Cl, Cp, Kp))
     dump(["finish", "fetch", "barrier1", "compute", "barrier2", "", "", ""])
+    dump_abs()
     del Y, Yp, dX
 for P, K, N in [(1048576, 96, 128), (1048576, 64, 96)]:
     X = rnd(P, K); W = rnd(N, K); b = rnd(N); Y = torch.empty(P, N, device=dev)
     stats = torch.zeros(16 * N, device=dev, dtype=torch.float64); aff = affine(K)
     for _ in range(3):
         assert lib.pn2_conv1x1_fwd(p(X), K, p(aff), p(W), K, p(b), p(Y), N, P, K, N, p(stats), None, None, st) == 0
-    print("fwd", (P, K, N))
+    import time
+    torch.cuda.synchronize(); t_0 = time.perf_counter()
+    for _ in range(20):
+        lib.pn2_conv1x1_fwd(p(X), K, p(aff), p(W), K, p(b), p(Y), N, P, K, N, p(stats), None, None, st)
+    torch.cuda.synchronize()
+    print("fwd", (P, K, N), "%.1f us per launch, 20 back to back" % ((time.perf_counter() - t_0) / 20 * 1e6))
     dump(["transform", "fetch", "mfma", "epilogue(last)", "epilogue", "", "", ""])
+    dump_abs()
