@@ -62,6 +62,9 @@ def algorithmic_work(name, a):
         P, M, N = a[15], a[16], a[17]
         dense = a[0] is not None
         return 2.0 * P * M * N, 4.0 * (P * M * (2 if dense else 1) + P * N + M * N)
+    if name == "pn2_conv1x1_wgrad_cf":       # dZ ldz coef X ldx W ldw bias mom dW lddw P M N: closed-form BatchNorm terms, Y not read
+        P, M, N = a[11], a[12], a[13]          # (booked with the bytes THIS formulation needs, not the general one's P*M more)
+        return 2.0 * P * M * N, 4.0 * (P * M + P * N + M * N)
     if name == "pn2_conv1x1_bwd_pair":       # dgrad + wgrad of one layer behind ONE grid: each body reads its own operands
         P, Co, Ci = a[22], a[23], a[24]
         dense, masked = a[0] is not None, a[11] is not None
@@ -588,6 +591,11 @@ def main():
                     name = "pn2_conv1x1_wgrad"
                 if name == "pn2_ball_query_ws":        # the same query (same leading arguments) with caller scratch
                     name = "pn2_ball_query"
+                if name == "pn2_conv1x1_wgrad_cf":     # a first layer's weight gradient (closed-form BatchNorm terms): same family
+                    fl, by = algorithmic_work(name, a)
+                    d = agg.setdefault("pn2_conv1x1_wgrad", [0.0, 0, 0.0, 0.0])
+                    d[0] += ms; d[1] += 1; d[2] += fl; d[3] += by
+                    continue
                 split = name == "pn2_conv1x1_bwd_pair_split"     # the pair entry point ran as dgrad + wgrad launches: booked half / half
                 fl, by = algorithmic_work("pn2_conv1x1_bwd_pair" if split else name, a)
                 if split:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 8
+#define PN2_ABI_VERSION 9
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -313,6 +313,20 @@ int pn2_conv1x1_wgrad_ws(const float *dZ, int ldz, const float *dZp, int ldo, co
                          int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                          const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,
                          const pn2_bn_coef_lazy *coef_lazy, float *workspace, pn2_stream_t stream);
+
+/* Weight gradient of a FIRST layer (C_in = N <= 15, C_out = M a multiple of 16, <= 128) whose data gradient nobody needs, from dZ
+ * and the input rows alone (ABI 9).  The BatchNorm-backward terms of dY = c0*dZ + q1*(y - mean) + q0 (model/pointnet_util.py:195-197,
+ * backward) are linear in sums the forward already fixed: with s = sum_p x_p, S = sum_p x_p x_p^T and y_p = W x_p + b,
+ *     dW[c][j] += c0[c] * sum_p dZ[p,c] x[p,j] + q1[c] * ((W S)[c][j] + (b[c] - mean[c]) * s[j]) + q0[c] * s[j]
+ * -- Y is never read (half the bytes of pn2_conv1x1_wgrad on these layers); s and S are accumulated by the same pass (fp64 across
+ * workgroups) and the closed-form part is added once, by the workgroup that finishes last.  `coef` as for pn2_conv1x1_wgrad
+ * (rows c0, q1, q0, mean of pitch round4(M); realised from `coef_lazy` when given); W [M, N] (pitch ldw) and bias [M] are the
+ * layer's parameters; `scratch`: pn2_conv1x1_wgrad_cf_scratch_bytes() bytes, 16-byte aligned, ZEROED by the caller (left dirty).
+ * PN2_EUNSUPPORTED for other shapes: use pn2_conv1x1_wgrad. */
+int64_t pn2_conv1x1_wgrad_cf_scratch_bytes(void);
+int pn2_conv1x1_wgrad_cf(const float *dZ, int ldz, const float *coef, const float *X, int ldx, const float *W, int ldw,
+                         const float *bias, void *scratch, float *dW, int lddw, int64_t P, int M, int N,
+                         const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
 
 /* pn2_conv1x1_dgrad followed by pn2_conv1x1_wgrad of ONE layer (same dZ / pooled pair, Y, coef; X = the layer's input, i.e.
  * prev_Y wherever there is a previous layer, with x_affine = prev_affine) as one call: on the few-row and mid-size layers

@@ -50,6 +50,8 @@ SIGNATURES = {
     "pn2_conv1x1_wgrad_workspace_bytes": (_i64, [_i64, _i, _i, _i]),
     "pn2_conv1x1_wgrad_ws": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp,
                                   _i64, _i, _i, _vp, _vp, _vp]),
+    "pn2_conv1x1_wgrad_cf_scratch_bytes": (_i64, []),
+    "pn2_conv1x1_wgrad_cf": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
     "pn2_conv1x1_bwd_pair": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                                   _i64, _i, _i, _vp, _vp]),
     "pn2_res_supported": (_i, [_i64, _i, _i]),
@@ -71,7 +73,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PN2_EUNSUPPORTED = -3            # include/pn2.h
 PN2_OK_SPLIT = 1                 # pn2_conv1x1_bwd_pair: done as two launches
 DWX_REPLICAS = 32        # PN2_DWX_REPLICAS of include/pn2.h
@@ -131,6 +133,7 @@ class _Timed:
         fn = getattr(_raw, name)
         if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes",
                                                    "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_bwd_res_supported", "pn2_conv1x1_wgrad_workspace_bytes",
+                                                   "pn2_conv1x1_wgrad_cf_scratch_bytes",
                                                    "pn2_ball_query_workspace_bytes"):
             return fn
 

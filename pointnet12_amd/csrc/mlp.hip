@@ -1575,6 +1575,149 @@ int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
                    int64_t P, int M, int N, LazyCoef lc, hipStream_t s, float *workspace = nullptr);
 int64_t pn2_wide_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled);
 
+namespace {
+
+// ----------------------------------------------------------------------------------------------- first-layer dW, closed form
+// The weight gradient of a FIRST layer (C_in = N <= 15: the 3 + D grouped input columns) whose data gradient nobody needs, from
+// dZ and the 48-byte input rows alone.  The BatchNorm-backward terms of dY = c0 dZ + q1 (y - mean) + q0 are linear in sums the
+// forward already fixed: with s = sum_p x_p, S = sum_p x_p x_p^T and y_p = W x_p + b,
+//     dW[c][j] = c0[c] sum_p dZ[p,c] x[p,j]  +  q1[c] ((W S)[c][j] + (b[c] - mean[c]) s[j])  +  q0[c] s[j]
+// so Y is not read at all: 872 of the 962 MB per MSG-SemSeg step that the general skinny kernel moved for sa1's three first
+// layers were dZ + Y.  Both sums are v_mfma_f32_16x16x4_f32 products straight from the loaded registers (lane = 16 k + n holds
+// dZ[p0 + k][c0 + n] resp. x[p0 + k][n]: the A operand of S = X^T X is the SAME register as its B operand), column 15 of the
+// row operand is a constant 1, so S[15][j] = s[j]; the S partials leave the fp32 accumulators for fp64 every 64 rows.  The
+// closed-form part needs the COMPLETE moments: the workgroup that draws the last ticket adds it, once, in fp64.
+typedef float cf_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CF_REPL = 8;                                        // scratch replicas: 1 / 8 of the workgroups add into each
+
+template <int NB, int U>                                          // 16-channel blocks: M = 16 NB; 4-row groups in flight per wave
+__global__ __launch_bounds__(256) void wgrad_first_cf_kernel(const float *__restrict__ dZ, int ldz, const float *__restrict__ coef, int ldc,
+                                                             const float *__restrict__ X, int ldx, int64_t P, int N,
+                                                             const float *__restrict__ W, int ldw, const float *__restrict__ bias,
+                                                             float *__restrict__ part, double *__restrict__ mom, unsigned *__restrict__ ticket,
+                                                             float *__restrict__ dW, int lddw, LazyCoef lc) {
+    constexpr int M = 16 * NB;
+    __shared__ float fold[4][NB][256];                            // [wave][block][lane * 4 + r]
+    __shared__ double sfold[4][256];
+    lazy_coef_prologue(lc);                                       // consumer-side BatchNorm backward (bn_tail.h)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, k = lane >> 4, n = lane & 15;
+    const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
+    const bool xin = n < N;
+    const float fill = n == 15 ? 1.f : 0.f;
+    const int nc = xin ? n : 0;                                   // pad lanes re-read column 0 (replaced by `fill`): never past a row
+    cf_f32x4 acc[NB], sacc = {0.f, 0.f, 0.f, 0.f};
+    double sd[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = cf_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t groups = (P + 3) >> 2;                          // 4 rows per MFMA
+    const int64_t stride = (int64_t)gridDim.x * 4 * U;
+    int rows64 = 0;
+    // Whole trips (U groups of 4 rows, all inside P) address everything as a WAVE-UNIFORM base (scalar arithmetic) plus one
+    // loop-invariant 32-bit lane offset per operand; only the last, ragged trip of the launch checks rows per lane.
+    const unsigned lo_z = (unsigned)k * (unsigned)ldz + (unsigned)(NB * n), lo_x = (unsigned)k * (unsigned)ldx + (unsigned)nc;
+    const int64_t full_groups = P >> 2;
+    auto load_a = [&](const float *zr, float (&av)[NB]) {
+        if (NB == 4 || NB == 8) {
+#pragma unroll
+            for (int h = 0; h < NB / 4; ++h) {
+                const float4 q4 = ld4(zr + 4 * h);
+                av[4 * h] = q4.x; av[4 * h + 1] = q4.y; av[(4 * h + 2) % NB] = q4.z; av[(4 * h + 3) % NB] = q4.w;
+            }
+        } else if (NB == 2 || NB == 6) {
+#pragma unroll
+            for (int h = 0; h < NB / 2; ++h) {
+                const float2 q2 = *reinterpret_cast<const float2 *>(zr + 2 * h);
+                av[2 * h] = q2.x; av[(2 * h + 1) % NB] = q2.y;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) av[b] = zr[b];
+        }
+    };
+    for (int64_t g0 = ((int64_t)blockIdx.x * 4 + wave) * U; g0 < groups; g0 += stride) {
+        float a[U][NB], x[U];
+        // the lane's NB CONSECUTIVE channels NB n .. NB n + NB - 1 of row p0 + k (one 4 NB-byte request: whole rows per
+        // instruction, not 64-byte fragments of four rows); accumulator tile b then holds the channels NB i + b
+        if (g0 + U <= full_groups) {
+            const float *zb = dZ + (size_t)(g0 * 4) * (unsigned)ldz, *xb = X + (size_t)(g0 * 4) * (unsigned)ldx;     // uniform
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                load_a(zb + (size_t)(4 * u) * (unsigned)ldz + lo_z, a[u]);
+                const float xv = xb[(size_t)(4 * u) * (unsigned)ldx + lo_x];
+                x[u] = xin ? xv : fill;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t p = (g0 + u) * 4 + k;
+                const bool v = p < P;
+                load_a(v ? dZ + p * ldz + NB * n : zp, a[u]);     // (a dead row reads the zero page)
+                const float xv = (v ? X + p * ldx + nc : zp)[0];
+                x[u] = v ? (xin ? xv : fill) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][b], x[u], acc[b], 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u], x[u], sacc, 0, 0, 0);
+        }
+        rows64 += 4 * U;
+        if (rows64 >= 64) {                                       // the moment partials move to fp64 every 64 rows
+            rows64 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sd[r] += (double)sacc[r]; sacc[r] = 0.f; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sd[r] += (double)sacc[r];
+    // D[i][j] of a 16 x 16 tile sits in lane 16 (i / 4) + j, register i % 4: fold the four waves through LDS, then one set of
+    // atomics per workgroup into ITS replica of the scratch (CF_REPL replicas: 1 / 8 of the adders per address)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fold[wave][b][lane * 4 + r] = acc[b][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sfold[wave][lane * 4 + r] = sd[r];
+    __syncthreads();
+    const int rep = blockIdx.x % CF_REPL;
+    for (int e = t; e < NB * 256; e += 256) {
+        const int b = e >> 8, q = e & 255, l2 = q >> 2, r = q & 3, i = 4 * (l2 >> 4) + r, j = l2 & 15;
+        if (j >= N) continue;
+        atomicAdd(part + (rep * M + NB * i + b) * 16 + j, fold[0][b][q] + fold[1][b][q] + fold[2][b][q] + fold[3][b][q]);
+    }
+    {
+        const int q = t, l2 = q >> 2, r = q & 3, i = 4 * (l2 >> 4) + r, j = l2 & 15;
+        if (j < N && (i < N || i == 15)) atomicAdd(mom + rep * 256 + i * 16 + j, sfold[0][q] + sfold[1][q] + sfold[2][q] + sfold[3][q]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this thread's atomics are performed (tail_is_last_block)
+    if (!tail_is_last_block(ticket, gridDim.x)) return;
+    // ---- the last workgroup: replicas -> sums, c0 * (sum dZ x) + the closed-form terms, ONE atomic per element of dW
+    double *ms = sfold[0];                                        // S[i][j] (i < N) and s[j] = S[15][j], summed over the replicas
+    {
+        double v = 0.0;
+        for (int r2 = 0; r2 < CF_REPL; ++r2) v += ld_f64_device(mom + r2 * 256 + t);
+        __syncthreads();
+        ms[t] = v;
+        __syncthreads();
+    }
+    for (int e = t; e < M * 16; e += 256) {
+        const int c = e >> 4, j = e & 15;
+        if (j >= N) continue;
+        float a1 = 0.f;
+        for (int r2 = 0; r2 < CF_REPL; ++r2) a1 += __hip_atomic_load(part + (r2 * M + c) * 16 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double sj = ms[15 * 16 + j];
+        double ws = 0.0;
+        for (int i = 0; i < N; ++i) ws += (double)W[(int64_t)c * ldw + i] * ms[i * 16 + j];
+        const double c0c = coef[c], q1c = coef[ldc + c], q0c = coef[2 * ldc + c], muc = coef[3 * ldc + c];
+        atomicAdd(dW + (int64_t)c * lddw + j, (float)(c0c * (double)a1 + q1c * (ws + ((double)bias[c] - muc) * sj) + q0c * sj));
+    }
+    if (t == 0) *ticket = 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int pn2_conv1x1_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
@@ -1734,6 +1877,36 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
 }
 
 int64_t pn2_conv1x1_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled) { return pn2_wide_wgrad_workspace_bytes(P, M, N, pooled); }
+
+int64_t pn2_conv1x1_wgrad_cf_scratch_bytes(void) { return CF_REPL * (128 * 16 * (int64_t)sizeof(float) + 256 * (int64_t)sizeof(double)) + 16; }
+
+int pn2_conv1x1_wgrad_cf(const float *dZ, int ldz, const float *coef, const float *X, int ldx, const float *W, int ldw, const float *bias,
+                         void *scratch, float *dW, int lddw, int64_t P, int M, int N, const pn2_bn_coef_lazy *coef_lazy,
+                         pn2_stream_t stream) {
+    PN2_CHECK_ARG(dZ && coef && X && W && bias && scratch && dW && P > 0 && P < (1LL << 31) && M > 0 && N > 0 && lazy_coef_ok(coef_lazy, coef, M));
+    if (M % 16 != 0 || M > 128 || N > 15) return PN2_EUNSUPPORTED;
+    PN2_CHECK_ARG(ldz >= M && ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0 && ldx >= N && lddw >= N && ldw >= N &&
+                  (reinterpret_cast<uintptr_t>(scratch) & 15) == 0);
+    const LazyCoef lc = make_lazy_coef(coef_lazy);
+    double *mom = reinterpret_cast<double *>(scratch);                              // [CF_REPL][16][16]
+    float *part = reinterpret_cast<float *>(mom + CF_REPL * 256);                   // [CF_REPL][M][16]
+    unsigned *ticket = reinterpret_cast<unsigned *>(part + CF_REPL * 128 * 16);
+    static const int per_cu = pn2_env_int("PN2_CF_WGS_PER_CU", 2);
+    constexpr int U = 8;
+    int64_t grid = pn2_cdiv(P, 4 * U * 4 * 4);                     // >= 4 trips per wave
+    if (grid > (int64_t)per_cu * pn2_num_cus()) grid = (int64_t)per_cu * pn2_num_cus();
+    if (grid < 1) grid = 1;
+    hipStream_t s = pn2_s(stream);
+    const int ldc = round4(M);
+#define PN2_CF_CASE(NBV)                                                                                                               \
+    case NBV: hipLaunchKernelGGL((wgrad_first_cf_kernel<NBV, U>), dim3((unsigned)grid), dim3(256), 0, s, dZ, ldz, coef, ldc, X, ldx, P, N, \
+                                 W, ldw, bias, part, mom, ticket, dW, lddw, lc); break;
+    switch (M / 16) {
+        PN2_CF_CASE(1) PN2_CF_CASE(2) PN2_CF_CASE(3) PN2_CF_CASE(4) PN2_CF_CASE(5) PN2_CF_CASE(6) PN2_CF_CASE(7) PN2_CF_CASE(8)
+    }
+#undef PN2_CF_CASE
+    return pn2_launch_status();
+}
 
 int pn2_conv1x1_wgrad_ws(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *X, int ldx,
                          const float *x_affine, float *dW, int lddw, float *dbias, int64_t P, int M, int N,

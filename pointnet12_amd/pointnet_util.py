@@ -516,6 +516,9 @@ FUSED_BN_TAILS = os.environ.get("PN2_FUSED_BN_TAILS", "0") == "1"
 LAZY_BN = os.environ.get("PN2_LAZY_BN", "1") == "1"
 # dgrad + wgrad of a layer as one call / one launch on the few-row and mid-size layers (pn2_conv1x1_bwd_pair); 0: A/B runs
 BWD_PAIR = os.environ.get("PN2_BWD_PAIR_CALL", "1") == "1"
+# first-layer weight gradients without a data gradient read dZ and the input rows only (closed-form BatchNorm-backward terms);
+# 0: the general kernel, which reads Y as well (A/B runs)
+WGRAD_CF = os.environ.get("PN2_WGRAD_CF", "1") != "0"
 # the last layer of a pooled MLP records the per-group extrema in its GEMM epilogue (pn2_conv1x1_fwd_pool); 0: A/B runs
 POOL_IN_EPILOGUE = os.environ.get("PN2_POOL_EPILOGUE", "1") == "1"
 # narrow first layers: gather + first conv in one launch (pn2_group_conv_fwd); 0: pn2_group then the GEMM (A/B runs)
@@ -881,6 +884,16 @@ class _SharedMLP(torch.autograd.Function):
                         _check(lib.pn2_conv1x1_dgrad(*c_dz, *c_pool, c_y, ldy, _p(coef), w_l, w_ld, None, 0, None, c_dx,
                                                      ldx, None, rn, co, ci, None, coef_lazy, st), "pn2_conv1x1_dgrad")
                     coef_lazy = None                            # filled: the weight gradient below reads it
+                if (WGRAD_CF and l == 0 and training and not need_dx and not pooled and ci <= 15 and co % 16 == 0 and co <= 128
+                        and chunk == P):
+                    # first layer without a data gradient: the BatchNorm-backward terms of dY in closed form from the input rows'
+                    # first and second moments -- the pass reads dZ and the rows, not Y (pn2_conv1x1_wgrad_cf, include/pn2.h)
+                    scratch = _zeros_small(int(lib.pn2_conv1x1_wgrad_cf_scratch_bytes()), dev)
+                    _check(lib.pn2_conv1x1_wgrad_cf(c_dz[0], c_dz[1], _p(coef), c_x, ldx, _p(_contig_weight(Ws[l])), ci,
+                                                    _p(flat[7 * l + 1]), _p(scratch), _p(dW), ci, rn, co, ci, coef_lazy, st),
+                           "pn2_conv1x1_wgrad_cf")
+                    coef_lazy = None
+                    continue
                 if side is not None and chunk == P:
                     # the weight gradient on the companion stream: ordered behind everything issued so far on this stream (the
                     # coefficients, dZ), joined once at the end of this backward

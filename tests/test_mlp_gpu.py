@@ -311,3 +311,62 @@ def test_pool_in_gemm_epilogue_equals_the_pooling_pass(dev, P, pool, chans):
     assert rows_beyond <= 8, rows_beyond
     for a, b in zip([xa] + res[True][2], [xb] + res[False][2]):
         assert float((a - b).norm()) <= 1e-2 * float(b.norm()), float((a - b).norm()) / float(b.norm())
+
+
+@pytest.mark.parametrize("P,pool,chans", [(262144, 64, [9, 64, 64, 128]), (131072, 32, [9, 32, 32, 64]), (65536, 16, [3, 32, 64]),
+                                          (40001, 0, [15, 64, 32]), (8192, 0, [12, 96]), (100000, 0, [6, 128, 64]), (1000, 0, [9, 16])])
+def test_first_layer_weight_gradient_closed_form(dev, P, pool, chans, monkeypatch):
+    """Round 4 (ABI 9, pn2_conv1x1_wgrad_cf): where the input of a shared MLP needs no gradient, its first
+    layer's weight gradient is formed from dZ and the input rows alone -- the BatchNorm-backward terms of dY in closed form from
+    the rows' first and second moments -- instead of reading Y as well.  Same layer, same seeds: the closed form against the
+    general kernel (PN2_WGRAD_CF = 0) and both against an fp64 statement of the op; every other gradient must not move at all
+    beyond the atomics' run-to-run order."""
+    gen = torch.Generator().manual_seed(P + chans[0])
+    c_in = chans[0]
+    ld = (c_in + 3) & ~3
+    rows = torch.zeros(P, ld)
+    rows[:, :c_in] = torch.randn(P, c_in, generator=gen) * torch.linspace(0.3, 2.0, c_in) + torch.linspace(-1.0, 3.0, c_in)   # non-zero means
+    convs = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])]).to(dev)
+    bns = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]]).to(dev)
+    for bn in bns:
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.uniform_(-0.5, 0.5)
+    x = rows.to(dev)
+    gw = None
+    got = {}
+    for cf in (True, False):
+        monkeypatch.setattr(U, "WGRAD_CF", cf)
+        for p in list(convs.parameters()) + list(bns.parameters()):
+            p.grad = None
+        for bn in bns:
+            bn.reset_running_stats()
+        calls = []
+        lib = _lib.load()
+        orig = lib.pn2_conv1x1_wgrad_cf
+        monkeypatch.setattr(lib, "pn2_conv1x1_wgrad_cf", lambda *a: (calls.append(1), orig(*a))[1])
+        out = U.shared_mlp(x, c_in, convs, bns, pool, True)
+        if gw is None:
+            gw = torch.randn(out.shape, generator=gen).to(dev)
+        (out * gw).sum().backward()
+        monkeypatch.setattr(lib, "pn2_conv1x1_wgrad_cf", orig)
+        assert len(calls) == (1 if cf else 0)
+        got[cf] = [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())]
+    x64 = rows[:, :c_in].to(dev).double()
+    c64 = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])]).to(dev).double()
+    b64 = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]]).to(dev).double()
+    c64.load_state_dict({k: v.double() for k, v in convs.state_dict().items()})
+    b64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bns.state_dict().items()})
+    (torch_mlp(x64, c64, b64, pool, True, torch.float64) * gw.double()).sum().backward()
+    ref = c64[0].weight.grad.reshape(chans[1], c_in)
+    a, b = got[True][0].reshape(chans[1], c_in).double(), got[False][0].reshape(chans[1], c_in).double()
+    scale = float(ref.abs().max())
+    ea, eb = float((a - ref).abs().max()) / scale, float((b - ref).abs().max()) / scale
+    print("first-layer dW: closed form %.2e, general kernel %.2e of max |dW| from fp64" % (ea, eb))
+    # the closed form takes fewer roundings (no per-row fp32 dY): it must be at least as close to fp64 as the general kernel, up to
+    # the decision flips both share (same dZ) -- and never further than 3e-5 of the tensor's max beyond it
+    assert ea <= eb + 3e-5
+    assert float((a - b).abs().max()) / scale <= max(3e-5, 2 * eb)
+    names = [n for n, _ in list(convs.named_parameters()) + list(bns.named_parameters())]
+    for n, u, v in zip(names[1:], got[True][1:], got[False][1:]):
+        s_ = max(float(v.abs().max()), 1e-9)
+        assert float((u - v).abs().max()) <= 2e-5 * s_, n                # nothing else reads the changed pass's output
