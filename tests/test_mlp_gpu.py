@@ -314,7 +314,8 @@ def test_pool_in_gemm_epilogue_equals_the_pooling_pass(dev, P, pool, chans):
 
 
 @pytest.mark.parametrize("P,pool,chans", [(262144, 64, [9, 64, 64, 128]), (131072, 32, [9, 32, 32, 64]), (65536, 16, [3, 32, 64]),
-                                          (40001, 0, [15, 64, 32]), (8192, 0, [12, 96]), (100000, 0, [6, 128, 64]), (1000, 0, [9, 16])])
+                                          (40001, 0, [15, 64, 32]), (8192, 0, [12, 96]), (100000, 0, [6, 128, 64]), (1000, 0, [9, 16]),
+                                          (5003, 0, [7, 48]), (5000, 0, [5, 80, 32]), (70, 0, [4, 112])])
 def test_first_layer_weight_gradient_closed_form(dev, P, pool, chans, monkeypatch):
     """Round 4 (ABI 9, pn2_conv1x1_wgrad_cf): where the input of a shared MLP needs no gradient, its first
     layer's weight gradient is formed from dZ and the input rows alone -- the BatchNorm-backward terms of dY in closed form from
