@@ -80,6 +80,27 @@ inline bool make_res_plan(int CI_T, ResPlan *out) {
     return true;
 }
 
+// The same deal for a 4-wave workgroup (two of them per CU: the narrow pairs whose LDS image fits twice): 2 CI_T units per wave,
+// every wave the same mix -- CI_T = 2: one dX tile + two quarters of a column each; CI_T = 1: two waves a dX tile, two waves
+// two quarters of the column.
+inline bool make_res_plan4(int CI_T, ResPlan *out) {
+    ResPlan p;
+    for (int w = 0; w < 8; ++w) { p.dx_rb[w] = p.dx_cj[w] = -1; p.dw_cj[w] = 0; p.dw_q0[w] = p.dw_q1[w] = 0; }
+    if (CI_T == 2) {
+        for (int w = 0; w < 4; ++w) {
+            p.dx_rb[w] = (signed char)(w & 1); p.dx_cj[w] = (signed char)(w >> 1);
+            p.dw_cj[w] = (signed char)(w >> 1); p.dw_q0[w] = (signed char)(2 * (w & 1)); p.dw_q1[w] = (signed char)(2 * (w & 1) + 2);
+        }
+    } else if (CI_T == 1) {
+        for (int w = 0; w < 2; ++w) { p.dx_rb[w] = (signed char)w; p.dx_cj[w] = 0; }
+        for (int w = 2; w < 4; ++w) { p.dw_cj[w] = 0; p.dw_q0[w] = (signed char)(2 * (w - 2)); p.dw_q1[w] = (signed char)(2 * (w - 2) + 2); }
+    } else {
+        return false;
+    }
+    *out = p;
+    return true;
+}
+
 extern __shared__ __attribute__((aligned(16))) float res_lds[];
 
 #ifdef PN2_STAMP
@@ -137,20 +158,20 @@ struct ResDy {
 // their MFMAs and waves 4-7 after theirs: the two waves of a SIMD (w and w + 4) sit in opposite phases, so one's
 // transform runs in the shadow of the other's matrix work instead of both queueing for the pipe and then both idling
 // it (single buffer: matrix pipe 43-57 % busy, the rest the lock-stepped transform / epilogue phases).
-template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF>
-__global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *__restrict__ Yp, int ldp,
+template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF, int NTHR = 512>
+__global__ __launch_bounds__(NTHR, 2) void bwd_res_kernel(ResDy dy, const float *__restrict__ Yp, int ldp,
                                                          const float *__restrict__ aff_p, const float *__restrict__ W, int ldw,
                                                          int64_t tiles, float *__restrict__ dX, int ldxo,
                                                          double *__restrict__ red_p, float *__restrict__ dW, int lddw,
                                                          ResPlan plan) {
     constexpr int Co = 32 * CO_T, Ci = 32 * CI_T, LDY = Co + 4, LDP = Ci + 4, QD = Co / 4, QP = Ci / 4;
-    constexpr int IT_D = RES_BM * QD / 512, IT_P = RES_BM * QP / 512;
-    static_assert(RES_BM * QD % 512 == 0 && RES_BM * QP % 512 == 0, "tiles must split evenly over 512 threads");
+    constexpr int IT_D = RES_BM * QD / NTHR, IT_P = RES_BM * QP / NTHR;
+    static_assert(RES_BM * QD % NTHR == 0 && RES_BM * QP % NTHR == 0, "tiles must split evenly over 512 threads");
     constexpr bool POOLED = POOL != 0;
     // 512 % QD == 0 (Co = 32, 64, 128): a thread's quads t + 512 i all sit in the same channel quad, RPI rows apart, so
     // the pooled operands (one row per GROUP) repeat: slot(i) = which of the NZ distinct (dZp, arg) quads quad i uses
-    constexpr int RPI = 512 / QD;
-    static_assert(!POOLED || 512 % QD == 0, "pooled variants need Co in {32, 64, 128}");
+    constexpr int RPI = NTHR / QD;
+    static_assert(!POOLED || NTHR % QD == 0, "pooled variants need Co in {32, 64, 128}");
     constexpr int NZ = !POOLED ? IT_D : (POOL == 2 && IT_D > 1 ? 2 : 1);
     auto slot = [](int i) { return POOL == 2 && IT_D > 1 ? (RPI * i) / 32 : 0; };
     static_assert(!DBUF || DEPTH == 1, "the double-buffered form keeps one register set");
@@ -165,11 +186,11 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     RABS(wave, 0)
     lazy_coef_prologue(dy.lc);                                     // consumer-side BatchNorm backward (bn_tail.h)
     // ---- one-time: W^T, coefficient table
-    for (int i = t; i < Co * Ci; i += 512) {
+    for (int i = t; i < Co * Ci; i += NTHR) {
         const int co = i / Ci, ci = i - co * Ci;
         Wt[ci * LDY + co] = W[(int64_t)co * ldw + ci];
     }
-    for (int i = t; i < 4 * Co; i += 512) tab[i] = dy.coef[i];
+    for (int i = t; i < 4 * Co; i += NTHR) tab[i] = dy.coef[i];
 
     // ---- this wave's share of every tile (fixed for the whole launch)
     const int dx_rb = plan.dx_rb[wave], dx_cj = plan.dx_cj[wave];
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     unsigned od[IT_D], og[NZ], kk[IT_D], op[IT_P];
 #pragma unroll
     for (int i = 0; i < IT_D; ++i) {
-        const int idx = t + 512 * i, row = idx / QD, q = idx - row * QD;
+        const int idx = t + NTHR * i, row = idx / QD, q = idx - row * QD;
         od[i] = (unsigned)row * (unsigned)dy.ld + 4u * q;
         kk[i] = 0;
         if (POOLED) {                                              // group of the row relative to the tile's first group
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     }
 #pragma unroll
     for (int i = 0; i < IT_P; ++i) {
-        const int idx = t + 512 * i, row = idx / QP, q = idx - row * QP;
+        const int idx = t + NTHR * i, row = idx / QP, q = idx - row * QP;
         op[i] = (unsigned)row * (unsigned)ldp + 4u * q;
     }
 
@@ -250,13 +271,13 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     // with every item -- they were 16 of the 23 ds_*_b128 a thread issues per tile of the 128 x 96 pair, all eight waves at
     // the same time with the matrix pipe idle (same-box A/B, round 4: 128 x 96 pooled 603 -> 593 us, 128 x 64 244 -> 236,
     // 64 x 64 162 -> 158).
-    constexpr bool DP_HOIST = 512 % QD == 0;
+    constexpr bool DP_HOIST = NTHR % QD == 0;
     DyParams dpk;
     auto finish_dy = [&](Regs &R, float *dst, int64_t tile) {
         const unsigned kbase = POOL == 1 ? (unsigned)(tile * RES_BM) & ((1u << dy.kshift) - 1u) : 0u;
 #pragma unroll
         for (int i = 0; i < IT_D; ++i) {
-            const int idx = t + 512 * i, row = idx / QD, q = idx - row * QD;
+            const int idx = t + NTHR * i, row = idx / QD, q = idx - row * QD;
             const DyParams dp = DP_HOIST ? dpk : dy_params_tab(tab, Co, 4 * q, true);
             float4 dz = R.z[POOLED ? slot(i) : i];
             if (POOLED) {
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void bwd_res_kernel(ResDy dy, const float *
     auto write_yp = [&](Regs &R) {
 #pragma unroll
         for (int i = 0; i < IT_P; ++i) {
-            const int idx = t + 512 * i, row = idx / QP, q = idx - row * QP;
+            const int idx = t + NTHR * i, row = idx / QP, q = idx - row * QP;
             *reinterpret_cast<float4 *>(&Yps[row * LDP + 4 * q]) = R.p[i];
         }
     };
@@ -453,7 +474,7 @@ inline size_t bwd_res_lds_bytes(int Co, int Ci, bool dbuf) {
     return sizeof(float) * ((size_t)Ci * (Co + 4) + (dbuf ? 2 : 1) * RES_BM * (Co + 4) + RES_BM * (Ci + 4) + 4 * Co);
 }
 
-template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF>
+template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF, int NTHR = 512>
 int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
                         double *red_p, float *dW, int lddw, hipStream_t s);
 
@@ -466,20 +487,31 @@ int launch_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const
     // (128x96 pooled 701 vs 676 us, 96x64 408 vs 385, 64x64 156 vs 136 -- profiles/r02_kernel_microbench.txt): the
     // transform did not hide under the partner wave's MFMAs, it only delayed this wave's own.
     constexpr int DEPTH = CO_T * CI_T <= 6 ? 2 : 1;
+    // Two 4-wave workgroups per CU instead of one of eight (round 4): the lock-stepped phases of one workgroup -- forming dY,
+    // issuing the next tile's requests, the barriers: 25 - 30 % of a tile with the matrix pipe idle (tools/stamp_res.py) -- then
+    // run beside the OTHER workgroup's products.  Where the LDS image fits twice and a 4-wave plan exists (C_in <= 64);
+    // PN2_RES_HALF=0: the 8-wave form (A/B runs).  Same-box A/B (us): 96 x 64 at 1 M rows 404 -> 385, 64 x 64 at 524 k 153 -> 142,
+    // 64 x 32 pooled at 524 k 89 -> 81, 32 x 32 at 524 k 66 -> 63; at 262 k rows the half-size workgroups' tails cost more
+    // (52 -> 55, 41 -> 47: not taken there); one register set (a second one: 142 -> 146, 81 -> 86); the step: within noise.
+    static const int half = [] { const char *e = getenv("PN2_RES_HALF"); return e ? atoi(e) : 1; }();
+    if constexpr (CI_T <= 2 && 2 * sizeof(float) * (32 * CI_T * (32 * CO_T + 4) + RES_BM * (32 * CO_T + 4) + RES_BM * (32 * CI_T + 4) + 128 * CO_T) <= 160 * 1024) {
+        if (half && tiles >= 32 * (int64_t)pn2_num_cus())           // (from 524 288 rows on: below, the two half-size workgroups' tails cost more)
+            return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, 1, false, 256>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
+    }
     return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, DEPTH, false>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
 }
 
-template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF>
+template <int CO_T, int CI_T, int POOL, bool MASKED, int DEPTH, bool DBUF, int NTHR>
 int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
                         double *red_p, float *dW, int lddw, hipStream_t s) {
     ResPlan plan;
-    if (!make_res_plan(CI_T, &plan)) return PN2_EINVAL;
+    if (!(NTHR == 256 ? make_res_plan4(CI_T, &plan) : make_res_plan(CI_T, &plan))) return PN2_EINVAL;
     const size_t lds = bwd_res_lds_bytes(32 * CO_T, 32 * CI_T, DBUF);
     static Pn2PerDevice raised;
-    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>), raised) != PN2_OK)
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF, NTHR>), raised) != PN2_OK)
         return PN2_ELAUNCH;
-    const int64_t cap = pn2_num_cus();                             // one 8-wave workgroup per CU
-    hipLaunchKernelGGL((bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF>), dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(512), lds, s, dy, Yp,
+    const int64_t cap = (int64_t)pn2_num_cus() * (512 / NTHR);     // one 8-wave workgroup per CU, or two of four waves
+    hipLaunchKernelGGL((bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF, NTHR>), dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(NTHR), lds, s, dy, Yp,
                        ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, plan);
     return pn2_launch_status();
 }
