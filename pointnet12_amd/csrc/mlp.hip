@@ -1398,6 +1398,15 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
         Affine a(aff, lda);
         const bool real = c < C;
         const float mu = real ? a.mean[c] : 0.f, is = real ? a.invstd[c] : 0.f;
+        // The normalised pre-BN value at the maximum, (y* - mean) * invstd, is recovered from the pooled OUTPUT where that is well
+        // conditioned: out = fma(y* - mean, gamma * invstd, beta) > 0, so x-hat = (out - beta) / gamma with an error of
+        // eps * |out| / |gamma| -- taken when |gamma| >= (1 + |beta|) / 4 (a fresh BatchNorm has gamma = 1, beta = 0; 3e-7 at worst).
+        // That drops the dependent gather Y[(g K + arg) ld + c]: one 64-byte sector per element (sixteen times the bytes) and
+        // a second memory round trip per trip -- 346 MB per MSG-SemSeg step by the PMC counters.  Channels with a small gamma
+        // keep the gather.
+        const float be = real ? a.beta[c] : 0.f, ga = real && is != 0.f ? a.scale[c] / is : 0.f;
+        const bool from_out = fabsf(ga) >= 0.25f * (1.f + fabsf(be));
+        const float rga = from_out ? 1.f / ga : 0.f;
         // four independent groups per trip: the out / dOut / arg requests of all four go out together and the
         // dependent Y[arg] gathers follow together -- two memory round trips per four groups instead of three per group
         const int64_t stride = (int64_t)gridDim.y * 4;
@@ -1415,7 +1424,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t g = g0 + u * stride;
-                y[u] = (g < G && o[u] > 0.f) ? Y[(g * K + a4[u]) * ldy + c] : mu;
+                y[u] = (!from_out && g < G && o[u] > 0.f) ? Y[(g * K + a4[u]) * ldy + c] : mu;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1425,7 +1434,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
                 dZp[g * ldo + c] = on ? dz[u] : 0.f;
                 if (on) {
                     s0 += (double)dz[u];
-                    s1 += (double)(dz[u] * ((y[u] - mu) * is));
+                    s1 += (double)(dz[u] * (from_out ? (o[u] - be) * rga : (y[u] - mu) * is));
                 }
             }
         }
@@ -1459,6 +1468,12 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
     if (c < C) {
         Affine a(aff, lda);
         const float mu = a.mean[c], is = a.invstd[c];
+        // x-hat = (y - mean) * invstd from the OUTPUT where that is well conditioned (see pool_bwd_reduce_kernel): out > 0 is
+        // the only case that counts, and there out = fma(y - mean, gamma * invstd, beta).  Y is then not read at all: a quarter
+        // of this pass's bytes.  Channels with a small gamma keep reading Y.
+        const float be = a.beta[c], ga = is != 0.f ? a.scale[c] / is : 0.f;
+        const bool from_out = fabsf(ga) >= 0.25f * (1.f + fabsf(be));
+        const float rga = from_out ? 1.f / ga : 0.f;
         const int64_t stride = (int64_t)gridDim.y * 4;
         // Four independent rows in flight, and the NEXT trip's rows are requested before this trip's stores go out: loads and
         // stores retire through one in-order counter, so a load issued behind a store waits for that store's HBM
@@ -1473,7 +1488,7 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
                 const int64_t pc = v ? p : 0;                     // (clamped: always a request, dropped below)
                 oo[u] = out[pc * ldo + c];
                 gg[u] = dOut[pc * ldo + c];
-                yy[u] = Y[pc * ldy + c];
+                yy[u] = from_out ? 0.f : Y[pc * ldy + c];
             }
         };
         int64_t p0 = (int64_t)blockIdx.y * 4 + gl;
@@ -1488,7 +1503,7 @@ __global__ __launch_bounds__(256) void relu_bwd_reduce_kernel(const float *__res
                 const float dz = o[u] > 0.f ? g4[u] : 0.f;
                 dZ[p * ldz + c] = dz;
                 s0 += (double)dz;
-                s1 += (double)(dz * ((y[u] - mu) * is));
+                s1 += (double)(dz * (from_out ? (o[u] - be) * rga : (y[u] - mu) * is));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { o[u] = on_[u]; g4[u] = gn[u]; y[u] = yn[u]; }
