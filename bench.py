@@ -130,6 +130,7 @@ STEP_MODEL_CFG5 = {("msg", 16): (118.13e9 / 524288, 3716e9 / 524288), ("ssg", 1)
 
 def make_step(workload, net, pts, labels, bucket):
     from pointnet12_amd.loss import nll_loss      # F.nll_loss (semseg.py:143) on the HIP library
+    from pointnet12_amd import graph as _graph
 
     def step():
         bucket.wait_reduced()                     # comm stream: the previous step's all-reduce (an event-wait node when captured)
@@ -140,6 +141,7 @@ def make_step(workload, net, pts, labels, bucket):
         else:
             lp = net(pts)
             loss = nll_loss(lp.reshape(-1, lp.shape[-1]), labels.reshape(-1))
+        _graph.fork_point()                       # (PN2_GEO_FORK_LATE=1: the next batch's geometry branch starts here)
         loss.backward()
         return loss
     return step

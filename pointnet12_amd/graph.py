@@ -19,6 +19,21 @@ import torch
 from . import pointnet_util as U
 
 _GEO_FIRST = os.environ.get("PN2_GEO_FIRST", "1") == "1"      # capture order of the two branches (the executor's launch order follows it)
+# The geometry branch of a captured step (the NEXT batch's FPS / ball query / 3-NN: 0.55 ms on 16 .. 64 CUs) starts where the step
+# function calls graph.fork_point() -- bench.py and tools/train_synthetic.py call it between forward and backward, so the branch
+# runs under the head / FP / sa4 / sa3 backward launches that do not fill the chip instead of under sa1's forward kernels, whose
+# one-workgroup-per-CU grids lose the CUs the FPS workgroups hold (same box, round 4: MSG 5.85 / 5.84 -> 5.75 / 5.78 ms, SSG within
+# noise).  A step function that never calls it gets the branch launched behind its own work, dependent on the graph's root only.
+# PN2_GEO_FORK_LATE=0: fork at the top of the step (round 3's order; A/B runs).
+_GEO_FORK_LATE = os.environ.get("PN2_GEO_FORK_LATE", "1") == "1"
+_fork_cb = None
+
+
+def fork_point():
+    """Called by a step function at the place where the next batch's geometry branch may start (no-op outside such a capture)."""
+    if _fork_cb is not None:
+        _fork_cb()
+
 
 
 class FpsStartFeed:
@@ -149,13 +164,30 @@ class GraphedStep:
                             with torch.no_grad():
                                 geometry_fn()
 
-                    if _GEO_FIRST:
+                    forked = [False]
+
+                    def fork_now():                                # (fork_point(): the step function chose where the branch starts)
+                        if forked[0]:
+                            return
+                        forked[0] = True
+                        geo_stream.wait_stream(torch.cuda.current_stream(device))
+                        keep = U.get_geometry_tape()
+                        geometry_branch()
+                        U.set_geometry_tape(keep)
+
+                    global _fork_cb
+                    if _GEO_FIRST and not _GEO_FORK_LATE:
+                        forked[0] = True
                         geometry_branch()
                     read.rewind("replay")                          # branch 1: this batch on the recorded geometry
                     U.set_geometry_tape(read)
-                    loss = fn()
+                    _fork_cb = fork_now if _GEO_FORK_LATE else None
+                    try:
+                        loss = fn()
+                    finally:
+                        _fork_cb = None
                     U.set_geometry_tape(None)
-                    if not _GEO_FIRST:
+                    if not forked[0]:
                         geometry_branch()
                         U.set_geometry_tape(None)
                     main.wait_stream(geo_stream)

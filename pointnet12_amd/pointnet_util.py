@@ -315,6 +315,10 @@ def set_geometry_tape(tape):
     _tape = tape
 
 
+def get_geometry_tape():
+    return _tape
+
+
 def _recording():
     return _tape is not None and _tape.mode == "record"
 

@@ -58,7 +58,7 @@ stats cfg5_msg $CFG5_MSG --steps 5 --warmup 2
 # 4. A/B lines of the round's switches (same box, back to back, twice)
 : > $O/ab_switches.txt
 for rep in 1 2; do
-  for v in "PN2_LAZY_BN=0" "PN2_LAZY_BN=1" "PN2_WIDE_POOL=0" "PN2_WIDE_POOL=1" "PN2_BWD_PAIR=0" "PN2_BWD_PAIR=1" "PN2_WGRAD_TWO_PHASE=0" "PN2_WGRAD_TWO_PHASE=1" "PN2_WGRAD_CF=0" "PN2_WGRAD_CF=1"; do
+  for v in "PN2_LAZY_BN=0" "PN2_LAZY_BN=1" "PN2_WIDE_POOL=0" "PN2_WIDE_POOL=1" "PN2_BWD_PAIR=0" "PN2_BWD_PAIR=1" "PN2_WGRAD_TWO_PHASE=0" "PN2_WGRAD_TWO_PHASE=1" "PN2_WGRAD_CF=0" "PN2_WGRAD_CF=1" "PN2_GEO_FORK_LATE=0" "PN2_GEO_FORK_LATE=1"; do
     for w in msg ssg; do
       env $v python3 bench.py --workload $w --no-cpu-baseline --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], d['ms_per_step'])" $v $w >> $O/ab_switches.txt
     done

@@ -66,6 +66,7 @@ def main():
     def compute():
         opt.zero_grad()                                            # free after the first step (fused into Adam)
         loss = nll_loss(net(pts.transpose(2, 1)).reshape(-1, CLASSES), lab.reshape(-1))
+        graph.fork_point()                                         # a captured step starts the next batch's geometry branch here
         loss.backward()
         bucket.all_reduce()
         opt.step()
