@@ -131,6 +131,10 @@ STEP_MODEL_CFG5 = {("msg", 16): (118.13e9 / 524288, 3716e9 / 524288), ("ssg", 1)
 def make_step(workload, net, pts, labels, bucket):
     from pointnet12_amd.loss import nll_loss      # F.nll_loss (semseg.py:143) on the HIP library
     from pointnet12_amd import graph as _graph
+    # Where the next batch's geometry branch may start: between forward and backward when that chain (0.55 ms at 4096 points) is
+    # short against the backward pass it then runs under; at the top of the step when it is not (cfg2: the FPS chain IS the step;
+    # cfg5: 2.6 - 23 ms of FPS) -- measured: cfg2 0.68 -> 0.76 ms and cfg5 SSG 6.30 -> 6.40 ms with the late fork
+    late_fork = workload in ("msg", "ssg") and pts.shape[-1] <= 8192
 
     def step():
         bucket.wait_reduced()                     # comm stream: the previous step's all-reduce (an event-wait node when captured)
@@ -141,7 +145,8 @@ def make_step(workload, net, pts, labels, bucket):
         else:
             lp = net(pts)
             loss = nll_loss(lp.reshape(-1, lp.shape[-1]), labels.reshape(-1))
-        _graph.fork_point()                       # (PN2_GEO_FORK_LATE=1: the next batch's geometry branch starts here)
+        if late_fork:
+            _graph.fork_point()                   # a captured step starts the next batch's geometry branch here
         loss.backward()
         return loss
     return step
@@ -546,7 +551,9 @@ def main():
         geometry = None
         if not args.no_prefetch:                    # geometry-only pass (recording tape) over the next batch
             geometry = (lambda: net(pts[:, :3, :], pts[:, 3:, :])) if args.workload == "sa" else (lambda: net.features(pts))
-        graphed = GraphedStep(compute, dev, geometry_fn=geometry)   # one hipGraph launch per step (failures raise)
+        # (fork_in_step: the geometry branch starts at make_step's fork_point() where that pays -- see make_step)
+        graphed = GraphedStep(compute, dev, geometry_fn=geometry,     # one hipGraph launch per step (failures raise)
+                              fork_in_step=args.workload in ("msg", "ssg") and n_points <= 8192)
     else:
         graphed = compute
 

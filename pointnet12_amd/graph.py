@@ -19,12 +19,13 @@ import torch
 from . import pointnet_util as U
 
 _GEO_FIRST = os.environ.get("PN2_GEO_FIRST", "1") == "1"      # capture order of the two branches (the executor's launch order follows it)
-# The geometry branch of a captured step (the NEXT batch's FPS / ball query / 3-NN: 0.55 ms on 16 .. 64 CUs) starts where the step
-# function calls graph.fork_point() -- bench.py and tools/train_synthetic.py call it between forward and backward, so the branch
+# GraphedStep(fork_in_step=True): the geometry branch of the captured step (the NEXT batch's FPS / ball query / 3-NN: 0.55 ms on
+# 16 .. 64 CUs) starts where the step function calls graph.fork_point() -- bench.py (B = 16 x 4096) and tools/train_synthetic.py
+# call it between forward and backward, so the branch
 # runs under the head / FP / sa4 / sa3 backward launches that do not fill the chip instead of under sa1's forward kernels, whose
 # one-workgroup-per-CU grids lose the CUs the FPS workgroups hold (same box, round 4: MSG 5.85 / 5.84 -> 5.75 / 5.78 ms, SSG within
-# noise).  A step function that never calls it gets the branch launched behind its own work, dependent on the graph's root only.
-# PN2_GEO_FORK_LATE=0: fork at the top of the step (round 3's order; A/B runs).
+# noise; cfg2, whose step IS the FPS chain, and cfg5 lose with it: 0.68 -> 0.76 ms, 6.30 -> 6.40 ms -- hence opt-in).
+# PN2_GEO_FORK_LATE=0: fork at the top of the step whatever the caller asked for (round 3's order; A/B runs).
 _GEO_FORK_LATE = os.environ.get("PN2_GEO_FORK_LATE", "1") == "1"
 _fork_cb = None
 
@@ -88,11 +89,16 @@ class GraphedStep:
     earlier, a side stream runs FPS / ball query / 3-NN for the following batch -- the 1 000-iteration FPS latency
     chain occupies 16 of the 256 CUs and disappears under the MLP kernels instead of heading every step.  The FPS
     start draws keep the reference's order (one set per batch, sa1 first).
+
+    ``fork_in_step``: the side branch starts where ``fn`` calls ``graph.fork_point()`` (once) instead of at the top of the step --
+    e.g. between forward and backward, so that the geometry chain runs under the backward stages that do not fill the chip.
+    Worth it when that chain is short against what follows the fork point (B = 16 x 4096 points: MSG-SemSeg 5.84 -> 5.76 ms);
+    with a long chain (one set-abstraction level alone, 65 536-point clouds) keep the default.
     """
 
-    def __init__(self, fn, device, warmup=3, geometry_fn=None):
+    def __init__(self, fn, device, warmup=3, geometry_fn=None, fork_in_step=False):
         if geometry_fn is not None:
-            self._init_prefetch(fn, geometry_fn, device, warmup)
+            self._init_prefetch(fn, geometry_fn, device, warmup, fork_in_step and _GEO_FORK_LATE)
             return
         self.fn = fn
         side = torch.cuda.Stream(device=device)
@@ -113,7 +119,7 @@ class GraphedStep:
             U.set_capture_scope(None)
             U.set_fps_start_feed(None)
 
-    def _init_prefetch(self, fn, geometry_fn, device, warmup):
+    def _init_prefetch(self, fn, geometry_fn, device, warmup, fork_in_step=False):
         self.fn = fn
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -176,12 +182,12 @@ class GraphedStep:
                         U.set_geometry_tape(keep)
 
                     global _fork_cb
-                    if _GEO_FIRST and not _GEO_FORK_LATE:
+                    if _GEO_FIRST and not fork_in_step:
                         forked[0] = True
                         geometry_branch()
                     read.rewind("replay")                          # branch 1: this batch on the recorded geometry
                     U.set_geometry_tape(read)
-                    _fork_cb = fork_now if _GEO_FORK_LATE else None
+                    _fork_cb = fork_now if fork_in_step else None
                     try:
                         loss = fn()
                     finally:

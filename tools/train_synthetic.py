@@ -77,7 +77,7 @@ def main():
                              out=(pts, lab))
 
     next_batch()
-    step = graph.GraphedStep(compute, dev) if args.graph else compute
+    step = graph.GraphedStep(compute, dev, fork_in_step=True) if args.graph else compute
     curve = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
