@@ -310,7 +310,8 @@ def test_prefetched_geometry_graph_matches_eager(dev):
     pts = torch.from_numpy(g["points"]).to(dev)
     labels = torch.from_numpy(g["labels"]).to(dev)
     seqs = []
-    for mode in ("eager", "prefetch"):
+    from pointnet12_amd import graph as G_
+    for mode in ("eager", "prefetch", "prefetch-forked"):
         torch.manual_seed(int(g["init_seed"]))
         net = M.PointNet2SemSegMsg(13, 6)
         net.drop1.p = 0.0
@@ -321,6 +322,7 @@ def test_prefetched_geometry_graph_matches_eager(dev):
             bucket.zero()
             lp = net(pts)
             loss = F.nll_loss(lp.reshape(-1, 13), labels.reshape(-1))
+            G_.fork_point()                       # (round 4) a no-op except under GraphedStep(fork_in_step=True)
             loss.backward()
             return loss
         torch.manual_seed(31)
@@ -329,14 +331,18 @@ def test_prefetched_geometry_graph_matches_eager(dev):
                 compute()
             step = compute
         else:
-            step = GraphedStep(compute, dev, warmup=2, geometry_fn=lambda: net.features(pts))
+            # "prefetch-forked": the geometry branch of the captured step starts at fork_point(), between forward and backward,
+            # instead of at its top -- when it runs changes, what it computes (draws, tapes) does not
+            step = GraphedStep(compute, dev, warmup=2, geometry_fn=lambda: net.features(pts), fork_in_step=mode == "prefetch-forked")
         losses = []
         for _ in range(4):
             losses.append(float(step()))
         seqs.append((losses, bucket.flat.clone()))
-    (la, ga), (lb, gb) = seqs
+    (la, ga), (lb, gb), (lc, gc) = seqs
     assert np.allclose(la, lb, rtol=0, atol=2e-5), (la, lb)
     assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
+    assert np.allclose(la, lc, rtol=0, atol=2e-5), (la, lc)
+    assert abs(float(ga.norm()) - float(gc.norm())) <= 5e-3 * float(ga.norm())
 
 
 def test_channel_last_copy_is_shared_and_follows_in_place_writes(dev):
