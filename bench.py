@@ -439,6 +439,37 @@ def dry_run(args, dist, torch):
         print(json.dumps(line))
 
 
+OTHER_CONFIGS = [   # name, extra arguments (the headline, cfg3 MSG, is the run that prints them)
+    ("cfg3_ssg_B16x4096", ["--workload", "ssg"]),
+    ("cfg2_sa_B8x4096", ["--workload", "sa"]),
+    ("cfg5_ssg_B8x65536", ["--workload", "ssg", "--points", "65536", "--batch", "8", "--steps", "10", "--warmup", "3"]),
+    ("cfg5_msg_B8x65536_npoint_x16", ["--workload", "msg", "--points", "65536", "--batch", "8", "--npoint-scale", "16", "--steps", "5",
+                                      "--warmup", "2"]),
+]
+
+
+def other_configs():
+    """{name: {ms_per_step, points_per_s, step_hbm_frac, step_mfma_frac, ...}} of the configurations the headline line does not
+    time: each one is this script again as a CHILD process (its own allocator pool; the parent never execs), with the same
+    timed protocol (barrier + synchronize around exactly --steps replays), without the CPU baseline."""
+    import subprocess
+    out = {}
+    for name, extra in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-other-configs"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            doc = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            sr = doc.get("step_roofline") or {}
+            out[name] = {"ms_per_step": doc["ms_per_step"], "points_per_s": doc["value"], "steps": doc["steps"], "warmup": doc["warmup"],
+                         "step_hbm_frac": sr.get("hbm_frac"), "step_mfma_frac": sr.get("mfma_frac"),
+                         "step_mfma_frac_reference_formulation": sr.get("mfma_frac_reference_formulation"),
+                         "workload": doc["config"]["workload"], "clouds": doc["config"]["clouds_per_gpu"],
+                         "points_per_cloud": doc["config"]["points_per_cloud"]}
+        except Exception as e:                         # a failed side run must not take the headline line down with it
+            out[name] = {"error": repr(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -457,6 +488,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute each batch's FPS/ball-query/3-NN inside its own step instead of one step ahead")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="headline run only: skip the short runs of the other BASELINE.json configurations (other_configs)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU only: exercise the launch / rendezvous / max-over-ranks timing / JSON relay with gloo ranks "
                          "and no GPU work (tests/test_bench_launch_cpu.py)")
@@ -709,7 +742,7 @@ def main():
                                      (" on a comm stream (verified against the step-stream result on this process group)"
                                       if bucket.comm is not None else " on the step's stream")),
                        "comm_stream_verified": comm_ok,
-                       "two_bucket": ({"late_bytes": 4 * bucket.n_late, "early_bytes": bucket.nbytes - 4 * bucket.n_late,
+                       "two_bucket": ({"experimental": True, "late_bytes": 4 * bucket.n_late, "early_bytes": bucket.nbytes - 4 * bucket.n_late,
                                        "in_graph_record_verified": two_detail} if two_bucket else
                                       {"off": True, "in_graph_record_check": two_detail}),
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
@@ -739,6 +772,14 @@ def main():
                          "mfma_frac_reference_formulation the reference's 6 x forward MACs"}
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        if (world == 1 and not use_dist and args.workload == "msg" and n_points == 4096 and args.npoint_scale == 1
+                and not args.no_other_configs and not args.no_graph and not args.no_cpu_baseline and not args.no_roofline):
+            # every other configuration of BASELINE.json under the same clock as the headline: after the timed
+            # region and outside it, a few graph replays each in a child process of its own, no CPU baseline.  Only the full
+            # default run does this (the tools' --no-cpu-baseline / --no-roofline / rocprofv3 runs stay single-process)
+            del graphed, compute, net, bucket
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs()
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -11,7 +11,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless it says "host"; tensors are dense row-major
  *     with the shapes given; float = IEEE fp32; indices = int64 (torch.long at the API);
- *   - the caller owns all memory (no allocation, no retained pointers, no global state);
+ *   - the caller owns all memory (no allocation, no retained pointers); the only process-wide state is the option table
+ *     below, changed by nothing but pn2_set_option() -- the library never reads the environment;
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
  *   - return value: PN2_OK (0) or a negative PN2_E* code (pn2_error_string() names it);
  *     launch errors are reported through hipGetLastError() as PN2_ELAUNCH;
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 9
+#define PN2_ABI_VERSION 10
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -99,6 +100,16 @@ typedef struct pn2_bn_coef_lazy {
 
 int pn2_version(void);
 const char *pn2_error_string(int code);
+
+/* Dispatch / tuning options (ABI 10).  Which kernel family takes a layer, tile overrides, A/B switches of measured
+ * experiments: one process-wide table of ints, every default the measured winner (the list with defaults and meanings:
+ * PN2_OPTION_LIST in pointnet12_amd/csrc/pn2_common.h).  No option changes RESULTS beyond fp32 summation order.  `name` is
+ * the option's name with or without its "PN2_" prefix ("PN2_RING", "WIDE_MIN_ROWS", ...).  An option takes effect with the
+ * next call; set options before work is enqueued from several threads.  pn2_option_name(i): name of option i, NULL past the
+ * end (enumeration).  Unknown name: PN2_EINVAL. */
+int pn2_set_option(const char *name, int value);
+int pn2_get_option(const char *name, int *value);
+const char *pn2_option_name(int index);
 
 /* ------------------------------------------------------------------ geometry (index-exact) */
 
@@ -246,7 +257,8 @@ int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_affine, const 
                          int ldy, int64_t P, int K, int N, double *stats, int Kpool, const float *gamma, float *pool_ws,
                          const pn2_bn_lazy *in_lazy, pn2_stream_t stream);
 /* out[g,c] = relu(bn(v)) of the recorded extreme value, arg[g,c] = its row (same outputs as pn2_bn_relu_max up to which of
- * several rows with EQUAL post-BN value is named).  C % 32 == 0, ldo == C. */
+ * several rows with EQUAL post-BN value is named; a channel whose scale is exactly 0 -- BatchNorm weight 0: every row gives
+ * relu(beta) -- names row 0, as torch.max of an all-equal group does).  C % 32 == 0, ldo == C. */
 int pn2_bn_pool_select(const float *pool_ws, const float *affine, int64_t G, int C, float *out, int ldo, int32_t *arg,
                        const pn2_bn_lazy *lazy, pn2_stream_t stream);
 
@@ -258,7 +270,14 @@ int pn2_bn_relu_max(const float *Y, int ldy, const float *affine, int64_t G, int
 
 /* Backward, last layer after max-pool: dZp[g,c] = out[g,c] > 0 ? dOut[g,c] : 0 (pitch ldo, pad lanes zero),
  * red[0..C) = sum dZ, red[C..2C) = sum dZ*yhat with dZ[g*K+k,c] = (k == arg[g,c]) ? dZp[g,c] : 0.
- * red is double[2*C], caller zeroes. */
+ * red is double[2*C], caller zeroes.
+ * PRECONDITION on `out` (round 4): it must be the pooled output THIS affine block produced, bit for bit --
+ * out[g,c] = max(fma(Y[(g*K + arg[g,c]), c] - mean, scale, beta), 0), what pn2_bn_relu_max / pn2_bn_pool_select write.
+ * Where |gamma| >= (1 + |beta|) / 4 the kernels take yhat of a positive output from it, yhat = (out - beta) / gamma (error
+ * eps * |out| / |gamma|: no gather of Y, one 64-byte sector per element); elsewhere (small or zero gamma) from Y as before.  An
+ * `out` from another path (an eval-mode fold, a post-processed slice) gives wrong d gamma / q1.  Y must be non-NULL either way.
+ * Both branches and both signs of gamma are held to an fp64 evaluation by tests/test_mlp_gpu.py
+ * (test_shared_mlp_negative_and_zero_gamma). */
 int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
                         const float *affine, int64_t G, int K, int C, float *dZp, double *red,
                         const pn2_bn_coef_tail *tail, pn2_stream_t stream);
@@ -268,7 +287,7 @@ int pn2_pool_bwd_reduce_ld(const float *dOut, int ld_dout, const float *out, int
                            const float *affine, int64_t G, int K, int C, float *dZp, double *red, const pn2_bn_coef_tail *tail,
                            pn2_stream_t stream);
 /* Backward, dense (FP) last layer: dZ = dOut * (out > 0) written to dZ [P, ldz] (its pad columns
- * C .. round4(C)-1 are written as zeros); same reductions. */
+ * C .. round4(C)-1 are written as zeros); same reductions, same precondition on `out` (= max(fma(Y - mean, scale, beta), 0)). */
 int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,
                         int64_t P, int C, float *dZ, int ldz, double *red, const pn2_bn_coef_tail *tail,
                         pn2_stream_t stream);

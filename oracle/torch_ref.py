@@ -36,9 +36,48 @@ def set_geometry(mode):
 POOL_ARGMAX = None
 
 
+# tests/test_parity_stages_gpu.py, decisions: the DISCRETE choices of a shared MLP -- every layer's ReLU mask (relu(bn(conv)) of
+# pointnet_util.py:197 / :255 / :312) and the pooled arg-max (:199 / :256).  None = off;
+#   {"record": []}             every stack appends {"masks": [bool [B,C,K,S] / [B,C,N] per layer], "argmax": int64 [B,C,S] or None}
+#   {"force": [...], "pos": 0} every stack takes the next entry and evaluates  bn(.) * mask  instead of relu(bn(.)) and a gather at
+#                              the given index instead of torch.max: the same function wherever the decisions agree, and the
+#                              smooth function "with those decisions" where they do not (what an evaluation that flipped a
+#                              decision within rounding of its threshold computes -- gradients included).
+DECISIONS = None
+_LAST_STACK = None
+
+
+def _next_stack():
+    global _LAST_STACK
+    dec = DECISIONS
+    if dec is None:
+        _LAST_STACK = None
+    elif "force" in dec:
+        _LAST_STACK = dec["force"][dec["pos"]]
+        dec["pos"] += 1
+    else:
+        _LAST_STACK = {"masks": [], "argmax": None}
+        dec["record"].append(_LAST_STACK)
+    return _LAST_STACK
+
+
+def _relu_decided(z, stack, layer):
+    if stack is None:
+        return F.relu(z)
+    if "force" in DECISIONS:
+        return z * stack["masks"][layer].to(z.dtype)
+    stack["masks"].append((z > 0).detach())
+    return F.relu(z)
+
+
 def _pool(y):
     """torch.max(new_points, 2)[0] of pointnet_util.py:199 / :256 on [B,C,K,S]."""
+    stack = _LAST_STACK if DECISIONS is not None else None
+    if stack is not None and "force" in DECISIONS:
+        return y.gather(2, stack["argmax"].unsqueeze(2)).squeeze(2)
     m = y.max(dim=2)
+    if stack is not None:
+        stack["argmax"] = m[1].detach()
     if POOL_ARGMAX is not None:
         POOL_ARGMAX.append((m[1].detach(), m[0].detach()))
     return m[0]
@@ -72,13 +111,14 @@ def _shared_mlp(x, convs, bns, training):
     the same statistics over a [P, C] row matrix drift to 1e-5 (measured).
     """
     y = x
-    for conv, bn in zip(convs, bns):
+    stack = _next_stack()
+    for layer, (conv, bn) in enumerate(zip(convs, bns)):
         y = F.conv2d(y, conv.weight, conv.bias) if y.dim() == 4 else F.conv1d(y, conv.weight, conv.bias)
         if training and bn.track_running_stats:
             bn.num_batches_tracked += 1
         y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                          training, bn.momentum, bn.eps)
-        y = F.relu(y)
+        y = _relu_decided(y, stack, layer)
     return y
 
 
@@ -229,7 +269,7 @@ class _SegHead(nn.Module):
         self.conv2 = nn.Conv1d(128, num_classes, 1)
 
     def head(self, feat):
-        x = self.drop1(F.relu(self.bn1(self.conv1(feat))))
+        x = self.drop1(_relu_decided(self.bn1(self.conv1(feat)), _next_stack(), 0))
         x = F.log_softmax(self.conv2(x), dim=1)
         return x.permute(0, 2, 1)
 

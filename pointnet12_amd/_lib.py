@@ -17,6 +17,9 @@ _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_
 SIGNATURES = {
     "pn2_version": (_i, []),
     "pn2_error_string": (ctypes.c_char_p, [_i]),
+    "pn2_set_option": (_i, [ctypes.c_char_p, _i]),
+    "pn2_get_option": (_i, [ctypes.c_char_p, _vp]),
+    "pn2_option_name": (ctypes.c_char_p, [_i]),
     "pn2_fps_workspace_bytes": (_i64, [_i, _i, _i]),
     "pn2_fps": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
@@ -73,7 +76,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PN2_EUNSUPPORTED = -3            # include/pn2.h
 PN2_OK_SPLIT = 1                 # pn2_conv1x1_bwd_pair: done as two launches
 DWX_REPLICAS = 32        # PN2_DWX_REPLICAS of include/pn2.h
@@ -131,7 +134,7 @@ class _Timed:
 
     def __getattr__(self, name):
         fn = getattr(_raw, name)
-        if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_fps_workspace_bytes",
+        if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_set_option", "pn2_get_option", "pn2_option_name", "pn2_fps_workspace_bytes",
                                                    "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_bwd_res_supported", "pn2_conv1x1_wgrad_workspace_bytes",
                                                    "pn2_conv1x1_wgrad_cf_scratch_bytes",
                                                    "pn2_ball_query_workspace_bytes"):
@@ -186,7 +189,39 @@ def load():
     if lib.pn2_version() != ABI_VERSION:
         raise Pn2Error("libpn2_hip.so ABI version %d, expected %d -- rebuild it" % (lib.pn2_version(), ABI_VERSION))
     _lib = _raw = lib
+    forward_env_options(lib)
     return lib
+
+
+def options(lib=None):
+    """{name: value} of every library option (pn2_option_name / pn2_get_option)."""
+    lib = lib or load()
+    out, i = {}, 0
+    while True:
+        name = lib.pn2_option_name(i)
+        if name is None:
+            return out
+        v = ctypes.c_int(0)
+        if lib.pn2_get_option(name, ctypes.addressof(v)) == 0:
+            out[name.decode()] = v.value
+        i += 1
+
+
+def set_option(name, value):
+    """pn2_set_option; raises on an unknown name."""
+    check(load().pn2_set_option(name.encode(), int(value)), "pn2_set_option(%s)" % name)
+
+
+def forward_env_options(lib):
+    """The library itself never reads the environment (include/pn2.h, options): A/B runs set PN2_<OPTION>=<int> in the
+    environment of THIS binding, which hands them to pn2_set_option once at load time."""
+    for name in options(lib):
+        v = os.environ.get(name)
+        if v is not None:
+            try:
+                lib.pn2_set_option(name.encode(), int(v))
+            except ValueError:
+                raise Pn2Error("%s=%r is not an integer" % (name, v))
 
 
 def check(rc, what):

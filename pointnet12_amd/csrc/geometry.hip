@@ -562,8 +562,8 @@ template <int THREADS, int PPT>
 int launch_fps_pruned(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, hipStream_t s) {
     // two-level pruning (fps_rows_kernel) where the wave-level kernel spills: 24+ points per thread; PN2_FPS_ROWS_MIN_PPT moves the
     // hand-over, PN2_FPS_ROWMAP picks the row ownership (A/B runs)
-    static const int rows_min = [] { const char *e = getenv("PN2_FPS_ROWS_MIN_PPT"); return e ? atoi(e) : 24; }();
-    static const int rowmap = [] { const char *e = getenv("PN2_FPS_ROWMAP"); return e ? atoi(e) : 2; }();
+    const int rows_min = pn2_opt(PN2_OPT_FPS_ROWS_MIN_PPT);
+    const int rowmap = pn2_opt(PN2_OPT_FPS_ROWMAP);
     const size_t fixed = sizeof(int) * ((size_t)THREADS * PPT + FPS_NC + 32 + 8 + 6 * (THREADS / 64) + 2) + 64;
     const bool in_lds = fixed + (size_t)N * 16 <= 160 * 1024;
     typedef void (*kernel_t)(const float *, int, const int64_t *, int, int64_t *);
@@ -1007,18 +1007,14 @@ extern "C" {
 // that fits 1024 threads' 128-VGPR budget without spilling); the cooperative kernel's iteration costs 2.2 us up to
 // N = 32 768 (its cross-CU exchange), so the hand-over sits at 24 576.  PN2_FPS_SINGLE_MAX moves it for A/B runs.
 static int fps_single_max() {
-    static const int n = [] {
-        const char *e = getenv("PN2_FPS_SINGLE_MAX");
-        const int v = e ? atoi(e) : 24576;
-        return v < 16384 ? 16384 : (v > 28672 ? 28672 : v);
-    }();
-    return n;
+    const int v = pn2_opt(PN2_OPT_FPS_SINGLE_MAX);
+    return v < 16384 ? 16384 : (v > 28672 ? 28672 : v);
 }
 
 static void fps_coop_plan(int B, int N, int *ppt, int *W) {
     *ppt = 0; *W = 0;
     if (N <= fps_single_max()) return;
-    static const int enabled = [] { const char *e = getenv("PN2_FPS_COOP"); return e ? atoi(e) : 1; }();
+    const int enabled = pn2_opt(PN2_OPT_FPS_COOP);
     if (!enabled) return;
     for (int p = 8; p <= 16; p *= 2) {
         const int w = (int)pn2_cdiv(N, 1024 * p);
@@ -1046,7 +1042,7 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
     if (N <= 2048) return launch_fps<256, 8>(xyz, B, N, start, npoint, out_idx, s);
     // spatially pruned kernel (exact, see fps_pruned_kernel) where a cloud spans at least eight waves and enough samples are
     // drawn to pay for the one-time sort; PN2_FPS_PRUNE=0 keeps the plain kernels (A/B runs)
-    static const int prune = [] { const char *e = getenv("PN2_FPS_PRUNE"); return e ? atoi(e) : 1; }();
+    const int prune = pn2_opt(PN2_OPT_FPS_PRUNE);
     // (measured, us per iteration plain -> pruned: N = 4096 0.55 -> 0.85, 8192 0.85 -> 0.92 -- the plain kernel keeps the
     // cloud in LDS and the winner's coordinates are one broadcast read away, the pruned one fetches them from L2 --
     // 16 384 1.39 -> 1.07, 20 000 1.62 -> 1.23, 25 000 2.19 -> 1.81.  PN2_FPS_PRUNE=2 forces it from N > 2048 on: tests.)
@@ -1088,7 +1084,7 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
 // The centres are put in spatial order first where that pays: large clouds (a full scan is long) with enough centres for the
 // ordering to form homogeneous workgroups.  PN2_BQ_ORDER=0: never (A/B runs).
 static bool bq_wants_order(int N, int S) {
-    static const int on = [] { const char *e = getenv("PN2_BQ_ORDER"); return e ? atoi(e) : 1; }();
+    const int on = pn2_opt(PN2_OPT_BQ_ORDER);
     return on && N >= 8192 && S >= 1024;
 }
 

@@ -498,16 +498,16 @@ struct PairJob {
     const float *X; int ldx; const float *x_aff;
     float *dW; int lddw; int M, N;
 };
-static thread_local PairJob g_pair_job = {false, false, nullptr, 0, nullptr, nullptr, 0, 0, 0};
+// (passed down the dispatch explicitly: round 4 posted it in thread-local storage, hidden state behind a C ABI that promises none)
 
 template <int BM, int BN, int BK, int WR, int WC, bool VEC, class ALoad, class Epi>
-bool launch_bwd_pair(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, unsigned nt_gx, unsigned nt_gy, int *rc);
+bool launch_bwd_pair(const PairJob &j, ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, unsigned nt_gx, unsigned nt_gy, int *rc);
 
 template <class A, class B> struct pn2_same { static constexpr bool v = false; };
 template <class A> struct pn2_same<A, A> { static constexpr bool v = true; };
 
 template <int BM, int BN, int BK, int WR, int WC, int MINB, int DEPTH, bool BNN, bool VEC, int ACCS = 1, bool ROT = false, class ALoad, class Epi>
-int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, int n_lo = 0, int n_hi = 0) {
+int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, int n_lo = 0, int n_hi = 0, PairJob *job = nullptr) {
     int64_t tiles_m = pn2_cdiv(P, BM);
     unsigned tiles_n = (unsigned)pn2_cdiv((n_hi ? n_hi : N) - n_lo, BN);     // output columns [n_lo, n_hi) of N
     int64_t cap = (int64_t)pn2_num_cus() * MINB / tiles_n;  // MINB resident workgroups per CU in total
@@ -516,7 +516,7 @@ int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream
     if constexpr (BNN && VEC && BM == 64 && BN == 128 && BK == 16 && WR == 2 && WC == 2 && DEPTH == 1 && ACCS == 1 && !ROT &&
                   (pn2_same<ALoad, LoadDyDense>::v || pn2_same<ALoad, LoadDyPooled>::v) &&
                   (pn2_same<Epi, EpiDgradMask>::v || pn2_same<Epi, EpiStore>::v)) {
-        if (g_pair_job.active && !g_pair_job.taken && n_lo == 0 && n_hi == 0) {
+        if (job != nullptr && job->active && !job->taken && n_lo == 0 && n_hi == 0) {
             int rc = PN2_OK;
             // both halves must be RESIDENT together (two workgroups of 70 KB fit a CU): one per CU for each body -- with the
             // persistent NT grid at its usual three per CU its blocks, dispatched first, took every slot and the TN half ran
@@ -524,8 +524,8 @@ int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream
             int64_t cap1 = (int64_t)pn2_num_cus() / tiles_n;
             if (cap1 < 1) cap1 = 1;
             const unsigned gx1 = (unsigned)(tiles_m < cap1 ? tiles_m : cap1);
-            if (launch_bwd_pair<BM, BN, BK, WR, WC, VEC>(aload, bm, P, K4, N, epi, s, gx1, tiles_n, &rc)) {
-                g_pair_job.taken = true;
+            if (launch_bwd_pair<BM, BN, BK, WR, WC, VEC>(*job, aload, bm, P, K4, N, epi, s, gx1, tiles_n, &rc)) {
+                job->taken = true;
                 return rc;
             }
         }
@@ -535,10 +535,6 @@ int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream
     return pn2_launch_status();
 }
 
-inline int pn2_env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 // ----------------------------------------------------------------------------- few-row NT GEMM
 // The sa3 / sa4 / fp4 / fp3 / fp2 products (P = 2 k .. 8 k rows, K up to 1536) have too few output tiles for the persistent
@@ -562,8 +558,10 @@ template <class T> struct fr_same<T, T> { static constexpr bool v = true; };
 // KS: waves sharing one 32 x 64 tile (they split K); a workgroup owns 4 / KS consecutive tiles of the (row tile, column tile) grid,
 // column tiles fastest -- its waves then read the same activation rows.  The host picks KS so that about four waves per CU
 // have 4+ stages each.
+// (one workgroup per CU in the bound: under the two-workgroup cap of 256 registers hipcc spilled 13 registers of the pooled
+// data gradient that it does not need when left alone -- the instantiations use 116 .. 246 registers, so two still fit)
 template <int KS, bool BNN, class ALoad, class Epi>
-__global__ __launch_bounds__(NTHREADS, 2) void fewrow_nt_kernel(ALoad aload, BMat bm, int K4, int N, Epi epi) {
+__global__ __launch_bounds__(NTHREADS, 1) void fewrow_nt_kernel(ALoad aload, BMat bm, int K4, int N, Epi epi) {
     constexpr bool kPlain = fr_same<ALoad, LoadPlain>::v, kBn = fr_same<ALoad, LoadBnRelu>::v;
     constexpr bool kDense = fr_same<ALoad, LoadDyDense>::v, kPooled = fr_same<ALoad, LoadDyPooled>::v;
     static_assert(kPlain || kBn || kDense || kPooled, "unknown operand loader");
@@ -775,8 +773,8 @@ bool launch_fewrow(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipS
     // measured against the persistent core (tools/bench_kernels.py, us): forward 2048 x 1536 -> 256 38.7 -> 25.4, 2048 x 512 -> 1024
     // 33.3 -> 32.5, 8192 x 576 -> 256 37.5 -> 36.3; dgrad 2048 x 1024 -> 512 (pooled) 49.1 -> 39.7, 2048 x 512 -> 256 16.9 -> 14;
     // the 8192-row dgrads (dword weight requests down the columns, 1024+ tiles) are 1 .. 3 us slower here and stay on the core
-    static const int max_tiles = BNN ? pn2_env_int("PN2_FEWROW_MAX_TILES_DGRAD", 512) : pn2_env_int("PN2_FEWROW_MAX_TILES", 1024);   // 0: off
-    static const int force_ks = pn2_env_int("PN2_FEWROW_KS", 0);
+    const int max_tiles = BNN ? pn2_opt(PN2_OPT_FEWROW_MAX_TILES_DGRAD) : pn2_opt(PN2_OPT_FEWROW_MAX_TILES);   // 0: off
+    const int force_ks = pn2_opt(PN2_OPT_FEWROW_KS);
     // K = bm.K is the contraction length as the caller states it: a multiple of 32 means there are no pad columns at all
     if (!bm.vec || (P & 31) || (N & 63) || (K4 & 31) || bm.K != K4 || K4 < 128) return false;
     const int64_t tiles = (P / 32) * (N / 64);
@@ -796,8 +794,8 @@ bool launch_fewrow(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipS
 }
 
 template <bool BNN, class ALoad, class Epi>
-int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
-    static const int cfg = pn2_env_int("PN2_NT_CFG", 0);     // tuning hook (tools/bench_kernels.py)
+int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, PairJob *job = nullptr) {
+    const int cfg = pn2_opt(PN2_OPT_NT_CFG);     // tuning hook (tools/bench_kernels.py)
     {
         int rc = PN2_OK;
         if (launch_fewrow<BNN>(aload, bm, P, K4, N, epi, s, &rc)) return rc;
@@ -814,7 +812,7 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
     // k-step issues 8.4 VALU + 4.5 SALU instructions per MFMA (64-bit addresses, predicates, the BatchNorm transform) in a
     // phase of its own -- with a single wave per SIMD nothing runs under the MFMAs (matrix pipe 31 % busy).  What helps is a
     // second workgroup per CU in another phase, not a deeper ring.
-    static const int sdepth = pn2_env_int("PN2_NT_SMALL_DEPTH", 1);
+    const int sdepth = pn2_opt(PN2_OPT_NT_SMALL_DEPTH);
     if (N > 32 && cfg != 7 && cfg != 8 && pn2_cdiv(P, 64) * pn2_cdiv(N, 64) * 2 <= pn2_num_cus()) {
         if (sdepth == 4) return launch_nt<32, 64, 32, 1, 2, 2, 1, BNN, true, 1, true>(aload, bm, P, K4, N, epi, s);   // rotated k order
         if (sdepth == 3) return launch_nt<32, 64, 32, 1, 2, 2, 1, BNN, true, 4>(aload, bm, P, K4, N, epi, s);         // four chains per tile
@@ -835,7 +833,7 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
     // 129..224 output channels (128->196, 256->196 of MSG sa2): 128 columns on the 64x128 tile and the remainder on the
     // narrowest tile that holds it, as a second launch, instead of a second 128-wide tile that is 47 % padding at 196.
     // (Not with a fused BatchNorm tail: its ticket counts the workgroups of ONE launch.)
-    static const int nsplit = pn2_env_int("PN2_NT_NSPLIT", 1);
+    const int nsplit = pn2_opt(PN2_OPT_NT_NSPLIT);
     if (nsplit && N > 128 && N <= 224 && epi.ticket() == nullptr) {
         int rc;
         if constexpr (ALoad::kRegs >= 8) rc = launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 0, 128);
@@ -851,15 +849,15 @@ int dispatch_nt_vec(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hip
     // 128x128x32 at two per CU (+10..17 %); deeper register prefetch rings (2..4 k-steps) were measured: no gain.
     // Loaders with a large in-flight register set (two or three tensors per operand row) get a 168-VGPR budget
     // (3 per CU) instead of 128 (4 per CU): no spills.
-    if constexpr (ALoad::kRegs >= 8) return launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
-    else return launch_nt<64, 128, 16, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s);
+    if constexpr (ALoad::kRegs >= 8) return launch_nt<64, 128, 16, 2, 2, 3, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 0, 0, job);
+    else return launch_nt<64, 128, 16, 2, 2, 4, 1, BNN, true>(aload, bm, P, K4, N, epi, s, 0, 0, job);
 }
 
 // Weights whose rows cannot be read as float4 (C_in = 9, 137, ...; column slices of a wider matrix) take guarded
 // scalar loads for the weight tile; three tile shapes cover them (these are the first layers: short K or short P).
 template <bool BNN, class ALoad, class Epi>
-int dispatch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s) {
-    if (bm.vec) return dispatch_nt_vec<BNN>(aload, bm, P, K4, N, epi, s);
+int dispatch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, PairJob *job = nullptr) {
+    if (bm.vec) return dispatch_nt_vec<BNN>(aload, bm, P, K4, N, epi, s, job);
     if (N > 32 && pn2_cdiv(P, 64) * pn2_cdiv(N, 128) * 2 <= pn2_num_cus())
         return launch_nt<64, 64, 32, 2, 2, ALoad::kRegs >= 8 ? 2 : 3, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
     if (N <= 32) return launch_nt<128, 32, 32, 4, 1, 2, 1, BNN, false>(aload, bm, P, K4, N, epi, s);
@@ -1060,7 +1058,7 @@ __global__ __launch_bounds__(NTHREADS, MINB) void gemm_tn_kernel(DyLoad dyload, 
 template <int NQ>
 __global__ __launch_bounds__(256, 2) void wgrad_skinny_kernel(const float *__restrict__ dZ, int ldz,
                                                               const float *__restrict__ Y, int ldy,
-                                                              const float *__restrict__ coef, int ldc,
+                                                              const float *coef, int ldc,   // (no __restrict__: the prologue writes it)
                                                               const float *__restrict__ X, int ldx, int64_t P, int M, int N,
                                                               int cg_log2, float *__restrict__ dW, int lddw,
                                                               float *__restrict__ dbias, LazyCoef lc) {
@@ -1160,7 +1158,7 @@ template <int BM, int BN, int WG_BP, int WR, int WC, int MINB, int KS = 1, int T
 int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s,
               int per_cu = MINB) {
     unsigned tm = (unsigned)pn2_cdiv(M, BM), tn = (unsigned)pn2_cdiv(N, BN);
-    static const int splitdiv = pn2_env_int("PN2_TN_SPLITDIV", 1);
+    const int splitdiv = pn2_opt(PN2_OPT_TN_SPLITDIV);
     int64_t want = (int64_t)pn2_num_cus() * per_cu / ((int64_t)tm * tn) / splitdiv;   // resident workgroups per CU
     if (want < 1) want = 1;
     int64_t max_split = pn2_cdiv(P, 8 * WG_BP);
@@ -1190,14 +1188,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void bwd_pair_kernel(ALoad aload, BMat
 }
 
 template <int BM, int BN, int BK, int WR, int WC, bool VEC, class ALoad, class Epi>
-bool launch_bwd_pair(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, unsigned nt_gx, unsigned nt_gy, int *rc) {
-    const PairJob &j = g_pair_job;
+bool launch_bwd_pair(const PairJob &j, ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream_t s, unsigned nt_gx, unsigned nt_gy, int *rc) {
     constexpr bool masked = pn2_same<Epi, EpiDgradMask>::v;
     if (masked != (j.x_aff != nullptr)) return false;      // the weight gradient's X loader follows the data gradient's epilogue
     // the split over P of launch_tn<64, 64, 32, 2, 2, 2, 1, 2, 4> (the few-row weight-gradient configuration)
     constexpr int WG_BP = 32;
     const unsigned tm = (unsigned)pn2_cdiv(j.M, 64), tn = (unsigned)pn2_cdiv(j.N, 64);
-    static const int splitdiv = pn2_env_int("PN2_TN_SPLITDIV", 1);
+    const int splitdiv = pn2_opt(PN2_OPT_TN_SPLITDIV);
     int64_t want = (int64_t)pn2_num_cus() / ((int64_t)tm * tn) / splitdiv;          // one TN workgroup per CU beside one NT workgroup
     if (want < 1) want = 1;
     const int64_t max_split = pn2_cdiv(P, 8 * WG_BP);
@@ -1223,12 +1220,12 @@ bool launch_bwd_pair(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hi
 
 template <class DyLoad, class XLoad>
 int dispatch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, int lddw, float *dbias, hipStream_t s) {
-    static const int cfg = pn2_env_int("PN2_TN_CFG", 0);     // tuning hook (tools/bench_kernels.py)
+    const int cfg = pn2_opt(PN2_OPT_TN_CFG);     // tuning hook (tools/bench_kernels.py)
     // narrow products (the 32-channel layers of sa1): tiles of one or two 32x32 wave tiles, the four waves split the
     // positions of a stage between them (KS) -- no loader thread idles on zero-page columns as in the 128x32 tile:
     // 524 288 x 32 x 32: 78 -> 43 us, 524 288 x 64 x 32 (pooled): 93 -> 57 us.  Every workgroup ends with atomics on
     // the same <= 2048 words, so the 32x32 case asks for two workgroups per CU, not four.
-    static const int narrow = pn2_env_int("PN2_TN_NARROW", 1);
+    const int narrow = pn2_opt(PN2_OPT_TN_NARROW);
     constexpr bool heavy_dy = DyLoad::kRegs >= 13;
     if (narrow && N <= 32 && M <= 32)
         return launch_tn<32, 32, 64, 1, 1, heavy_dy ? 3 : 4, 4>(dyload, xload, P, M, N, dW, lddw, dbias, s, 2);
@@ -1245,9 +1242,9 @@ int dispatch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, 
     // multiply than 128x128, and enough tiles to fill the chip without a deep split (small-P wgrad 350 -> 259 us/step)
     // (the same holds up to P = 65 536 -- 65 536 x 128 x 128: 52.6 -> 35.5 us, 32 768 x 256 x 320: 90 -> 81 us -- and at
     // P = 131 072 for a 128 x 128 product, 72 -> 65 us, but not for 256 x 128, 118 -> 140 us)
-    static const int small_p = pn2_env_int("PN2_TN_SMALLP", 65536);
+    const int small_p = pn2_opt(PN2_OPT_TN_SMALLP);
     if ((P <= small_p || (P <= 2 * (int64_t)small_p && (int64_t)M * N <= 16384)) && cfg != 3) {
-        static const int tdepth = pn2_env_int("PN2_TN_SMALL_DEPTH", 2);     // stages in flight (latency-bound chains: see TD)
+        const int tdepth = pn2_opt(PN2_OPT_TN_SMALL_DEPTH);     // stages in flight (latency-bound chains: see TD)
         if (tdepth >= 3) return launch_tn<64, 64, 32, 2, 2, 2, 1, 2, 1>(dyload, xload, P, M, N, dW, lddw, dbias, s);
         if (tdepth == 2) return launch_tn<64, 64, 32, 2, 2, 2, 1, 2, 4>(dyload, xload, P, M, N, dW, lddw, dbias, s);
         return launch_tn<64, 64, 32, 2, 2, 2>(dyload, xload, P, M, N, dW, lddw, dbias, s);
@@ -1297,7 +1294,7 @@ __global__ void bn_finalize_kernel(const double *__restrict__ stats, double inv_
 // share ONE group, each takes a quarter of its K rows, and the partial (max, first k) pairs meet in LDS.
 template <bool kPooled>
 __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restrict__ Y, int ldy,
-                                                          const float *__restrict__ aff, int lda, int64_t G, int K,
+                                                          const float *aff, int lda, int64_t G, int K,   // (no __restrict__: the prologue writes it)
                                                           int lpr_log2, int ksplit, float *__restrict__ out, int ldo,
                                                           int32_t *__restrict__ arg, LazyBn lz) {
     __shared__ float sh_v[4][64][4];
@@ -1607,7 +1604,7 @@ typedef float cf_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int CF_REPL = 8;                                        // scratch replicas: 1 / 8 of the workgroups add into each
 
 template <int NB, int U>                                          // 16-channel blocks: M = 16 NB; 4-row groups in flight per wave
-__global__ __launch_bounds__(256) void wgrad_first_cf_kernel(const float *__restrict__ dZ, int ldz, const float *__restrict__ coef, int ldc,
+__global__ __launch_bounds__(256) void wgrad_first_cf_kernel(const float *__restrict__ dZ, int ldz, const float *coef /* written by the prologue */, int ldc,
                                                              const float *__restrict__ X, int ldx, int64_t P, int N,
                                                              const float *__restrict__ W, int ldw, const float *__restrict__ bias,
                                                              float *__restrict__ part, double *__restrict__ mom, unsigned *__restrict__ ticket,
@@ -1848,10 +1845,11 @@ int pn2_bn_bwd_coef(const double *red, int64_t P, int C, const float *gamma, con
     return pn2_launch_status();
 }
 
-int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
-                      const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
-                      double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail, const pn2_bn_coef_lazy *coef_lazy,
-                      pn2_stream_t stream) {
+// `job`: the weight-gradient half pn2_conv1x1_bwd_pair wants to ride in this launch (null for the plain entry point)
+static int conv1x1_dgrad_impl(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
+                              const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
+                              double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail, const pn2_bn_coef_lazy *coef_lazy,
+                              pn2_stream_t stream, PairJob *job) {
     PN2_CHECK_ARG(Y && coef && W && dXout && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && coef_tail_ok(prev_tail, prev_red) &&
                   (prev_tail == nullptr || prev_Y != nullptr) && lazy_coef_ok(coef_lazy, coef, K));
     LazyCoef lc = make_lazy_coef(coef_lazy);                            // realised by the FIRST launch below
@@ -1880,15 +1878,23 @@ int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const
         LoadDyDense ld{dZ, ldz, Y, ldy, coef, ldc, zero_page_dev(), lc};
         if (prev_Y)
             return dispatch_nt<true>(ld, bm, P, K4, N,
-                                     EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s);
-        return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
+                                     EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s, job);
+        return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s, job);
     }
     PN2_CHECK_ARG(ldo % 4 == 0 && ldo >= K4);
     LoadDyPooled ld{dZp, ldo, arg, Kpool, Y, ldy, coef, ldc, zero_page_dev(), pow2_shift(Kpool), lc};
     if (prev_Y)
         return dispatch_nt<true>(ld, bm, P, K4, N,
-                                 EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s);
-    return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s);
+                                 EpiDgradMask{dXout, ldxo, prev_Y, ld_prev, prev_affine, round4(N), prev_red, ct, zero_page_dev()}, s, job);
+    return dispatch_nt<true>(ld, bm, P, K4, N, EpiStore{dXout, ldxo}, s, job);
+}
+
+int pn2_conv1x1_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy, const float *coef, const float *W, int ldw,
+                      const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
+                      double *prev_red, int64_t P, int K, int N, const pn2_bn_coef_tail *prev_tail, const pn2_bn_coef_lazy *coef_lazy,
+                      pn2_stream_t stream) {
+    return conv1x1_dgrad_impl(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, W, ldw, prev_Y, ld_prev, prev_affine, dXout, ldxo, prev_red, P, K, N,
+                              prev_tail, coef_lazy, stream, nullptr);
 }
 
 int64_t pn2_conv1x1_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled) { return pn2_wide_wgrad_workspace_bytes(P, M, N, pooled); }
@@ -1906,7 +1912,7 @@ int pn2_conv1x1_wgrad_cf(const float *dZ, int ldz, const float *coef, const floa
     double *mom = reinterpret_cast<double *>(scratch);                              // [CF_REPL][16][16]
     float *part = reinterpret_cast<float *>(mom + CF_REPL * 256);                   // [CF_REPL][M][16]
     unsigned *ticket = reinterpret_cast<unsigned *>(part + CF_REPL * 128 * 16);
-    static const int per_cu = pn2_env_int("PN2_CF_WGS_PER_CU", 2);
+    const int per_cu = pn2_opt(PN2_OPT_CF_WGS_PER_CU);
     constexpr int U = 8;
     int64_t grid = pn2_cdiv(P, 4 * U * 4 * 4);                     // >= 4 trips per wave
     if (grid > (int64_t)per_cu * pn2_num_cus()) grid = (int64_t)per_cu * pn2_num_cus();
@@ -1950,7 +1956,7 @@ int pn2_conv1x1_wgrad_ws(const float *dZ, int ldz, const float *dZp, int ldo, co
         if (rc != PN2_EUNSUPPORTED) return rc;
     }
     if (dZ) {
-        static const int skinny = pn2_env_int("PN2_WGRAD_SKINNY", 1);
+        const int skinny = pn2_opt(PN2_OPT_WGRAD_SKINNY);
         if (skinny && x_affine == nullptr && N <= 16 && P >= 4096) {     // first layers: stream dZ / Y once, no MFMA
             switch ((N + 3) / 4) {
                 case 1: return launch_skinny<1>(dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N, dW, lddw, dbias, s, lc);
@@ -1974,17 +1980,16 @@ int pn2_conv1x1_bwd_pair(const float *dZ, int ldz, const float *dZp, int ldo, co
                          float *dXout, int ldxo, double *prev_red, const float *X, int ldx, const float *x_affine, float *dW, int lddw,
                          int64_t P, int C_out, int C_in, const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream) {
     PN2_CHECK_ARG(X && dW && C_out > 0 && C_in > 0 && ldx % 4 == 0 && ldx >= round4(C_in) && lddw >= C_in);
-    static const int on = pn2_env_int("PN2_BWD_PAIR", 1), small_p = pn2_env_int("PN2_TN_SMALLP", 65536);
-    static const int tn_cfg = pn2_env_int("PN2_TN_CFG", 0), tdepth = pn2_env_int("PN2_TN_SMALL_DEPTH", 2);
+    const int on = pn2_opt(PN2_OPT_BWD_PAIR), small_p = pn2_opt(PN2_OPT_TN_SMALLP);
+    const int tn_cfg = pn2_opt(PN2_OPT_TN_CFG), tdepth = pn2_opt(PN2_OPT_TN_SMALL_DEPTH);
     const int M = C_out, N = C_in;
     // the weight-gradient half rides in the data gradient's launch only where dispatch_tn would take its few-row configuration
     const bool tn_small = N > 32 && M > 32 && !(M <= 64 && N <= 64) && tn_cfg == 0 && tdepth == 2 &&
                           (P <= small_p || (P <= 2 * (int64_t)small_p && (int64_t)M * N <= 16384));
-    g_pair_job = PairJob{on && tn_small, false, X, ldx, x_affine, dW, lddw, M, N};
-    const int rc = pn2_conv1x1_dgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, W, ldw, prev_Y, ld_prev, prev_affine, dXout, ldxo, prev_red, P,
-                                     C_out, C_in, nullptr, coef_lazy, stream);
-    const bool taken = g_pair_job.taken;
-    g_pair_job.active = false;
+    PairJob job{on && tn_small, false, X, ldx, x_affine, dW, lddw, M, N};
+    const int rc = conv1x1_dgrad_impl(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, W, ldw, prev_Y, ld_prev, prev_affine, dXout, ldxo, prev_red, P,
+                                      C_out, C_in, nullptr, coef_lazy, stream, &job);
+    const bool taken = job.taken;
     if (rc != PN2_OK || taken) return rc;
     const int rc2 = pn2_conv1x1_wgrad(dZ, ldz, dZp, ldo, arg, Kpool, Y, ldy, coef, X, ldx, x_affine, dW, lddw, nullptr, P, C_out, C_in, nullptr,
                                       stream);

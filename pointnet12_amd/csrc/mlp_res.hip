@@ -493,7 +493,7 @@ int launch_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const
     // PN2_RES_HALF=0: the 8-wave form (A/B runs).  Same-box A/B (us): 96 x 64 at 1 M rows 404 -> 385, 64 x 64 at 524 k 153 -> 142,
     // 64 x 32 pooled at 524 k 89 -> 81, 32 x 32 at 524 k 66 -> 63; at 262 k rows the half-size workgroups' tails cost more
     // (52 -> 55, 41 -> 47: not taken there); one register set (a second one: 142 -> 146, 81 -> 86); the step: within noise.
-    static const int half = [] { const char *e = getenv("PN2_RES_HALF"); return e ? atoi(e) : 1; }();
+    const int half = pn2_opt(PN2_OPT_RES_HALF);
     if constexpr (CI_T <= 2 && 2 * sizeof(float) * (32 * CI_T * (32 * CO_T + 4) + RES_BM * (32 * CO_T + 4) + RES_BM * (32 * CI_T + 4) + 128 * CO_T) <= 160 * 1024) {
         if (half && tiles >= 32 * (int64_t)pn2_num_cus())           // (from 524 288 rows on: below, the two half-size workgroups' tails cost more)
             return launch_bwd_res_impl<CO_T, CI_T, POOL, MASKED, 1, false, 256>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s);
@@ -565,7 +565,7 @@ struct ResPool {
 };
 
 template <int K_T, int N_T, bool ACT, int POOL>      // POOL: 0 none, 1 groups of whole slabs (Kp % 32 == 0), 2 Kp == 16
-__global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ aff,
+__global__ __launch_bounds__(512, 2) void fwd_res_kernel(const float *__restrict__ X, int ldx, const float *aff /* written by the lazy prologue */,
                                                          const float *__restrict__ W, int ldw, const float *__restrict__ bias,
                                                          float *__restrict__ Y, int ldy, int64_t slabs, double *__restrict__ stats,
                                                          ResPool pool) {
@@ -794,10 +794,14 @@ template <int K_T, int N_T, bool ACT, int POOL>
 int launch_fwd_res(const float *X, int ldx, const float *aff, const float *W, int ldw, const float *bias, float *Y, int ldy,
                    int64_t P, double *stats, const ResPool &pool, hipStream_t s) {
     constexpr int K = 32 * K_T, N = 32 * N_T, LDA = K + 4;
-    const size_t fixed = sizeof(float) * ((size_t)N * LDA + 3 * K), per_wave = sizeof(float) * 32 * LDA;
-    int nw = (int)((160 * 1024 - fixed) / per_wave);
-    if (nw > 8) nw = 8;
-    if (nw < 8) return PN2_EUNSUPPORTED;                             // fewer than two waves per SIMD cannot fill each other's phases
+    constexpr size_t fixed = sizeof(float) * ((size_t)N * LDA + 3 * K), per_wave = sizeof(float) * 32 * LDA;
+    constexpr int nw_fit = (int)((160 * 1024 - fixed) / per_wave);
+    // fewer than two waves per SIMD cannot fill each other's phases: W plus eight staging buffers must fit the LDS.  Decided at
+    // compile time, so the shapes that do not fit (128 -> 64 / 96 / 128) are not instantiated at all (round 4 shipped them as
+    // dead code, one of them with 140 bytes of scratch that tools/check_isa.py had to allow-list)
+    if constexpr (nw_fit < 8) return PN2_EUNSUPPORTED;
+    else {
+    constexpr int nw = 8;
     size_t lds = fixed + nw * per_wave;
     const size_t red = sizeof(double) * 2 * N * nw;                 // the final fold reuses the image
     if (lds < red) lds = red;
@@ -809,6 +813,7 @@ int launch_fwd_res(const float *X, int ldx, const float *aff, const float *W, in
     hipLaunchKernelGGL((fwd_res_kernel<K_T, N_T, ACT, POOL>), dim3((unsigned)grid), dim3(64 * nw), lds, s, X, ldx, aff, W, ldw, bias, Y, ldy,
                        slabs, stats, pool);
     return pn2_launch_status();
+    }
 }
 
 template <int K_T, bool ACT, int POOL>
@@ -836,7 +841,7 @@ int dispatch_fwd_res(int K, int N, const float *X, int ldx, const float *aff, co
 }
 
 inline int res_min_rows() {
-    static const int v = [] { const char *e = getenv("PN2_RES_MIN_ROWS"); return e ? atoi(e) : 32768; }();
+    const int v = pn2_opt(PN2_OPT_RES_MIN_ROWS);
     return v;
 }
 
@@ -860,7 +865,7 @@ extern "C" int pn2_debug_stamps_res(unsigned long long *host_out, int n) {
 #endif
 
 extern "C" int pn2_res_supported(int64_t P, int C_out, int C_in) {
-    static const int on = [] { const char *e = getenv("PN2_RES"); return e ? atoi(e) : 1; }();
+    const int on = pn2_opt(PN2_OPT_RES);
     return on && P >= res_min_rows() && P < (1LL << 31) && res_shape_ok(C_out, C_in);
 }
 
@@ -890,7 +895,7 @@ int pn2_fwd_res(const float *X, int ldx, const float *in_affine, const float *W,
 namespace {
 // out[g,c] = relu(bn(v)) with v the recorded maximum where the folded scale is >= 0 and the minimum where it is negative; arg
 // = the row that attained it.  Pad columns (c >= C) get the zero pad of the affine block like pn2_bn_relu_max writes them.
-__global__ __launch_bounds__(256) void bn_pool_select_kernel(const float2 *__restrict__ rec, int ldp, const float *__restrict__ aff, int lda,
+__global__ __launch_bounds__(256) void bn_pool_select_kernel(const float2 *__restrict__ rec, int ldp, const float *aff /* written by the prologue */, int lda,
                                                              int64_t G, int C, float *__restrict__ out, int ldo, int32_t *__restrict__ arg,
                                                              LazyBn lz) {
     lazy_bn_prologue(lz);                                          // consumer-side BatchNorm (bounded grid: paid once per workgroup)
@@ -908,7 +913,12 @@ __global__ __launch_bounds__(256) void bn_pool_select_kernel(const float2 *__res
         o.z = fmaxf(bn_act(r23.x, mu.z, sc.z, be.z), 0.f);
         o.w = fmaxf(bn_act(r23.z, mu.w, sc.w, be.w), 0.f);
         *reinterpret_cast<float4 *>(out + g * ldo + c) = o;
-        *reinterpret_cast<int4 *>(arg + g * ldo + c) = make_int4(__float_as_int(r01.y), __float_as_int(r01.w), __float_as_int(r23.y), __float_as_int(r23.w));
+        // A channel whose BatchNorm weight is exactly 0 has scale 0: every row of the group gives relu(beta), and torch.max
+        // (model/pointnet_util.py:199, :256) routes the gradient of an all-equal group to its FIRST row -- not to the row with the
+        // largest pre-BN value the epilogue recorded (found by the signed-gamma test of round 5: d gamma of those channels).
+        *reinterpret_cast<int4 *>(arg + g * ldo + c) = make_int4(sc.x == 0.f ? 0 : __float_as_int(r01.y), sc.y == 0.f ? 0 : __float_as_int(r01.w),
+                                                                 sc.z == 0.f ? 0 : __float_as_int(r23.y),
+                                                                 sc.w == 0.f ? 0 : __float_as_int(r23.w));
     }
 }
 }  // namespace

@@ -465,12 +465,388 @@ int launch_regw(const RegwArgs &g, hipStream_t s) {
     return pn2_launch_status();
 }
 
-inline int wide_env(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
+
+// ================================================================================================ forward, LDS-DMA ring (round 5)
+// The same register-stationary product with the streamed operand moved global -> LDS by LDS-DMA (global_load_lds_dwordx4:
+// no VGPR destination) instead of through a register set of the staging threads, and with the two waves of every SIMD
+// running HALF A STEP APART.  What the in-kernel stamps of the register-staged kernel and of the first ring version said
+// (tools/stamp_wide.py, profiles/r05_stamp_ring.txt): the MFMA sections of a tile keep the matrix pipe busy, everything else --
+// the epilogue's 64 stores per wave (6 - 12 % of the launch), the barrier skew and the DMA / address phase behind each
+// barrier (9 - 14 %) -- happens on both waves of a SIMD at the same time, with the pipe idle.  So:
+//   * ring of FOUR slots, step s = (tile, 64-deep chunk); every wave: barrier, DMA of step s + 2 (its own 1-KiB pieces),
+//     first half of the step's k blocks with the BatchNorm + ReLU of step s + 1 applied IN PLACE between them (every thread
+//     its own float4 items: the staging pass of the kernel above, once per workgroup), s_waitcnt vmcnt(0) lgkmcnt(0), barrier,
+//     second half, epilogue after the last chunk of a tile;
+//   * waves NW / 2 .. NW - 1 (group B: the SECOND wave of every SIMD) execute one more barrier in front of the loop and the
+//     others (group A) one more behind it: identical code, B one barrier interval behind A.  A's epilogue and DMA issue then
+//     sit beside B's MFMAs and the other way round.  The fourth slot is what the lag costs: B still reads step s - 1 when
+//     A requests step s + 2.  Who needs what when (G(k): the k-th barrier interval; A runs its half steps 2 s, 2 s + 1 in
+//     G(2 s), G(2 s + 1), B in G(2 s + 1), G(2 s + 2)):
+//       DMA(s + 2)      issued at the head of G(2 s) (A) / G(2 s + 1) (B) into the slot of step s - 2, last read in G(2 s - 2);
+//                       waited for by its issuer at the end of that interval (half a step, > 3 us later);
+//       transform(s + 1) in the FIRST half step only: A's items in G(2 s), B's in G(2 s + 1); its raw data landed before
+//                       barrier 2 s (B's wait at the end of G(2 s - 1)); first read behind barrier 2 s + 2;
+//   * no load is visible to the compiler inside the tile loop, so it never waits for one (the register-staged kernel opened
+//     every tile with a vmcnt(0) that also waited for the HBM acknowledgement of the previous tile's 64 stores: loads and
+//     stores retire through one in-order counter).  Barriers are raw s_barrier: __syncthreads() would drain the DMA.
+//   LDS image of a chunk: row r = 64 floats = sixteen 16-byte slots, slot s holds the row's k quad s ^ (r & 15).  One DMA
+//   instruction writes 1 KiB = four whole rows (lane L: row 4 p + L / 16, slot L % 16), so the image is lane-linear as the
+//   DMA requires and the swizzle sits in the per-lane SOURCE address; the sixteen lanes of every ds_read_b128 service group
+//   ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: sixteen distinct r & 15) then read sixteen distinct slots: conflict-free
+//   without a padded pitch (SQ_LDS_BANK_CONFLICT 1.6e4 of 1.0e7 LDS cycles).  K = 196: the 49th quad (k = 192 .. 195) of
+//   the rows rides as a 16-byte-per-row image behind the last full chunk and is consumed as a ninth k block of that step
+//   (the lanes of the upper half-wave multiply it by the zero weights of k = 196 .. 199).
+#ifdef PN2_STAMP
+// Diagnostic build only (make STAMP=1): per-phase shader-cycle sums of every wave of the first 64 workgroups of the last ring
+// kernel launch (pn2_debug_stamps_wide).  Phases: 0 barriers, 1 DMA issue, 2 first half, 3 waits, 4 epilogue, 5 second half.
+__device__ unsigned long long pn2_wide_stamp_buf[64 * 8 * 8];
+#define WSTAMP_DECL unsigned long long wst_t = clock64(), wst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long wst_c0 = wst_t, wst_w0 = wall_clock64();
+#define WSTAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = clock64(); wst_acc[i] += n_ - wst_t; wst_t = n_; __builtin_amdgcn_sched_barrier(0); }
+#define WSTAMP_FLUSH(wv) { wst_acc[6] = clock64() - wst_c0; wst_acc[7] = wall_clock64() - wst_w0; if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) { for (int i_ = 0; i_ < 8; ++i_) pn2_wide_stamp_buf[(blockIdx.x * 8 + (wv)) * 8 + i_] = wst_acc[i_]; } }
+#else
+#define WSTAMP_DECL
+#define WSTAMP(i)
+#define WSTAMP_FLUSH(wv)
+#endif
+
+// 16 bytes per lane global -> LDS: the lane's bytes land at m0 + 16 lane.  `base` wave-uniform, `voff` the lane's byte offset.
+__device__ __forceinline__ void glds16(const float *base, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+// NX: N is a whole number of 32-column blocks (no column predicate: 64 unconditional stores per tile instead of 64 branches).
+// (Measured and removed, profiles/r05_ring_fwd.txt: the wave groups IN step -- same time within 1 %, the barrier waits move, the
+// total does not; the k block's MFMAs round robin over the row blocks instead of four dependent products per block -- equal.)
+template <int K4, int NCB, int RS, int TM, int MODE, int PKP, bool NX>
+__global__ __launch_bounds__(64 * NCB * RS) void ring_fwd_kernel(const RegwArgs g) {
+    constexpr int KC = 64, KP = (K4 + 7) & ~7, NW = NCB * RS, NT = 64 * NW, BM = 32 * TM * RS, LDPW = KC + 4;
+    constexpr int NCH = K4 / KC;                                    // steps per tile (full chunks)
+    constexpr bool TAIL = K4 % KC != 0;                             // one more k quad per row, riding with the last chunk
+    static_assert(K4 % KC == 0 || (K4 % KC == 4 && KP == K4 + 4), "a tail is exactly one quad");
+    static_assert(MODE == MODE_PLAIN || MODE == MODE_BNRELU, "forward modes");
+    constexpr int NTAB = MODE == MODE_BNRELU ? 3 : 0;
+    constexpr int NSLOT = 4;
+    constexpr int SLOTF = BM * KC + (TAIL ? BM * 4 : 0);            // floats per ring slot
+    constexpr int PIECES = BM / 4, PW = (PIECES + NW - 1) / NW;     // 1-KiB DMA pieces of a full chunk, per wave
+    constexpr int QI = BM * 16, A_IT = (QI + NT - 1) / NT;          // float4 items of a full chunk, per thread
+    constexpr bool HOIST = (NT / 16) % 16 == 0;                     // a thread's items share one k quad
+    constexpr int KBF = KC / 8, KBH = KBF / 2;                      // k blocks of a full chunk / of its first half
+    static_assert(BM % 64 == 0 && NW * 32 * LDPW <= NSLOT * SLOTF, "tail pieces are 64 rows; the W staging regions alias the ring");
+    static_assert(A_IT <= KBH + 1, "the transform fits the first half step");
+
+    float *tab = wide_lds + NSLOT * SLOTF;                          // NTAB rows of KP floats
+    float4 *lds4 = reinterpret_cast<float4 *>(wide_lds);
+    const unsigned ring_b = (unsigned)(uintptr_t)wide_lds;         // LDS byte address of the ring
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int cb = wave % NCB, rs = wave / NCB;
+    const int n = cb * 32 + l31;
+    const int N = g.N, K = g.K;
+    const bool grp_b = wave >= (NW + 1) / 2;                        // uniform
+    if (MODE == MODE_BNRELU) lazy_bn_prologue(g.lz);
+
+    // ---- one-time: this lane's slice of W (as regw_nt_kernel: through a wave-private LDS transposition)
+    float w[KP / 2];
+    {
+        float *reg = wide_lds + wave * (32 * LDPW);
+        const bool vec = (g.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(g.W) & 15) == 0 && (K & 3) == 0;
+        constexpr int NCW = (KP + KC - 1) / KC;
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) {
+            const int qt = ((KP - c * KC) < KC ? (KP - c * KC) : KC) / 4;
+            if (vec) {
+                for (int idx = lane; idx < 32 * qt; idx += 64) {
+                    const int row = idx / qt, q = idx - row * qt, k = c * KC + 4 * q, nn = cb * 32 + row;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (nn < N && k < K) v = ld4(g.W + (int64_t)nn * g.ldw + k);
+                    *reinterpret_cast<float4 *>(&reg[row * LDPW + 4 * q]) = v;
+                }
+            } else {
+                for (int idx = lane; idx < 32 * 4 * qt; idx += 64) {
+                    const int row = idx / (4 * qt), kk = idx - row * (4 * qt), k = c * KC + kk, nn = cb * 32 + row;
+                    reg[row * LDPW + kk] = (nn < N && k < K) ? g.W[(int64_t)nn * g.ldw + k] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < KC / 8; ++kb)
+                if (kb < qt / 2) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&reg[l31 * LDPW + 8 * kb + 4 * lh]);
+                    const int wi = (c * (KC / 8) + kb) * 4;
+                    w[wi] = v.x; w[wi + 1] = v.y; w[wi + 2] = v.z; w[wi + 3] = v.w;
+                }
+        }
+        __syncthreads();                                            // the regions alias the ring (no DMA in flight yet)
+    }
+    for (int i = t; i < NTAB * KP; i += NT) {
+        const int r = i / KP, k = i - r * KP;
+        tab[i] = k < K4 ? g.tab[r * K4 + k] : 0.f;
+    }
+
+    const int N4 = (N + 3) & ~3;
+    float e0 = n < N ? g.bias[n] : 0.f;
+    constexpr int FPOOL = PKP;
+    static_assert(FPOOL == 0 || (RS == 1 && BM % FPOOL == 0 && FPOOL % 32 == 0), "forward pooling: whole groups inside a wave's tile");
+    float e1 = 0.f;
+    if (FPOOL > 0) e1 = __int_as_float((n < N && g.pool_gamma[n] < 0.f) ? (int)0x80000000 : 0);
+    double st0 = 0.0, st1 = 0.0;
+    // (a use: the compiler waits for these two loads HERE, not at their first use behind the stores of the first epilogue)
+    asm volatile("" : "+v"(e0), "+v"(e1));
+
+    const int64_t tiles = g.tiles;
+    const int G = gridDim.x;
+    // ---- LDS-DMA of one chunk: piece p = rows 4 p .. 4 p + 3; this wave's pieces p = wave + NW i
+    const unsigned drow = (unsigned)(lane >> 4), dslot = (unsigned)(lane & 15);
+    auto issue_dma = [&](int64_t tile_, int c, unsigned slot) {       // slot: float offset of the ring slot in wide_lds
+        const unsigned tl = (unsigned)(tile_ < tiles ? tile_ : tiles - 1);    // past the end: the last tile once more (never used)
+        const float *base = g.A + (size_t)tl * BM * (unsigned)g.lda + (unsigned)(c * KC);        // uniform
+        const unsigned sb = ring_b + slot * 4u;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            int p = wave + NW * i;
+            if (PIECES % NW != 0 && p >= PIECES) p = PIECES - 1;    // dummy: the last piece once more (same bytes, same place)
+            const unsigned row = 4u * (unsigned)p + drow, q = dslot ^ (row & 15u);
+            glds16(base, 4u * (row * (unsigned)g.lda + 4u * q), (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)p * 1024u)));
+        }
+        if (TAIL && c == NCH - 1 && wave < BM / 64) {               // quad K4 / 4 - 1 of 64 rows per piece
+            const unsigned row = 64u * (unsigned)wave + (unsigned)lane;
+            glds16(base, 4u * (row * (unsigned)g.lda + (unsigned)KC),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)(BM * KC * 4) + (unsigned)wave * 1024u)));
+        }
+    };
+    // ---- BatchNorm + ReLU of a landed chunk, in place: item i of thread t is the float4 at 4 (t + NT i)
+    struct Consts { float4 mu, sc, be; };
+    const int xrow = t >> 4, xslot = t & 15;
+    auto chunk_consts = [&](int c) {
+        Consts o;
+        const int k = c * KC + 4 * (xslot ^ (xrow & 15));
+        o.mu = *reinterpret_cast<const float4 *>(&tab[k]);
+        o.sc = *reinterpret_cast<const float4 *>(&tab[KP + k]);
+        o.be = *reinterpret_cast<const float4 *>(&tab[2 * KP + k]);
+        return o;
+    };
+    auto act4 = [&](float4 x, const float4 &mu, const float4 &sc, const float4 &be) {
+        x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f);
+        x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+        x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f);
+        x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+        return x;
+    };
+    auto xform_item = [&](unsigned slot, int c, int i, const Consts &cc) {
+        if (MODE != MODE_BNRELU) return;
+        if (NT * i >= QI) return;                                    // static
+        const int idx = t + NT * i;
+        if (NT * (i + 1) > QI && idx >= QI) return;                  // the last, partly filled pass
+        float4 *p = &lds4[slot / 4u + (unsigned)idx];
+        if (HOIST) *p = act4(*p, cc.mu, cc.sc, cc.be);
+        else {
+            const int row = idx >> 4, k = c * KC + 4 * ((idx & 15) ^ (row & 15));
+            *p = act4(*p, *reinterpret_cast<const float4 *>(&tab[k]), *reinterpret_cast<const float4 *>(&tab[KP + k]),
+                      *reinterpret_cast<const float4 *>(&tab[2 * KP + k]));
+        }
+    };
+    auto xform_tail = [&](unsigned slot) {                           // the tail quad of row t (k = K4 - 4 .. K4 - 1)
+        if (MODE != MODE_BNRELU || !TAIL) return;
+        if (t < BM) {
+            float4 *p = &lds4[slot / 4u + (unsigned)(BM * KC / 4 + t)];
+            constexpr int k = K4 - 4;
+            *p = act4(*p, *reinterpret_cast<const float4 *>(&tab[k]), *reinterpret_cast<const float4 *>(&tab[KP + k]),
+                      *reinterpret_cast<const float4 *>(&tab[2 * KP + k]));
+        }
+    };
+
+    // ---- prologue: steps 0 and 1 requested, step 0 transformed
+    unsigned cur = 0u, nxt = SLOTF, nx2 = 2 * SLOTF, nx3 = 3 * SLOTF;
+    int64_t tile = blockIdx.x;
+    issue_dma(tile, 0, cur);
+    if (NCH > 1) issue_dma(tile, 1, nxt); else issue_dma(tile + G, 0, nxt);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces have landed, its table entries are written
+    asm volatile("s_barrier" ::: "memory");                         // ... everybody's
+    {
+        const Consts c0 = (MODE == MODE_BNRELU && HOIST) ? chunk_consts(0) : Consts{};
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) xform_item(cur, 0, i, c0);
+        if (NCH == 1) xform_tail(cur);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (grp_b) asm volatile("s_barrier" ::: "memory");              // group B: one barrier interval behind from here on
+
+    // lane part of the operand address in float4 units: row (rs TM 32 + l31), k quad (2 kb + lh) ^ (l31 & 15)
+    // (float4 units on purpose: with float offsets hipcc lost the 16-byte alignment through the rotating slot offsets and split
+    // every operand read into two ds_read2_b32 -- 2.2e7 bank-conflict cycles per launch)
+    const unsigned arow4 = (unsigned)((rs * TM * 32 + l31) * (KC / 4));
+    const unsigned ax = (unsigned)(l31 & 15);
+    const unsigned atail4 = (unsigned)(BM * KC / 4 + (rs * TM * 32 + l31));
+
+    WSTAMP_DECL
+    while (tile < tiles) {
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool last = c == NCH - 1;
+            const int64_t t1 = last ? tile + G : tile;              // step s + 1: transformed during the first half of this step
+            const int c1 = last ? 0 : c + 1;
+            const bool last1 = c1 == NCH - 1;
+            const int64_t t2 = last1 ? t1 + G : t1;                 // step s + 2: requested now
+            const int c2 = last1 ? 0 : c1 + 1;
+            const int kbs = KBF + ((TAIL && last) ? 1 : 0);         // 8-wide k blocks of this step
+            // ((2 kb + lh) ^ ax) = (2 kb) ^ (lh ^ ax): one opaque register per step, so that hipcc re-derives the eight
+            // operand addresses of a step with one v_xor each instead of keeping them (and their per-slot sums) in
+            // registers across the tile loop (the 128 -> 256 instantiation spilled 34 loop-invariant registers)
+            unsigned ay = (unsigned)lh ^ ax;
+            asm volatile("" : "+v"(ay));
+            auto a_read = [&](int kb, int i) {
+                if (kb < KBF) return lds4[cur / 4u + arow4 + (unsigned)(i * 32 * KC / 4) + ((unsigned)(2 * kb) ^ ay)];
+                return lds4[cur / 4u + atail4 + (unsigned)(i * 32)];
+            };
+            float4 a[2][TM];
+            auto k_block = [&](int kb, bool xf, const Consts &cc) {
+                __builtin_amdgcn_sched_barrier(0);                  // (k blocks stay apart: hipcc otherwise overlaps several and spills)
+                asm volatile("" ::: "memory");
+                if (kb + 1 < kbs) {                                 // operand reads run one k block ahead (also across the mid-step barrier)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[(kb + 1) & 1][i] = a_read(kb + 1, i);
+                }
+                if (xf) {
+#pragma unroll
+                    for (int i = 0; i < A_IT; ++i)
+                        if ((i < KBH ? i : KBH - 1) == kb) xform_item(nxt, c1, i, cc);
+                    if (kb == KBH - 1 && TAIL && last1) xform_tail(nxt);
+                }
+                asm volatile("" ::: "memory");
+                const int wi = (c * KBF + kb) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float4 av = a[kb & 1][i];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, w[wi + 0], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, w[wi + 1], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, w[wi + 2], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, w[wi + 3], acc[i], 0, 0, 0);
+                }
+            };
+            WSTAMP(5)
+            // ---- first half: request step s + 2, transform step s + 1
+            asm volatile("s_barrier" ::: "memory");
+            WSTAMP(0)
+            issue_dma(t2, c2, nx2);
+            WSTAMP(1)
+            {
+                const Consts cc = (MODE == MODE_BNRELU && HOIST) ? chunk_consts(c1) : Consts{};
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[0][i] = a_read(0, i);
+#pragma unroll
+                for (int kb = 0; kb < KBH; ++kb) k_block(kb, true, cc);
+            }
+            WSTAMP(2)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // own DMA pieces of step s + 2 (and older stores); own in-place writes
+            WSTAMP(3)
+            // ---- second half
+            asm volatile("s_barrier" ::: "memory");
+            WSTAMP(0)
+#pragma unroll
+            for (int kb = KBH; kb < KBF + 1; ++kb)
+                if (kb < kbs) k_block(kb, false, Consts{});
+            const unsigned tp = cur; cur = nxt; nxt = nx2; nx2 = nx3; nx3 = tp;
+        }
+        WSTAMP(5)
+        // ---- epilogue straight from the accumulators: column on the lane, 128 contiguous bytes per half-wave and register;
+        // wave-uniform base + one 32-bit lane offset (an SGPR-base store: no 64-bit address arithmetic per store)
+        {
+            float *yb = g.Out + ((size_t)(unsigned)tile * BM + (unsigned)(rs * TM * 32)) * (unsigned)g.ldout;      // uniform
+            unsigned off = (unsigned)(4 * lh) * (unsigned)g.ldout + (unsigned)n;
+            asm volatile("" : "+v"(off));                            // (opaque per tile: 64 store addresses are not hoisted into registers)
+            const unsigned lo = off;
+            float s0 = 0.f, s1 = 0.f;
+            constexpr int GPT = FPOOL > 0 ? BM / (FPOOL > 0 ? FPOOL : 1) : 1, BPG = FPOOL > 0 ? FPOOL / 32 : TM;
+            const int sg = __float_as_int(e1);
+            float mv[GPT];
+            int mk[GPT];
+#pragma unroll
+            for (int gq = 0; gq < GPT; ++gq) { mv[gq] = -INFINITY; mk[gq] = 0; }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y = acc[i][r] + e0;
+                    if (NX || n < N4) PN2_STREAM_STORE(y, yb + off);      // pad columns receive exact zeros (w = bias = 0)
+                    s0 += y;
+                    s1 = __builtin_fmaf(y, y, s1);
+                    if (FPOOL > 0) {
+                        // ascending block, ascending register = ascending row for this lane: a strict > keeps the first row
+                        const int gq = i / BPG;
+                        const float yp = __int_as_float(__float_as_int(y) ^ sg);
+                        const int row = (i - gq * BPG) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        mk[gq] = yp > mv[gq] ? row : mk[gq];
+                        mv[gq] = fmaxf(mv[gq], yp);
+                    }
+                    off += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldout;   // rows (r & 3) + 8 (r >> 2): +1 +1 +1 +5
+                }
+            if (FPOOL > 0) {
+#pragma unroll
+                for (int gq = 0; gq < GPT; ++gq) {
+                    const float ov = __shfl_xor(mv[gq], 32, 64);   // the two half-waves hold disjoint rows of the column
+                    const int ok = __shfl_xor(mk[gq], 32, 64);
+                    const bool take = ov > mv[gq] || (ov == mv[gq] && ok < mk[gq]);
+                    const float v = take ? ov : mv[gq];
+                    const int k = take ? ok : mk[gq];
+                    // unconditional 8-byte stores, the same number every tile (both half-waves write the same record)
+                    if (NX || n < N4)
+                        g.pool_rec[(int64_t)((unsigned)tile * GPT + gq) * g.pool_ld + (unsigned)n] =
+                            make_float2(__int_as_float(__float_as_int(v) ^ sg), __int_as_float(k));
+                }
+            }
+            (void)lo;
+            st0 += (double)s0; st1 += (double)s1;
+        }
+        WSTAMP(4)
+        tile += G;
+    }
+    WSTAMP_FLUSH(wave)
+    if (!grp_b) asm volatile("s_barrier" ::: "memory");             // group A: the barrier group B is one short of
+    if (g.red != nullptr) {
+        st0 += __shfl_xor(st0, 32, 64);
+        st1 += __shfl_xor(st1, 32, 64);
+        if (lh == 0 && n < N) {
+            double *rep = g.red + (size_t)(blockIdx.x % PN2_STAT_REPLICAS) * 2 * N;
+            atomicAdd(rep + n, st0);
+            atomicAdd(rep + N + n, st1);
+        }
+    }
+}
+
+template <int K4, int NCB, int RS, int TM, int MODE, int PKP, bool NX>
+int launch_ring_fwd_nx(const RegwArgs &g, hipStream_t s) {
+    constexpr int KC = 64, KP = (K4 + 7) & ~7, BM = 32 * TM * RS;
+    constexpr int SLOTF = BM * KC + (K4 % KC != 0 ? BM * 4 : 0);
+    constexpr int NTAB = MODE == MODE_BNRELU ? 3 : 0;
+    constexpr size_t lds = sizeof(float) * (4 * SLOTF + NTAB * KP);
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = ring_fwd_kernel<K4, NCB, RS, TM, MODE, PKP, NX>;
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
+    const int64_t cap = pn2_num_cus();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles < cap ? g.tiles : cap)), dim3(64 * NCB * RS), lds, s, g);
+    return pn2_launch_status();
+}
+
+template <int K4, int NN, int NCB, int RS, int TM, int MODE, int PKP = 0>
+int launch_ring_fwd(const RegwArgs &g, hipStream_t s) {
+    static_assert(NN <= 32 * NCB && NN > 32 * (NCB - 1), "column blocks");
+    return launch_ring_fwd_nx<K4, NCB, RS, TM, MODE, PKP, NN % 32 == 0>(g, s);
 }
 
 }  // namespace
+
+#ifdef PN2_STAMP
+extern "C" int pn2_debug_stamps_wide(unsigned long long *host_out, int n) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pn2_wide_stamp_buf), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------ dispatch
 // Shapes with an instantiation (every one is a fully unrolled kernel of its own).  Rows: whole tiles of BM; the caller runs
@@ -483,9 +859,12 @@ inline int wide_env(const char *name, int dflt) {
 int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y, int ldy,
                  int64_t P, int K, int N, double *stats, LazyBn lz, hipStream_t s, int64_t *rows_done, int Kpool,
                  const float *pool_gamma, float *pool_ws) {
-    static const int on = wide_env("PN2_WIDE", 1), min_rows = wide_env("PN2_WIDE_MIN_ROWS", PN2_WIDE_MIN_ROWS_DEFAULT);
+    const int on = pn2_opt(PN2_OPT_WIDE), min_rows = pn2_opt(PN2_OPT_WIDE_MIN_ROWS);
     *rows_done = 0;
     if (!on || P < min_rows || ldx != ((K + 3) & ~3)) return PN2_EUNSUPPORTED;
+    // the LDS-DMA ring form (16-byte aligned rows; PN2_RING=0: the register-staged kernel, A/B runs)
+    const int ring_on = pn2_opt(PN2_OPT_RING);
+    const bool ring = ring_on && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     RegwArgs g{};
     g.lz = lz;
     g.A = X; g.lda = ldx; g.tab = in_affine; g.W = W; g.ldw = ldw; g.bias = bias; g.Out = Y; g.ldout = ldy; g.red = stats;
@@ -493,13 +872,14 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
     g.pool_rec = reinterpret_cast<float2 *>(pool_ws); g.pool_gamma = pool_gamma; g.pool_ld = N;
     if (Kpool > 0) {
         // the last layer of a pooled MLP: whole tiles only (a pooled launch has no streamed tail), needs an input affine block
-        static const int pool_on = wide_env("PN2_WIDE_POOL", 1);
+        const int pool_on = pn2_opt(PN2_OPT_WIDE_POOL);
         if (!pool_on || !in_affine || !pool_gamma || !pool_ws || P % 128 != 0) return PN2_EUNSUPPORTED;
 #define WIDE_FWD_POOL(KK, NN, NCB, TM, PKP)                                                                              \
         if (K == KK && N == NN && Kpool == PKP) {                                                                        \
             static_assert(32 * TM == 128, "pooled forward: 128-row tiles");                                              \
             g.tiles = P / 128;                                                                                           \
             *rows_done = P;                                                                                              \
+            if (ring) return launch_ring_fwd<((KK + 3) & ~3), NN, NCB, 1, TM, MODE_BNRELU, PKP>(g, s);                     \
             return launch_regw<((KK + 3) & ~3), NCB, 1, TM, 64, MODE_BNRELU, EPI_FWD, false, PKP>(g, s);                  \
         }
         WIDE_FWD_POOL(128, 256, 8, 4, 64)         // sa2 of MSG (K = 64), PointNet2ClsMsg
@@ -513,6 +893,8 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
         constexpr int BM = 32 * TM * RS;                                                                                 \
         g.tiles = P / BM;                                                                                                \
         *rows_done = g.tiles * BM;                                                                                       \
+        if (ring && in_affine) return launch_ring_fwd<((KK + 3) & ~3), NN, NCB, RS, TM, MODE_BNRELU>(g, s);                \
+        if (ring) return launch_ring_fwd<((KK + 3) & ~3), NN, NCB, RS, TM, MODE_PLAIN>(g, s);                              \
         if (in_affine) return launch_regw<((KK + 3) & ~3), NCB, RS, TM, 64, MODE_BNRELU, EPI_FWD, false>(g, s);          \
         return launch_regw<((KK + 3) & ~3), NCB, RS, TM, 64, MODE_PLAIN, EPI_FWD, false>(g, s);                          \
     }
@@ -529,7 +911,7 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
 int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *W, int ldw, const float *prev_Y, int ld_prev, const float *prev_affine,
                    float *dXout, int ldxo, double *prev_red, int64_t P, int K, int N, LazyCoef lc, hipStream_t s, int64_t *rows_done) {
-    static const int on = wide_env("PN2_WIDE", 1), min_rows = wide_env("PN2_WIDE_MIN_ROWS", PN2_WIDE_MIN_ROWS_DEFAULT);
+    const int on = pn2_opt(PN2_OPT_WIDE), min_rows = pn2_opt(PN2_OPT_WIDE_MIN_ROWS);
     *rows_done = 0;
     if (!on || P < min_rows || ldy != ((K + 3) & ~3) || prev_Y == nullptr) return PN2_EUNSUPPORTED;
     if (!dZ && (Kpool <= 0 || P % Kpool != 0)) return PN2_EUNSUPPORTED;
@@ -546,7 +928,7 @@ int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
         return launch_regw<((KK + 3) & ~3), NCB, RS, TM, KC, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, EPI_MASK, true, PKP, ADB>(g, s); \
     }
     WIDE_DGRAD(128, 128, 4, 2, 2, 64, 0, true, 98304)      // 65 536 rows: ties the streamed kernel (33.9 vs 33.6 us)
-    static const int adb196 = wide_env("PN2_WIDE_ADB196", 1);      // A/B: operand reads one k block ahead (two register sets)
+    const int adb196 = pn2_opt(PN2_OPT_WIDE_ADB196);      // A/B: operand reads one k block ahead (two register sets)
     if (adb196) { WIDE_DGRAD(196, 128, 4, 2, 2, 64, 0, true, 0) }
     WIDE_DGRAD(196, 128, 4, 2, 2, 64, 0, false, 0)
     WIDE_DGRAD(256, 128, 4, 2, 1, 128, 64, true, 0)
@@ -874,8 +1256,8 @@ int launch_wgrad_full(WgradArgs g, hipStream_t s) {
 int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *Y, int ldy,
                    const float *coef, const float *X, int ldx, const float *x_affine, float *dW, int lddw, float *dbias,
                    int64_t P, int M, int N, LazyCoef lc, hipStream_t s, float *workspace) {
-    static const int on = wide_env("PN2_WIDE", 1) && wide_env("PN2_WIDE_WGRAD", 1);
-    static const int min_rows = wide_env("PN2_WIDE_WGRAD_MIN_ROWS", 131072);
+    const int on = pn2_opt(PN2_OPT_WIDE) && pn2_opt(PN2_OPT_WIDE_WGRAD);
+    const int min_rows = pn2_opt(PN2_OPT_WIDE_WGRAD_MIN_ROWS);
     if (!on || P < min_rows || x_affine == nullptr || ldy != ((M + 3) & ~3) || ldx != ((N + 3) & ~3)) return PN2_EUNSUPPORTED;
     if (!dZ && (Kpool <= 0 || P % Kpool != 0)) return PN2_EUNSUPPORTED;
     if (dZ && ldz != ldy) return PN2_EUNSUPPORTED;                 // (one lane offset serves Y and dZ)
@@ -899,12 +1281,12 @@ int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
 // Bytes of caller scratch with which pn2_conv1x1_wgrad flushes dW in two phases (0: this shape keeps the atomic flush, or the
 // two-phase form is switched off: PN2_WGRAD_TWO_PHASE, default by measurement -- see DESIGN.md section 4).
 int64_t pn2_wide_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled) {
-    static const int on = wide_env("PN2_WIDE", 1) && wide_env("PN2_WIDE_WGRAD", 1) && wide_env("PN2_WGRAD_TWO_PHASE", 0);
-    static const int min_rows = wide_env("PN2_WIDE_WGRAD_MIN_ROWS", 131072);
+    const int on = pn2_opt(PN2_OPT_WIDE) && pn2_opt(PN2_OPT_WIDE_WGRAD) && pn2_opt(PN2_OPT_WGRAD_TWO_PHASE);
+    const int min_rows = pn2_opt(PN2_OPT_WIDE_WGRAD_MIN_ROWS);
     if (!on || P < min_rows) return 0;
     // measured alone on the chip (us, atomic flush -> two-phase): 256 x 196 360.8 -> 340.4, 196 x 128 192.2 -> 193.8, 256 x 128
     // 105.9 -> 111.3: only the largest product has a tail long enough to pay for the second launch
-    static const int all = wide_env("PN2_WGRAD_TWO_PHASE_ALL", 0);
+    const int all = pn2_opt(PN2_OPT_WGRAD_TWO_PHASE_ALL);
     const bool shape = (M == 256 && N == 196 && pooled) || (all && ((M == 256 && N == 128 && pooled) || (M == 196 && N == 128 && !pooled)));
     if (!shape) return 0;
     return (int64_t)pn2_num_cus() * ((M + 31) / 32 * 32) * ((N + 31) / 32 * 32) * (int64_t)sizeof(float);

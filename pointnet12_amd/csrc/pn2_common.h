@@ -29,6 +29,55 @@ static inline hipStream_t pn2_s(pn2_stream_t s) { return reinterpret_cast<hipStr
 
 static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ----------------------------------------------------------------------------- library options
+// Dispatch / tuning switches of the library.  They are set EXPLICITLY through pn2_set_option() (include/pn2.h): the library
+// never reads the process environment, so an external caller's results depend on its arguments and on the options it set,
+// nothing else (the Python binding forwards PN2_* environment variables for A/B runs -- _lib.load()).
+// Every default is the measured winner.  Read per call (a relaxed load): an option changed between two calls takes effect.
+#define PN2_OPTION_LIST(X) \
+    X(FPS_ROWS_MIN_PPT, 24) /* FPS rows kernel: points per thread from which it replaces the wave-level pruned kernel */ \
+    X(FPS_ROWMAP, 2) /* FPS rows kernel: row ownership (0 contiguous run per wave, 1 round robin, 2 groups of four rows round robin) */ \
+    X(FPS_SINGLE_MAX, 24576) /* largest cloud of the single-workgroup FPS kernel (clamped to 16384 .. 28672) */ \
+    X(FPS_COOP, 1) /* cooperative multi-workgroup FPS above FPS_SINGLE_MAX */ \
+    X(FPS_PRUNE, 1) /* spatially pruned FPS kernels (8192 < N) */ \
+    X(BQ_ORDER, 1) /* ball query: centres taken in Morton order (pn2_ball_query_ws) */ \
+    X(FEWROW_MAX_TILES, 1024) /* fewrow_nt_kernel (forward): largest 32 x 64 tile count it takes (0: off) */ \
+    X(FEWROW_MAX_TILES_DGRAD, 512) /* the same for the data gradient */ \
+    X(FEWROW_KS, 0) /* fewrow_nt_kernel: waves per tile (0: automatic) */ \
+    X(NT_CFG, 0) /* NT GEMM tile override (tuning) */ \
+    X(NT_SMALL_DEPTH, 1) /* few-row NT GEMM: k-steps in flight / accumulator chains / rotated k order (1 .. 4) */ \
+    X(NT_NSPLIT, 1) /* 129 .. 224 output columns as 128 + remainder */ \
+    X(TN_SPLITDIV, 1) /* weight-gradient split depth divisor */ \
+    X(TN_CFG, 0) /* TN GEMM tile override (tuning) */ \
+    X(TN_NARROW, 1) /* 32 x 32 / 64 x 32 wave-split tiles for narrow weight gradients */ \
+    X(TN_SMALLP, 65536) /* 64 x 64 tiles up to this many rows */ \
+    X(TN_SMALL_DEPTH, 2) /* few-row TN GEMM: stages in flight */ \
+    X(CF_WGS_PER_CU, 2) /* closed-form first-layer weight gradient: workgroups per CU */ \
+    X(WGRAD_SKINNY, 1) /* streaming first-layer weight-gradient kernel */ \
+    X(BWD_PAIR, 1) /* pn2_conv1x1_bwd_pair: dgrad + wgrad bodies in one launch */ \
+    X(RES, 1) /* weight-resident kernels (csrc/mlp_res.hip) */ \
+    X(RES_MIN_ROWS, 32768) /* rows from which they take a layer */ \
+    X(RES_HALF, 1) /* two 4-wave workgroups per CU on the fused backward pairs that fit twice */ \
+    X(WIDE, 1) /* register-stationary kernels (csrc/mlp_wide.hip) */ \
+    X(WIDE_MIN_ROWS, 65536) /* rows from which they take a layer */ \
+    X(RING, 0) /* forward: the LDS-DMA ring form of the register-stationary kernel (measured equal: DESIGN.md section 4) */ \
+    X(WIDE_POOL, 1) /* pooling extrema in the register-stationary forward's epilogue */ \
+    X(WIDE_ADB196, 1) /* 196 -> 128 data gradient: operand reads one k block ahead */ \
+    X(WIDE_WGRAD, 1) /* full-tile weight gradient */ \
+    X(WIDE_WGRAD_MIN_ROWS, 131072) /* rows from which it takes a layer */ \
+    X(WGRAD_TWO_PHASE, 0) /* two-phase dW flush through caller scratch (256 x 196) */ \
+    X(WGRAD_TWO_PHASE_ALL, 0) /* ... for all three full-tile shapes */ \
+    X(SEG_CHUNK, 0) /* segmented scatter: members per lane group (0: automatic) */
+
+enum Pn2Option {
+#define PN2_X(name, dflt) PN2_OPT_##name,
+    PN2_OPTION_LIST(PN2_X)
+#undef PN2_X
+    PN2_OPT_COUNT
+};
+extern int pn2_option_table[PN2_OPT_COUNT];                          // api.hip
+static inline int pn2_opt(int id) { return __atomic_load_n(&pn2_option_table[id], __ATOMIC_RELAXED); }
+
 // Current device, clamped to the per-device tables below (a process driving more than PN2_MAX_DEVICES GPUs shares the
 // last slot, which only costs it a redundant attribute call or a CU count of the wrong device for grid sizing).
 #define PN2_MAX_DEVICES 16

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void invert_lds_kernel(const int64_t *__restr
 // Members per lane group: long chunks mean few segments straddle a boundary (those add atomically, the rest is stored), short
 // ones mean more lane groups in flight; 64 where that still leaves eight waves per CU, else 32 (four), else 16.  PN2_SEG_CHUNK: A/B.
 static int seg_chunk(int64_t members, int lanes_per_row) {
-    static const int forced = [] { const char *e = getenv("PN2_SEG_CHUNK"); return e ? atoi(e) : 0; }();
+    const int forced = pn2_opt(PN2_OPT_SEG_CHUNK);
     if (forced == 16 || forced == 32 || forced == 64) return forced;
     const int64_t per_cu = (int64_t)pn2_num_cus() * (64 / lanes_per_row);           // lane groups of one wave per CU
     if (members / 64 >= 8 * per_cu) return 64;                                       // (measured on the MSG / SSG level sizes:
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void three_interp_bwd_seg_kernel(const float *
 // workgroup, one atomic per (c, a) and workgroup).  A lane owns a float4 of channels; LPR lanes per member row.
 __global__ __launch_bounds__(256) void group_affine_bwd_seg_kernel(const float *__restrict__ dZ, int ldz,
                                                                    const float *__restrict__ Y, int ldy,
-                                                                   const float *__restrict__ coef, int ldc,
+                                                                   const float *coef, int ldc,   // (no __restrict__: the prologue writes it)
                                                                    const float *__restrict__ xyz,
                                                                    const float *__restrict__ new_xyz,
                                                                    const int *__restrict__ members,

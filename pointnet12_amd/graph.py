@@ -20,8 +20,8 @@ from . import pointnet_util as U
 
 _GEO_FIRST = os.environ.get("PN2_GEO_FIRST", "1") == "1"      # capture order of the two branches (the executor's launch order follows it)
 # GraphedStep(fork_in_step=True): the geometry branch of the captured step (the NEXT batch's FPS / ball query / 3-NN: 0.55 ms on
-# 16 .. 64 CUs) starts where the step function calls graph.fork_point() -- bench.py (B = 16 x 4096) and tools/train_synthetic.py
-# call it between forward and backward, so the branch
+# 16 .. 64 CUs) starts where the step function calls graph.fork_point() -- bench.py (B = 16 x 4096) calls it between forward and
+# backward, so the branch
 # runs under the head / FP / sa4 / sa3 backward launches that do not fill the chip instead of under sa1's forward kernels, whose
 # one-workgroup-per-CU grids lose the CUs the FPS workgroups hold (same box, round 4: MSG 5.85 / 5.84 -> 5.75 / 5.78 ms, SSG within
 # noise; cfg2, whose step IS the FPS chain, and cfg5 lose with it: 0.68 -> 0.76 ms, 6.30 -> 6.40 ms -- hence opt-in).
@@ -97,6 +97,10 @@ class GraphedStep:
     """
 
     def __init__(self, fn, device, warmup=3, geometry_fn=None, fork_in_step=False):
+        if fork_in_step and geometry_fn is None:
+            raise ValueError("fork_in_step=True needs a geometry_fn: without a geometry branch there is nothing to fork "
+                             "(graph.fork_point() in the step function would be a no-op)")
+        self.fork_point_reached = None           # prefetch captures with fork_in_step: did fn() call graph.fork_point()?
         if geometry_fn is not None:
             self._init_prefetch(fn, geometry_fn, device, warmup, fork_in_step and _GEO_FORK_LATE)
             return
@@ -178,8 +182,10 @@ class GraphedStep:
                         forked[0] = True
                         geo_stream.wait_stream(torch.cuda.current_stream(device))
                         keep = U.get_geometry_tape()
-                        geometry_branch()
-                        U.set_geometry_tape(keep)
+                        try:
+                            geometry_branch()
+                        finally:                                   # (a raising geometry_fn must not leave the step on the wrong tape)
+                            U.set_geometry_tape(keep)
 
                     global _fork_cb
                     if _GEO_FIRST and not fork_in_step:
@@ -193,7 +199,14 @@ class GraphedStep:
                     finally:
                         _fork_cb = None
                     U.set_geometry_tape(None)
+                    if fork_in_step:
+                        self.fork_point_reached = forked[0]
                     if not forked[0]:
+                        if fork_in_step:
+                            import warnings
+                            warnings.warn("GraphedStep(fork_in_step=True): the step function never called graph.fork_point(); the "
+                                          "geometry branch was captured behind it and depends on the TOP of the step only "
+                                          "(the PN2_GEO_FIRST=0 order), not where the caller meant it to start")
                         geometry_branch()
                         U.set_geometry_tape(None)
                     main.wait_stream(geo_stream)

@@ -108,6 +108,8 @@ class FlatGradBucket:
         self.reduced = None       # event: the last all-reduce has finished
         self.n_late = 0           # two-bucket protocol: flat[:n_late] = the gradients the backward produces LAST
         self.early_ready = None   # event recorded inside the step where flat[n_late:] is final
+        self._early_marked = False      # mark_early_ready() fired in the (eager) step that precedes this all-reduce
+        self._early_in_graph = False    # ... or was captured into the step's graph (every replay records it)
 
     def use_comm_stream(self):
         """Issue the all-reduce on a stream of its own.  The step that follows only has to wait where it first touches the
@@ -122,7 +124,9 @@ class FlatGradBucket:
 
     def use_two_buckets(self, late_params):
         """Two-bucket protocol (VERDICT r3 #7b): the gradients of ``late_params`` -- the stage the backward reaches last, sa1 --
-        form a small LATE bucket, everything else the EARLY bucket.  The step calls ``mark_early_ready()`` where the early
+        form a small LATE bucket, everything else the EARLY bucket.  EXPERIMENTAL: no runtime of this pool accepts the external
+        event record under capture it needs, so the GPU path has never run to RCCL-TWO-BUCKET-OK; an
+        all-reduce whose step did not call ``mark_early_ready()`` falls back to the one-bucket order.  The step calls ``mark_early_ready()`` where the early
         gradients are final (a tensor hook on sa1's output: autograd has accumulated its gradient, i.e. every later stage's
         backward has been issued); the early all-reduce then runs on the comm stream UNDER sa1's backward, and only the late
         bucket (a few hundred KB) is reduced behind the step.  ``late_params`` must be a prefix of the bucket (the first stage of
@@ -146,9 +150,16 @@ class FlatGradBucket:
         return self
 
     def mark_early_ready(self):
-        """Called by the step where every gradient outside the late bucket is final (no-op without the two-bucket protocol)."""
+        """Called by the step where every gradient outside the late bucket is final (no-op without the two-bucket protocol).
+        Sets the flag ``_all_reduce`` consumes: without it -- the hook never armed, the first stage's output not requiring a
+        gradient, a step that did not run the hook -- the early collective would bind to the PREVIOUS step's record and reduce
+        gradients the backward is still writing; the all-reduce then falls back to one reduce behind the whole step."""
         if self.early_ready is not None:
             self.early_ready.record(torch.cuda.current_stream(self.flat.device))
+            if self.flat.is_cuda and torch.cuda.is_current_stream_capturing():
+                self._early_in_graph = True
+            else:
+                self._early_marked = True
 
     def arm(self, first_stage):
         """Wire ``mark_early_ready`` into a network: a forward hook on its first stage (``net.sa1``) puts a tensor hook on the
@@ -218,6 +229,13 @@ class FlatGradBucket:
                 reduce_(late)
                 if marks:
                     marks[1].record()
+                return
+            marked, self._early_marked = (self._early_marked or self._early_in_graph), False
+            if not marked:                                 # no record belongs to this step: one reduce behind the whole step
+                self.comm.wait_stream(torch.cuda.current_stream(self.flat.device))
+                with torch.cuda.stream(self.comm):
+                    collective()
+                    self.reduced.record(self.comm)
                 return
             self.early_ready.wait(self.comm)               # the point INSIDE the step where the early gradients are final
             with torch.cuda.stream(self.comm):

@@ -40,6 +40,28 @@ def test_argument_checks_need_no_gpu():
     assert lib.pn2_fps_workspace_bytes(200, 65536, 1024) == 200 * 65536 * 4    # too many clouds to co-schedule: fallback
 
 
+def test_options_are_explicit_and_the_library_never_reads_the_environment():
+    """dispatch switches live in ONE table behind pn2_set_option / pn2_get_option (include/pn2.h); the library
+    has no getenv of its own (the Python binding forwards PN2_* variables once, at load time)."""
+    lib = _lib.load()
+    opts = _lib.options()
+    assert {"PN2_WIDE", "PN2_RING", "PN2_TN_SMALLP", "PN2_FPS_SINGLE_MAX", "PN2_BWD_PAIR"} <= set(opts)
+    v = ctypes.c_int(-7)
+    assert lib.pn2_get_option(b"PN2_TN_SMALLP", ctypes.addressof(v)) == 0 and v.value == opts["PN2_TN_SMALLP"]
+    old = opts["PN2_NT_CFG"]
+    try:
+        assert lib.pn2_set_option(b"NT_CFG", 9) == 0                                  # with or without the prefix
+        assert lib.pn2_get_option(b"PN2_NT_CFG", ctypes.addressof(v)) == 0 and v.value == 9
+    finally:
+        _lib.set_option("PN2_NT_CFG", old)
+    assert lib.pn2_set_option(b"PN2_NO_SUCH_OPTION", 1) == -1 and lib.pn2_get_option(b"PN2_WIDE", None) == -1
+    assert lib.pn2_option_name(len(opts)) is None and lib.pn2_option_name(-1) is None
+    for f in os.listdir(_lib.CSRC):                                                  # no hidden switches
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(_lib.CSRC, f)).read(), f
+    assert "thread_local" not in open(os.path.join(_lib.CSRC, "mlp.hip")).read()
+
+
 def test_cpu_tensors_are_refused():
     import torch
     from pointnet12_amd import pointnet_util as U

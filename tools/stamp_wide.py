@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the waves of the LDS-DMA ring forward (csrc/mlp_wide.hip, ring_fwd_kernel) spend their cycles.
+Needs a STAMP build of the library (make -C pointnet12_amd/csrc STAMP=1) loaded through PN2_LIB_PATH:
+    PN2_LIB_PATH=pointnet12_amd/libpn2_hip_stamp.so python tools/stamp_wide.py
+"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pointnet12_amd import _lib
+from pointnet12_amd._lib import ptr as p
+lib = _lib.load(); raw = ctypes.CDLL(_lib.LIB_PATH)
+dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
+g = torch.Generator(device=dev).manual_seed(0)
+rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+NAMES = ["barrier", "dma", "half1+xform", "wait", "epilogue", "half2"]
+
+
+def r4(c):
+    return (c + 3) & ~3
+
+
+def affine(c):
+    a = torch.zeros(4 * r4(c), device=dev)
+    a[:c] = rnd(c) * 0.1; a[r4(c):r4(c) + c] = 1.0 + rnd(c) * 0.1; a[2 * r4(c):2 * r4(c) + c] = rnd(c) * 0.1; a[3 * r4(c):3 * r4(c) + c] = 1.0
+    return a
+
+
+def dump():
+    buf = (ctypes.c_ulonglong * (64 * 8 * 8))()
+    raw.pn2_debug_stamps_wide(buf, 64 * 8 * 8)
+    a = np.array(buf, dtype=np.float64).reshape(64, 8, 8)
+    for w in range(8):
+        v = a[:, w, :]
+        v = v[v.sum(1) > 0]
+        if not len(v):
+            continue
+        tot = v[:, :6].sum(1).mean()
+        ghz = (v[:, 6] / np.maximum(v[:, 7], 1)).mean() * 0.1
+        print("   wave %d  %8.0f cycles (%.0f us at the %.2f GHz it held): " % (w, tot, v[:, 7].mean() / 100.0, ghz)
+              + "  ".join("%s %4.1f%%" % (n, 100 * x / tot) for n, x in zip(NAMES, v.mean(0)[:6])))
+
+
+for P, K, N in [(262144, 196, 256), (131072, 128, 256), (262144, 128, 196), (131072, 128, 128)]:
+    X = torch.zeros(P, r4(K), device=dev); X[:, :K] = rnd(P, K)
+    W, bias, Y = rnd(N, K), rnd(N), torch.empty(P, r4(N), device=dev)
+    stats = torch.zeros(8 * 2 * N, device=dev, dtype=torch.float64)
+    aff = affine(K)
+    for _ in range(5):
+        assert lib.pn2_conv1x1_fwd(p(X), r4(K), p(aff), p(W), K, p(bias), p(Y), r4(N), P, K, N, p(stats), None, None, st) == 0
+    torch.cuda.synchronize()
+    print("fwd", (P, K, N))
+    dump()

@@ -66,7 +66,6 @@ def main():
     def compute():
         opt.zero_grad()                                            # free after the first step (fused into Adam)
         loss = nll_loss(net(pts.transpose(2, 1)).reshape(-1, CLASSES), lab.reshape(-1))
-        graph.fork_point()                                         # a captured step starts the next batch's geometry branch here
         loss.backward()
         bucket.all_reduce()
         opt.step()
@@ -77,7 +76,7 @@ def main():
                              out=(pts, lab))
 
     next_batch()
-    step = graph.GraphedStep(compute, dev, fork_in_step=True) if args.graph else compute
+    step = graph.GraphedStep(compute, dev) if args.graph else compute      # (no geometry prefetch in this loop: the batch changes between replays)
     curve = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
