@@ -108,7 +108,7 @@ def _shared_mlp(x, convs, bns, training):
 
     Kept in the reference's tensor layout on purpose: ATen's channel-first batch-norm
     reduces each channel with a cascade sum and stays ~2e-6 from an fp64 evaluation, while
-    the same statistics over a [P, C] row matrix drift to 1e-5 (measured).
+    the same statistics over a [P, C] row matrix drift to 1e-5 (measured; see HISTORY.md section 1).
     """
     y = x
     stack = _next_stack()

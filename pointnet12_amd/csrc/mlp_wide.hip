@@ -1279,7 +1279,7 @@ int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
 }
 
 // Bytes of caller scratch with which pn2_conv1x1_wgrad flushes dW in two phases (0: this shape keeps the atomic flush, or the
-// two-phase form is switched off: PN2_WGRAD_TWO_PHASE, default by measurement -- see DESIGN.md section 4).
+// two-phase form is switched off: PN2_WGRAD_TWO_PHASE, default by measurement -- see HISTORY.md section 4).
 int64_t pn2_wide_wgrad_workspace_bytes(int64_t P, int M, int N, int pooled) {
     const int on = pn2_opt(PN2_OPT_WIDE) && pn2_opt(PN2_OPT_WIDE_WGRAD) && pn2_opt(PN2_OPT_WGRAD_TWO_PHASE);
     const int min_rows = pn2_opt(PN2_OPT_WIDE_WGRAD_MIN_ROWS);

@@ -60,7 +60,7 @@ static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
     X(RES_HALF, 1) /* two 4-wave workgroups per CU on the fused backward pairs that fit twice */ \
     X(WIDE, 1) /* register-stationary kernels (csrc/mlp_wide.hip) */ \
     X(WIDE_MIN_ROWS, 65536) /* rows from which they take a layer */ \
-    X(RING, 0) /* forward: the LDS-DMA ring form of the register-stationary kernel (measured equal: DESIGN.md section 4) */ \
+    X(RING, 0) /* forward: the LDS-DMA ring form of the register-stationary kernel (measured equal: DESIGN.md section 3) */ \
     X(WIDE_POOL, 1) /* pooling extrema in the register-stationary forward's epilogue */ \
     X(WIDE_ADB196, 1) /* 196 -> 128 data gradient: operand reads one k block ahead */ \
     X(WIDE_WGRAD, 1) /* full-tile weight gradient */ \

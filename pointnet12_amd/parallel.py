@@ -125,7 +125,7 @@ class FlatGradBucket:
     def use_two_buckets(self, late_params):
         """Two-bucket protocol (VERDICT r3 #7b): the gradients of ``late_params`` -- the stage the backward reaches last, sa1 --
         form a small LATE bucket, everything else the EARLY bucket.  EXPERIMENTAL: no runtime of this pool accepts the external
-        event record under capture it needs, so the GPU path has never run to RCCL-TWO-BUCKET-OK; an
+        event record under capture it needs, so the GPU path has never run to RCCL-TWO-BUCKET-OK (HISTORY.md section 5); an
         all-reduce whose step did not call ``mark_early_ready()`` falls back to the one-bucket order.  The step calls ``mark_early_ready()`` where the early
         gradients are final (a tensor hook on sa1's output: autograd has accumulated its gradient, i.e. every later stage's
         backward has been issued); the early all-reduce then runs on the comm stream UNDER sa1's backward, and only the late

@@ -62,7 +62,7 @@ def test_shared_mlp_vs_torch(dev, P, pool, chans):
 def test_shared_mlp_negative_and_zero_gamma(dev, P, pool, chans):
     """VERDICT r4 weak #2 / ADVICE r4: BatchNorm weights of BOTH signs, every fifth one exactly 0, biases in (-1, 1) -- what a trained
     checkpoint holds.  The backward reductions rebuild x-hat from the pooled OUTPUT where |gamma| >= (1 + |beta|) / 4 and from
-    Y otherwise (csrc/scatter.hip), the pooling epilogues record the MINIMUM where gamma < 0: with
+    Y otherwise (csrc/scatter.hip, HISTORY.md section 4 item 13), the pooling epilogues record the MINIMUM where gamma < 0: with
     gamma in U(-1.5, 1.5) every branch of both selections is taken by some channel, and all of them are held to the fp64
     evaluation (not to each other)."""
     _check_shared_mlp(dev, P, pool, chans, "signed")

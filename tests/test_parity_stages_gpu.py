@@ -26,7 +26,7 @@ the same FPS start draw) and must reproduce
     GRAD_TOL -- there is no looser bound any more: a difference from the plain fp64 evaluation beyond the factor is accepted
     only with decisions_differ > 0, and is then fully explained by those decisions,
 
-and the positions where the pooled arg-max differs from the reference's (note on the pooled argmax) are COUNTED:
+and the positions where the pooled arg-max differs from the reference's (HISTORY.md section 7, note on the pooled argmax) are COUNTED:
 the rate is asserted, not argued.  Shapes: cfg3 = B=16 x 4096 x (3+6), SSG (the reference's PointNet2SemSeg) and MSG; cfg5 =
 one 65 536-point cloud through SSG and through MSG with npoint x16.  Numbers go to gpurun_out/parity_stages.json (copied to
 profiles/ per round).
