@@ -150,6 +150,33 @@ def _check_shared_mlp(dev, P, pool, chans, gamma_mode):
         y = F.relu((y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + bn.eps) * bn.weight + bn.bias)
 
 
+@pytest.mark.parametrize("P,pool,chans", [(131072 + 128, 128, [128, 128, 196, 256]), (131072, 64, [128, 128, 256]), (131072, 0, [128, 128, 128])])
+def test_ring_forward_option_is_bit_equal(dev, P, pool, chans):
+    """The LDS-DMA ring forward (csrc/mlp_wide.hip ring_fwd_kernel, option PN2_RING, off by default -- DESIGN.md section 3) computes the
+    same fp32 fma chain per output element as the register-staged kernel: pooled outputs and every saved pre-BN activation are
+    bit-equal, through pn2_set_option (no environment)."""
+    gen = torch.Generator().manual_seed(P)
+    c_in = chans[0]
+    rows = (torch.randn(P, c_in, generator=gen) * 2 + 0.5).to(dev)
+    convs = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])]).to(dev)
+    bns = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]]).to(dev)
+    res = {}
+    old = _lib.options()["PN2_RING"]
+    try:
+        for ring in (0, 1):
+            _lib.set_option("PN2_RING", ring)
+            for bn in bns:
+                bn.reset_running_stats()
+            out = U.shared_mlp(rows.clone().requires_grad_(True), c_in, convs, bns, pool, True)
+            saved = out.grad_fn.saved_tensors
+            L = len(chans) - 1
+            res[ring] = [out.detach().clone()] + [y.clone() for y in saved[3:3 + L]] + [bn.running_var.clone() for bn in bns]
+    finally:
+        _lib.set_option("PN2_RING", old)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 def test_eval_mode_with_grad(dev):
     gen = torch.Generator().manual_seed(0)
     convs = nn.ModuleList([nn.Conv2d(8, 16, 1), nn.Conv2d(16, 12, 1)]).to(dev)

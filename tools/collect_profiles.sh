@@ -58,7 +58,7 @@ stats cfg5_msg $CFG5_MSG --steps 5 --warmup 2
 # 4. A/B lines of the round's switches (same box, back to back, twice)
 : > $O/ab_switches.txt
 for rep in 1 2; do
-  for v in "PN2_LAZY_BN=0" "PN2_LAZY_BN=1" "PN2_WIDE_POOL=0" "PN2_WIDE_POOL=1" "PN2_BWD_PAIR=0" "PN2_BWD_PAIR=1" "PN2_WGRAD_TWO_PHASE=0" "PN2_WGRAD_TWO_PHASE=1" "PN2_WGRAD_CF=0" "PN2_WGRAD_CF=1" "PN2_GEO_FORK_LATE=0" "PN2_GEO_FORK_LATE=1"; do
+  for v in "PN2_RING=0" "PN2_RING=1" "PN2_LAZY_BN=0" "PN2_LAZY_BN=1" "PN2_WIDE_POOL=0" "PN2_WIDE_POOL=1" "PN2_BWD_PAIR=0" "PN2_BWD_PAIR=1" "PN2_GEO_FORK_LATE=0" "PN2_GEO_FORK_LATE=1"; do
     for w in msg ssg; do
       env $v python3 bench.py --workload $w --no-cpu-baseline --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], d['ms_per_step'])" $v $w >> $O/ab_switches.txt
     done
@@ -66,6 +66,7 @@ for rep in 1 2; do
 done
 
 tools/exp/mfma_peak > $O/mfma_peak.txt 2>&1
+[ -x tools/exp/mfma_shape ] && tools/exp/mfma_shape > $O/mfma_shape.txt 2>&1
 if [ -z "$QUICK" ]; then
   python3 tools/bench_kernels.py all > $O/kernel_microbench.txt 2>/dev/null
   python3 tools/bench_infer.py > $O/infer_single_cloud.jsonl 2> $O/infer.err
