@@ -839,6 +839,362 @@ int launch_ring_fwd(const RegwArgs &g, hipStream_t s) {
     return launch_ring_fwd_nx<K4, NCB, RS, TM, MODE, PKP, NN % 32 == 0>(g, s);
 }
 
+// ================================================================================================ fp32 products on the bf16 pipe (round 5)
+// Where the fp32 GEMMs stand (profiles/r05_ring_fwd.txt): inside their tile loops the register-stationary kernels keep the matrix
+// pipe ~88 % busy at the ~2.07 GHz the chip holds -- v_mfma_f32_32x32x2_f32 (157 TF) IS their limit, and the same pipe runs bf16
+// sixteen times faster.  Every fp32 number is EXACTLY hi + mid + lo with three bf16 pieces (8 + 8 + 8 significand bits: hi =
+// bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); both subtractions are exact in fp32), so
+//     a b = a_hi b_hi + (a_hi b_mid + a_mid b_hi) + (a_hi b_lo + a_lo b_hi + a_mid b_mid) + [three terms <= 2^-24 |a b|, dropped]
+// -- six v_mfma_f32_32x32x16_bf16 (each bf16 x bf16 product is exact, the sums are taken in the fp32 accumulator) instead of
+// eight v_mfma_f32_32x32x2_f32 per 32 x 32 x 16 block: 192 instead of 512 matrix-pipe cycles.  The dropped terms are below one
+// rounding of the product.  MEASURED (tools/exp/split_gemm.hip, profiles/r05_split_gemm_probe.txt, against fp64 on 11 - 22 k
+// sampled outputs with |y| up to 13): max error 2.9e-6 / 4.3e-6 / 7.8e-6 at K = 128 / 192 / 256 where a sequential fp32 fma
+// chain -- what v_mfma_f32_32x32x2_f32 and the reference's sgemm compute -- has 5.3e-6 / 5.9e-6 / 7.3e-6 (rms 3.6e-7 vs 4.7e-7):
+// AT LEAST as close to the exact product as the fp32 arithmetic it replaces.  (Two pieces / three products: 4e-5 -- not used.)
+// The kernels below are then bound by HBM (128 -> 256 at 131 072 rows: 4.07 TB/s in the probe), which is where this path belongs.
+//
+// split_nt_kernel: Out[P, N] = op(A)[P, K] * W^T (forward: W [N, K] rows; data gradient: W [K, N], BNN) for K <= 208:
+//   * a wave owns one 32-column block for the whole launch, its W slice pre-split into three bf16 fragment sets in registers
+//     (4 VGPRs per 16-deep k block and piece: 96 at K = 128, 156 at K = 196), two 32-row blocks per wave (TM = 2);
+//   * the streamed operand is staged through registers: BatchNorm + ReLU / the BatchNorm-backward transform exactly as the fp32
+//     kernels form it (same expressions, same fp32 value), THEN split, three bf16 images per 64-deep chunk in LDS
+//     ([piece][row][128 bytes], the 16-byte slot of (k block, half-wave) XOR-swizzled by (row >> 1) & 7: the sixteen rows of a
+//     ds_read_b128 service group cover sixteen distinct bank slots), double-buffered, one barrier per chunk;
+//   * epilogues as the fp32 kernels': the accumulator layout of 32x32x16 is that of 32x32x2.
+typedef __bf16 pn2_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pn2_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float pn2_f32x2 __attribute__((ext_vector_type(2)));
+union SplitFrag { pn2_bf16x8 v; unsigned u[4]; uint4 q; };
+
+// two fp32 values -> three packed bf16 pairs (v_cvt_pk_bf16_f32, v_and / v_lshl, v_pk_add_f32: nine instructions)
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo) {
+    pn2_f32x2 v = {a, b};
+    const pn2_bf16x2 h = __builtin_convertvector(v, pn2_bf16x2);
+    v = v - __builtin_convertvector(h, pn2_f32x2);
+    const pn2_bf16x2 m = __builtin_convertvector(v, pn2_bf16x2);
+    v = v - __builtin_convertvector(m, pn2_f32x2);
+    const pn2_bf16x2 l = __builtin_convertvector(v, pn2_bf16x2);
+    hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
+}
+
+// KS = 2 (contraction lengths whose W slice does not fit one wave's registers: K = 256): TWO waves share a column block, each
+// holds the W fragments of two of every chunk's four k blocks and accumulates its half of the contraction; at the end of a tile
+// the pair swaps one row block each through LDS, so that each wave finishes (adds, masks, stores, reduces) one of the two.
+// gridDim.y column groups of NCB blocks each (N = 196 with K = 256: 4 + 4 blocks; the staging of a tile is then done by two
+// workgroups -- its rows come from HBM once and from L2 / MALL the second time).
+template <int K4, int NCB, int RS, int TM, int MODE, int EPI, bool BNN, int PKP, bool NX, int KS>
+__global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) void split_nt_kernel(const RegwArgs g) {
+    constexpr int KC = 64, NW = NCB * RS * KS, NT = 64 * NW, BM = 32 * TM * RS;
+    static_assert(KS == 1 || (KS == 2 && TM == 2 && K4 % KC == 0), "K split: pairs swap one of two row blocks, whole chunks");
+    constexpr int KB = (K4 + 15) / 16, KPAD = 16 * KB, NCH = (KPAD + KC - 1) / KC;    // 16-deep k blocks; 64-deep chunks
+    constexpr int IMG = BM * KC * 2;                                // bytes of one bf16 piece image of a chunk
+    constexpr int NTAB = MODE == MODE_PLAIN ? 0 : (MODE == MODE_BNRELU ? 3 : 4);
+    constexpr bool DY = MODE == MODE_DYDENSE || MODE == MODE_DYPOOLED, POOLED = MODE == MODE_DYPOOLED;
+    constexpr int FPOOL = EPI == EPI_FWD ? PKP : 0;
+    constexpr int SUB = FPOOL > BM ? FPOOL / BM : 1;                // tiles per pooling group (a group spans SUB consecutive tiles)
+    constexpr int KBW = KB / KS;                                    // k blocks whose W fragments this wave holds
+    static_assert(K4 % 4 == 0 && KBW <= 13, "W slice: 12 registers per k block");
+    static_assert(FPOOL == 0 || (RS == 1 && (BM % FPOOL == 0 || FPOOL % BM == 0) && FPOOL % 32 == 0), "forward pooling geometry");
+    static_assert(!POOLED || (PKP > 0 && (PKP % BM == 0 || BM % PKP == 0)), "pooled dY: groups and tiles nest");
+    unsigned char *lds_b = reinterpret_cast<unsigned char *>(wide_lds);
+    float *tab = wide_lds + (2 * 3 * IMG) / 4;                      // NTAB rows of KPAD floats
+    float *xch = tab + NTAB * KPAD;                                 // KS == 2: one row block of accumulators per wave (16 x 64 floats)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int cb = wave % NCB + (int)blockIdx.y * NCB, rs = (wave / NCB) % RS, ks = wave / (NCB * RS);
+    const int n = cb * 32 + l31;
+    const int N = g.N, K = g.K;
+    if (MODE == MODE_BNRELU) lazy_bn_prologue(g.lz);
+    if (DY) lazy_coef_prologue(g.lc);
+
+    // ---- this lane's W slice: column n, k = 16 kb + 8 lh + 0 .. 7, three fragment sets (KS == 2: k blocks 2 ks, 2 ks + 1 of every chunk)
+    SplitFrag wh[KBW], wm[KBW], wl[KBW];
+#pragma unroll
+    for (int kbw = 0; kbw < KBW; ++kbw) {
+        float v[8];
+        const int kb = KS == 1 ? kbw : (kbw >> 1) * 4 + 2 * ks + (kbw & 1);
+        const int k0 = 16 * kb + 8 * lh;
+        if (BNN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (n < N && k0 + e < K) ? g.W[(int64_t)(k0 + e) * g.ldw + n] : 0.f;
+        } else {
+            const bool vec = (g.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(g.W) & 15) == 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + 4 * h;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < N && k + 3 < K && vec) q = ld4(g.W + (int64_t)n * g.ldw + k);
+                else if (n < N) {
+                    q.x = k < K ? g.W[(int64_t)n * g.ldw + k] : 0.f; q.y = k + 1 < K ? g.W[(int64_t)n * g.ldw + k + 1] : 0.f;
+                    q.z = k + 2 < K ? g.W[(int64_t)n * g.ldw + k + 2] : 0.f; q.w = k + 3 < K ? g.W[(int64_t)n * g.ldw + k + 3] : 0.f;
+                }
+                v[4 * h] = q.x; v[4 * h + 1] = q.y; v[4 * h + 2] = q.z; v[4 * h + 3] = q.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], wh[kbw].u[e], wm[kbw].u[e], wl[kbw].u[e]);
+    }
+    for (int i = t; i < NTAB * KPAD; i += NT) {
+        const int r = i / KPAD, k = i - r * KPAD;
+        tab[i] = k < K4 ? g.tab[r * K4 + k] : 0.f;
+    }
+
+    const int N4 = (N + 3) & ~3;
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;                   // EPI_FWD: bias, pooling sign; EPI_MASK: mean, scale, beta, invstd of column n
+    if (EPI == EPI_FWD) {
+        e0 = n < N ? g.bias[n] : 0.f;
+        if (FPOOL > 0) e1 = __int_as_float((n < N && g.pool_gamma[n] < 0.f) ? (int)0x80000000 : 0);
+    } else if (EPI == EPI_MASK && n < N4) {
+        Affine a(g.prev_aff, N4);
+        e0 = a.mean[n]; e1 = a.scale[n]; e2 = a.beta[n]; e3 = a.invstd[n];
+    }
+    double st0 = 0.0, st1 = 0.0;
+
+    // ---- staging: item i of thread t covers the float4 quad q = idx % 16 of row idx / 16 of a chunk (idx = t + NT i)
+    constexpr int QI = BM * 16, A_IT = (QI + NT - 1) / NT;
+    struct Raw { float4 y[A_IT]; float4 z[DY ? A_IT : 1]; int4 a[POOLED ? A_IT : 1]; };
+    Raw raw;
+    const int64_t tiles = g.tiles;
+    const int G = gridDim.x;
+    auto lds_off = [](int buf, int row, int slot) { return (unsigned)(buf * 3 * IMG + row * 128 + 16 * (slot ^ ((row >> 1) & 7))); };
+    auto item_ok = [&](int c, int i, int &row, int &q) {            // false: this thread has no i-th item in chunk c
+        const int idx = t + NT * i;
+        row = idx >> 4; q = idx & 15;
+        if (NT * i >= QI) return false;
+        if (NT * (i + 1) > QI && idx >= QI) return false;
+        return c * KC + 4 * q < KPAD;                               // the last chunk may be narrower
+    };
+    auto fetch = [&](int64_t tile_, int c) {
+        const unsigned tl = (unsigned)(tile_ < tiles ? tile_ : tiles - 1);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int row, q;
+            if (!item_ok(c, i, row, q)) continue;
+            const int k = c * KC + 4 * q;
+            const unsigned kk = k < K4 ? (unsigned)k : (unsigned)(K4 - 4);        // a pad quad re-reads the last one (zeroed when staged)
+            const unsigned m = tl * BM + (unsigned)row;
+            raw.y[i] = ld4(g.A + row_off(m, g.lda) + kk);
+            if (MODE == MODE_DYDENSE) raw.z[DY ? i : 0] = ld4(g.dZ + row_off(m, g.ldz) + kk);
+            if (POOLED) {
+                const unsigned grp = m / (unsigned)(PKP > 0 ? PKP : 1);
+                raw.z[DY ? i : 0] = ld4(g.dZp + row_off(grp, g.ldo) + kk);
+                raw.a[POOLED ? i : 0] = ld4i(g.arg + row_off(grp, g.ldo) + kk);
+            }
+        }
+    };
+    auto stage = [&](int64_t tile_, int c, int buf) {
+        const unsigned tl = (unsigned)(tile_ < tiles ? tile_ : tiles - 1);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int row, q;
+            if (!item_ok(c, i, row, q)) continue;
+            const int k = c * KC + 4 * q;
+            float4 x = raw.y[i];
+            if (MODE == MODE_BNRELU) {
+                const float4 mu = *reinterpret_cast<const float4 *>(&tab[k]), sc = *reinterpret_cast<const float4 *>(&tab[KPAD + k]);
+                const float4 be = *reinterpret_cast<const float4 *>(&tab[2 * KPAD + k]);
+                x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f); x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+                x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f); x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+            }
+            if (DY) {
+                const DyParams dp = dy_params_tab(tab, KPAD, k, true);
+                float4 dz = raw.z[DY ? i : 0];
+                if (POOLED) {
+                    const int4 a = raw.a[POOLED ? i : 0];
+                    const int kk = (int)((tl * BM + (unsigned)row) % (unsigned)(PKP > 0 ? PKP : 1));
+                    dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f; dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
+                }
+                x = dy_from(dz, x, dp);
+            }
+            if (k >= K4) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned h0, m0, l0, h1, m1, l1;
+            split2(x.x, x.y, h0, m0, l0);
+            split2(x.z, x.w, h1, m1, l1);
+            const unsigned o = lds_off(buf, row, q >> 1) + 8u * (unsigned)(q & 1);
+            *reinterpret_cast<uint2 *>(lds_b + o) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(lds_b + o + IMG) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2 *>(lds_b + o + 2 * IMG) = make_uint2(l0, l1);
+        }
+    };
+    // the WG's tile sequence: pooling groups that span SUB tiles are walked tile by tile inside one workgroup
+    auto tile_of = [&](int64_t seq) { return ((int64_t)blockIdx.x + (seq / SUB) * G) * SUB + (seq % SUB); };
+    int64_t seq = 0;
+    int64_t tile = tile_of(0);
+    if (tile >= tiles) return;
+    __syncthreads();                                                // the table (and the lazy prologue's stores) are in place
+    fetch(tile, 0);
+    stage(tile, 0, 0);
+    if (NCH > 1) fetch(tile, 1); else fetch(tile_of(1), 0);
+    int buf = 0;
+    float mv[FPOOL > 0 ? (SUB > 1 ? 1 : BM / (FPOOL > 0 ? FPOOL : 1)) : 1];
+    int mk[FPOOL > 0 ? (SUB > 1 ? 1 : BM / (FPOOL > 0 ? FPOOL : 1)) : 1];
+
+    while (tile < tiles) {
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int64_t tile_next = tile_of(seq + 1);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            __syncthreads();                                        // chunk c is staged in `buf`; every wave is done with buf ^ 1
+            const bool last = c == NCH - 1;
+            const int64_t t1 = last ? tile_next : tile;             // staged now (fetched one step ago)
+            const int c1 = last ? 0 : c + 1;
+            const bool last1 = c1 == NCH - 1;
+            const int64_t t2 = last1 ? (last ? tile_of(seq + 2) : tile_next) : t1;       // requested now
+            const int c2 = last1 ? 0 : c1 + 1;
+            stage(t1, c1, buf ^ 1);
+            fetch(t2, c2);
+            constexpr int KBC = KC / 16;
+            const int kbs = (KPAD - c * KC) < KC ? (KPAD - c * KC) / 16 : KBC;
+#pragma unroll
+            for (int kbl = 0; kbl < KBC / KS; ++kbl) {
+                const int kb = KS == 1 ? kbl : 2 * ks + kbl;        // (KS == 2: this wave's two k blocks of the chunk)
+                if (KS == 2 || kb < kbs) {
+                    const int kg = KS == 1 ? c * KBC + kb : c * 2 + kbl;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = rs * TM * 32 + i * 32 + l31;
+                        const unsigned o = lds_off(buf, row, 2 * kb + lh);
+                        SplitFrag ah, am, al;
+                        ah.q = *reinterpret_cast<const uint4 *>(lds_b + o);
+                        am.q = *reinterpret_cast<const uint4 *>(lds_b + o + IMG);
+                        al.q = *reinterpret_cast<const uint4 *>(lds_b + o + 2 * IMG);
+                        // smallest terms first
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, wh[kg].v, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wl[kg].v, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wm[kg].v, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wh[kg].v, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wm[kg].v, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wh[kg].v, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            buf ^= 1;
+        }
+        if (KS == 2) {
+            // the pair (ks = 0, 1) of a column block: hand the row block the OTHER wave finishes over, take the partner's share of one's own
+            float *mine = xch + (size_t)wave * (16 * 64), *theirs = xch + (size_t)(wave ^ (NCB * RS)) * (16 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = ks == 0 ? acc[1][r] : acc[0][r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float o = theirs[r * 64 + lane];
+                if (ks == 0) acc[0][r] += o; else acc[1][r] += o;
+            }
+        }
+        // ---- epilogue straight from the accumulators (the layout of v_mfma_f32_32x32x2_f32: column on the lane)
+        {
+            const unsigned row0 = (unsigned)tile * BM + rs * TM * 32 + 4 * lh;
+            unsigned lo = (unsigned)n;
+            asm volatile("" : "+v"(lo));
+            float s0 = 0.f, s1 = 0.f;
+            if (EPI == EPI_FWD) {
+                float *yb = g.Out + row_off(row0, g.ldout);
+                unsigned off = lo;
+                constexpr int GPT = FPOOL > 0 ? (SUB > 1 ? 1 : BM / (FPOOL > 0 ? FPOOL : 1)) : 1;
+                constexpr int BPG = FPOOL > 0 ? (SUB > 1 ? TM : FPOOL / 32) : TM;        // row blocks of this tile per group
+                const int sg = __float_as_int(e1);
+                const int sub = (int)(seq % SUB);
+                if (FPOOL > 0 && sub == 0) {
+#pragma unroll
+                    for (int gq = 0; gq < GPT; ++gq) { mv[gq] = -INFINITY; mk[gq] = 0; }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        static_assert(KS == 1 || EPI != EPI_FWD, "the K split serves the data gradient only");
+                        const float y = acc[i][r] + e0;
+                        if (NX || n < N4) PN2_STREAM_STORE(y, yb + off);      // pad columns receive exact zeros (w = bias = 0)
+                        s0 += y;
+                        s1 = __builtin_fmaf(y, y, s1);
+                        if (FPOOL > 0) {
+                            // ascending tile, block, register = ascending row for this lane: a strict > keeps the first row
+                            const int gq = SUB > 1 ? 0 : i / BPG;
+                            const float yp = __int_as_float(__float_as_int(y) ^ sg);
+                            const int row = sub * BM + (i - gq * BPG) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            mk[gq] = yp > mv[gq] ? row : mk[gq];
+                            mv[gq] = fmaxf(mv[gq], yp);
+                        }
+                        off += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldout;   // rows (r & 3) + 8 (r >> 2): +1 +1 +1 +5
+                    }
+                if (FPOOL > 0 && sub == SUB - 1) {
+#pragma unroll
+                    for (int gq = 0; gq < GPT; ++gq) {
+                        const float ov = __shfl_xor(mv[gq], 32, 64);   // the two half-waves hold disjoint rows of the column
+                        const int ok = __shfl_xor(mk[gq], 32, 64);
+                        const bool take = ov > mv[gq] || (ov == mv[gq] && ok < mk[gq]);
+                        const float v = take ? ov : mv[gq];
+                        const int k = take ? ok : mk[gq];
+                        const int64_t grp = SUB > 1 ? tile / SUB : (int64_t)tile * GPT + gq;
+                        if (NX || n < N4)
+                            g.pool_rec[grp * g.pool_ld + lo] = make_float2(__int_as_float(__float_as_int(v) ^ sg), __int_as_float(k));
+                    }
+                }
+            } else {
+                const float *pb = g.prevY + row_off(row0, g.ldp);
+                float *xb = g.Out + row_off(row0, g.ldout);
+                unsigned offp = lo, offx = lo;
+                asm volatile("" : "+v"(offx));
+                if (KS == 2) {                                           // this wave finishes row block ks only
+                    offp += (unsigned)(32 * ks) * (unsigned)g.ldp;
+                    offx += (unsigned)(32 * ks) * (unsigned)g.ldout;
+                }
+#pragma unroll
+                for (int i = 0; i < TM / KS; ++i) {
+                    float pv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        pv[r] = (NX || n < N4) ? pb[offp] : 0.f;
+                        offp += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldp;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float y = pv[r];
+                        const float a = KS == 1 ? acc[i][r] : (ks == 0 ? acc[0][r] : acc[1][r]);
+                        const float dz = bn_act(y, e0, e1, e2) > 0.f ? a : 0.f;   // pad columns: scale = beta = 0 -> 0
+                        if (NX || n < N4) PN2_STREAM_STORE(dz, xb + offx);
+                        s0 += dz;
+                        s1 = __builtin_fmaf(dz, (y - e0) * e3, s1);
+                        offx += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldout;
+                    }
+                }
+            }
+            st0 += (double)s0; st1 += (double)s1;
+        }
+        ++seq;
+        tile = tile_next;
+    }
+    if (g.red != nullptr) {
+        st0 += __shfl_xor(st0, 32, 64);
+        st1 += __shfl_xor(st1, 32, 64);
+        if (lh == 0 && n < N) {
+            double *rep = g.red + (size_t)(blockIdx.x % PN2_STAT_REPLICAS) * 2 * N;
+            atomicAdd(rep + n, st0);
+            atomicAdd(rep + N + n, st1);
+        }
+    }
+}
+
+template <int K4, int NN, int NCB, int RS, int TM, int MODE, int EPI, bool BNN, int PKP = 0, int KS = 1, int NG = 1>
+int launch_split(const RegwArgs &g, hipStream_t s) {
+    static_assert(NN <= 32 * NCB * NG && NN > 32 * (NCB * NG - NCB), "column blocks");
+    constexpr int KC = 64, BM = 32 * TM * RS, KPAD = 16 * ((K4 + 15) / 16);
+    constexpr int NTAB = MODE == MODE_PLAIN ? 0 : (MODE == MODE_BNRELU ? 3 : 4);
+    constexpr size_t lds = 2 * 3 * (size_t)(BM * KC * 2) + sizeof(float) * (NTAB * KPAD + (KS == 2 ? NCB * RS * KS * 16 * 64 : 0));
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = split_nt_kernel<K4, NCB, RS, TM, MODE, EPI, BNN, PKP, NN % 32 == 0 && NN == 32 * NCB * NG, KS>;
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
+    constexpr int SUB = (EPI == EPI_FWD && PKP > BM) ? PKP / BM : 1;
+    const int64_t cap = pn2_num_cus() / NG, units = g.tiles / SUB;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(units < cap ? units : cap), NG), dim3(64 * NCB * RS * KS), lds, s, g);
+    return pn2_launch_status();
+}
+
 }  // namespace
 
 #ifdef PN2_STAMP
@@ -870,6 +1226,39 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
     g.A = X; g.lda = ldx; g.tab = in_affine; g.W = W; g.ldw = ldw; g.bias = bias; g.Out = Y; g.ldout = ldy; g.red = stats;
     g.K = K; g.N = N;
     g.pool_rec = reinterpret_cast<float2 *>(pool_ws); g.pool_gamma = pool_gamma; g.pool_ld = N;
+    // fp32 products on the bf16 pipe (split_nt_kernel; option PN2_SPLIT): 64-row tiles (128 where the waves split the rows)
+    if (pn2_opt(PN2_OPT_SPLIT) && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+        const bool pool_ok = Kpool == 0 || (in_affine && pool_gamma && pool_ws && pn2_opt(PN2_OPT_WIDE_POOL) && P % 128 == 0);
+#define SPLIT_FWD(KK, NN, NCB, RS, TM, PKP)                                                                              \
+        if (K == KK && N == NN && Kpool == PKP && pool_ok) {                                                             \
+            constexpr int BM = 32 * TM * RS;                                                                             \
+            g.tiles = P / BM;                                                                                            \
+            if (PKP > 0) g.tiles = (P / (PKP > BM ? PKP : BM)) * ((PKP > BM ? PKP : BM) / BM);                           \
+            *rows_done = g.tiles * BM;                                                                                   \
+            if (g.tiles > 0) {                                                                                           \
+                if (in_affine) return launch_split<((KK + 3) & ~3), NN, NCB, RS, TM, MODE_BNRELU, EPI_FWD, false, PKP>(g, s);  \
+                if (PKP == 0) return launch_split<((KK + 3) & ~3), NN, NCB, RS, TM, MODE_PLAIN, EPI_FWD, false, 0>(g, s);    \
+            }                                                                                                            \
+        }
+        if (P >= 98304) { SPLIT_FWD(128, 128, 4, 2, 1, 0) }          // (eight waves with one row block each: 64-row tiles)
+        SPLIT_FWD(128, 256, 8, 1, 2, 0)
+        SPLIT_FWD(128, 196, 7, 1, 2, 0)
+        SPLIT_FWD(196, 256, 8, 1, 2, 0)
+        SPLIT_FWD(128, 256, 8, 1, 2, 64)
+        SPLIT_FWD(128, 256, 8, 1, 2, 128)
+        SPLIT_FWD(196, 256, 8, 1, 2, 128)
+        if (pn2_opt(PN2_OPT_SPLIT_NARROW)) {                        // the sa1 layers the weight-resident kernels serve (A/B)
+            SPLIT_FWD(64, 96, 3, 2, 2, 0)
+            SPLIT_FWD(96, 128, 4, 2, 1, 0)
+            SPLIT_FWD(96, 128, 4, 1, 2, 128)
+            SPLIT_FWD(96, 128, 4, 1, 2, 64)
+            SPLIT_FWD(64, 64, 2, 2, 2, 0)
+            SPLIT_FWD(64, 128, 4, 2, 1, 0)
+            SPLIT_FWD(64, 128, 4, 1, 2, 64)
+        }
+#undef SPLIT_FWD
+        *rows_done = 0;
+    }
     if (Kpool > 0) {
         // the last layer of a pooled MLP: whole tiles only (a pooled launch has no streamed tail), needs an input affine block
         const int pool_on = pn2_opt(PN2_OPT_WIDE_POOL);
@@ -920,6 +1309,34 @@ int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
     g.A = Y; g.lda = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.kshift = 0; g.tab = coef;
     g.W = W; g.ldw = ldw; g.Out = dXout; g.ldout = ldxo; g.prevY = prev_Y; g.ldp = ld_prev; g.prev_aff = prev_affine; g.red = prev_red;
     g.K = K; g.N = N;
+    if (pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_K256) && dZ == nullptr && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && ldo % 4 == 0) {
+        // K = 256 (the pooled last layers of sa2): the contraction split over wave pairs, N = 196 as two column groups
+#define SPLIT_DGRAD_P(KK, NN, NCB, NG, PKP)                                                                              \
+        if (K == KK && N == NN && Kpool == PKP && P % 64 == 0) {                                                         \
+            g.tiles = P / 64;                                                                                            \
+            *rows_done = P;                                                                                              \
+            return launch_split<KK, NN, NCB, 1, 2, MODE_DYPOOLED, EPI_MASK, true, PKP, 2, NG>(g, s);                     \
+        }
+        SPLIT_DGRAD_P(256, 128, 4, 1, 64)
+        SPLIT_DGRAD_P(256, 128, 4, 1, 128)
+        SPLIT_DGRAD_P(256, 196, 4, 2, 128)
+        SPLIT_DGRAD_P(256, 196, 4, 2, 64)
+#undef SPLIT_DGRAD_P
+    }
+    if (pn2_opt(PN2_OPT_SPLIT) && dZ != nullptr && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0) {
+        // fp32 products on the bf16 pipe, contraction lengths that fit the register-held W slice (K <= 208): the dense data gradients
+#define SPLIT_DGRAD(KK, NN, NCB, RS, TM, MINROWS)                                                                        \
+        if (K == KK && N == NN && P >= MINROWS) {                                                                        \
+            constexpr int BM = 32 * TM * RS;                                                                             \
+            g.tiles = P / BM;                                                                                            \
+            *rows_done = g.tiles * BM;                                                                                   \
+            return launch_split<((KK + 3) & ~3), NN, NCB, RS, TM, MODE_DYDENSE, EPI_MASK, true, 0>(g, s);                \
+        }
+        // (two raw streams per row: eight waves with one row block each keep the in-flight set at 16 registers)
+        SPLIT_DGRAD(128, 128, 4, 2, 1, 98304)
+        SPLIT_DGRAD(196, 128, 4, 2, 1, 0)
+#undef SPLIT_DGRAD
+    }
 #define WIDE_DGRAD(KK, NN, NCB, RS, TM, KC, PKP, ADB, MINROWS)                                                           \
     if (K == KK && N == NN && P >= MINROWS && (PKP == 0 ? dZ != nullptr : (dZ == nullptr && Kpool == PKP))) {           \
         constexpr int BM = 32 * TM * RS;                                                                                 \
@@ -1222,6 +1639,198 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, bf16 pipe
+// dW[M, N] += sum_p dY[p, m] X[p, n] with fp32 products formed from exact three-way bf16 splits (see split_nt_kernel): the
+// whole dW in the accumulators of one workgroup as in wgrad_full_kernel (wave: one 32-row block of dW x TNW 32-column blocks),
+// the P rows in chunks of 16 = ONE v_mfma_f32_32x32x16_bf16 contraction block.  Both operands are needed "down the columns"
+// (eight consecutive rows p of one channel per lane): the staging pass forms dY / relu(bn(X)) exactly as the fp32 kernel does,
+// splits, and stores three bf16 images per operand as plain rows [p][128 channels] per 128-channel panel with the chunk XOR of
+// the programming guide's dual-use image (b) -- off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) --
+// and the fragments come back through ds_read_b64_tr_b16 (the hardware's 4 x 16 transpose: lane 4 q + p of a 16-lane group
+// supplies the address of block row q, elements 4 p .. 4 p + 3; lane i receives column i): two reads per fragment, conflict-free.
+typedef short pn2_s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned tr_img_off(int row, int ch) {      // byte offset of 16-byte chunk ch of row `row` inside a panel
+    return (unsigned)(256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))));
+}
+
+template <int MM, int NN, int TNW, int DYM, int PKP, int BP>          // BP: rows per chunk = BP / 16 contraction blocks
+__global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) void split_tn_kernel(const WgradArgs g) {
+    constexpr int MB = (MM + 31) / 32, NB = (NN + 31) / 32, WN = NB / TNW, NW = MB * WN, NT = 64 * NW;
+    static_assert(BP == 16 || BP == 32, "chunk rows");
+    constexpr int M4 = (MM + 3) & ~3, N4 = (NN + 3) & ~3, QA = M4 / 4, QB = N4 / 4;
+    constexpr int PA = (MB * 32 + 127) / 128, PB = (NB * 32 + 127) / 128;      // 128-channel panels
+    constexpr int PANEL = BP * 256;                                 // bytes of one panel of one piece
+    constexpr int IMG_A = PA * PANEL, IMG_B = PB * PANEL, BUF = 3 * (IMG_A + IMG_B);
+    constexpr bool POOLED = DYM == MODE_DYPOOLED;
+    static_assert(NB % TNW == 0 && NW <= 16, "wave grid");
+    static_assert(!POOLED || (NT % QA == 0 && PKP % BP == 0), "pooled: one channel quad per thread, chunks inside a group");
+    constexpr int PBLK = BP / 16; (void)PBLK;
+    unsigned char *lds_b = reinterpret_cast<unsigned char *>(wide_lds);
+    float *ctab = wide_lds + (2 * BUF) / 4;                         // 4 rows of MB * 32: c0, q1, q0, mean
+    float *xtab = ctab + 4 * MB * 32;                               // 3 rows of NB * 32: mean, scale, beta of the input BatchNorm
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int mb = wave / WN, nb0 = (wave % WN) * TNW;
+
+    lazy_coef_prologue(g.lc);
+    for (int i = t; i < 4 * MB * 32; i += NT) { const int r = i / (MB * 32), c = i - r * (MB * 32); ctab[i] = c < M4 ? g.coef[r * M4 + c] : 0.f; }
+    for (int i = t; i < 3 * NB * 32; i += NT) { const int r = i / (NB * 32), c = i - r * (NB * 32); xtab[i] = c < N4 ? g.x_aff[r * N4 + c] : 0.f; }
+    // zero both buffers once: the channels past M4 / N4 of the last panels are never written and must read as zeros
+    for (int i = t; i < 2 * BUF / 16; i += NT) reinterpret_cast<uint4 *>(lds_b)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    f32x16 acc[TNW];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int64_t p_begin = (int64_t)blockIdx.x * g.rows_per_wg;
+    const int64_t p_end = p_begin + g.rows_per_wg < g.P ? p_begin + g.rows_per_wg : g.P;
+    constexpr int ITA = (BP * QA + NT - 1) / NT, ITB = (BP * QB + NT - 1) / NT;
+    struct Raw { float4 y[ITA]; float4 z[POOLED ? 1 : ITA]; int4 a[1]; float4 x[ITB]; };
+    Raw raw;
+    auto a_item = [&](int i, int &row, int &q) { const int idx = t + NT * i; row = idx / QA; q = idx - row * QA; return idx < BP * QA; };
+    auto b_item = [&](int i, int &row, int &q) { const int idx = t + NT * i; row = idx / QB; q = idx - row * QB; return idx < BP * QB; };
+    auto fetch = [&](int64_t p0) {
+        const int64_t pb = p0 < p_end ? p0 : p_begin;              // past the end: re-read valid rows (zeroed when staged)
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) {
+            int row, q;
+            if (!a_item(i, row, q)) continue;
+            raw.y[i] = ld4(g.Y + (size_t)(pb + row) * (unsigned)g.ldy + 4 * q);
+            if (!POOLED) raw.z[POOLED ? 0 : i] = ld4(g.dZ + (size_t)(pb + row) * (unsigned)g.ldy + 4 * q);
+        }
+        if (POOLED) {
+            const size_t go = (size_t)(pb / (PKP > 0 ? PKP : 1)) * (unsigned)g.ldo + 4u * (unsigned)(t % QA);
+            raw.z[0] = ld4(g.dZp + go);
+            raw.a[0] = ld4i(g.arg + go);
+        }
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) {
+            int row, q;
+            if (!b_item(i, row, q)) continue;
+            raw.x[i] = ld4(g.X + (size_t)(pb + row) * (unsigned)g.ldx + 4 * q);
+        }
+    };
+    // a float4 of channels 4 q .. 4 q + 3 of row `row`: three 8-byte stores (4 bf16 each) into the piece images
+    auto store_split = [&](unsigned char *img, int img_bytes, int row, int q, float4 v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2(v.x, v.y, h0, m0, l0);
+        split2(v.z, v.w, h1, m1, l1);
+        const int col = 4 * q, panel = col >> 7, ch = (col & 127) >> 3;
+        const unsigned o = (unsigned)(panel * PANEL) + tr_img_off(row, ch) + 8u * (unsigned)((col >> 2) & 1);
+        *reinterpret_cast<uint2 *>(img + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(img + o + img_bytes) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2 *>(img + o + 2 * img_bytes) = make_uint2(l0, l1);
+    };
+    auto stage = [&](int64_t p0, int buf) {
+        const bool live = p0 < p_end;
+        unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * IMG_A;
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) {
+            int row, q;
+            if (!a_item(i, row, q)) continue;
+            const DyParams dp = dy_params_tab(ctab, MB * 32, 4 * q, true);
+            float4 dz = raw.z[POOLED ? 0 : i];
+            if (POOLED) {
+                const int4 a = raw.a[0];
+                const int kk = (int)((unsigned)p0 & (unsigned)(PKP - 1)) + row;       // the chunk lies inside one group
+                dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f; dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
+            }
+            float4 v = dy_from(dz, raw.y[i], dp);
+            if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            store_split(ia, IMG_A, row, q, v);
+        }
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) {
+            int row, q;
+            if (!b_item(i, row, q)) continue;
+            const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]), sc = *reinterpret_cast<const float4 *>(&xtab[NB * 32 + 4 * q]);
+            const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * NB * 32 + 4 * q]);
+            float4 x = raw.x[i];
+            x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f); x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+            x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f); x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+            if (!live) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            store_split(ib, IMG_B, row, q, x);
+        }
+    };
+    // transposed fragment: channels cblk * 32 + l31, rows 16 pb + 8 lh + 0 .. 7 of the chunk, of one piece image
+    const int g16 = lane >> 4, j16 = lane & 15, tq = j16 >> 2, tp = j16 & 3;
+    auto frag = [&](const unsigned char *img, int cblk, int pb) {
+        const int col0 = cblk * 32 + 16 * (g16 & 1), panel = col0 >> 7, c0 = (col0 & 127) >> 3;
+        SplitFrag f;
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int row = 16 * pb + 8 * (g16 >> 1) + 4 * r2 + tq;
+            const unsigned o = (unsigned)(panel * PANEL) + tr_img_off(row, c0 + (tp >> 1)) + 8u * (unsigned)(tp & 1);
+            const pn2_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                reinterpret_cast<__attribute__((address_space(3))) pn2_s16x4 *>((__attribute__((address_space(3))) unsigned char *)(img) + o));
+            const uint2 u = __builtin_bit_cast(uint2, v);
+            f.u[2 * r2] = u.x; f.u[2 * r2 + 1] = u.y;
+        }
+        return f;
+    };
+
+    if (p_begin < p_end) {
+        __syncthreads();                                            // tables, zeroed images
+        fetch(p_begin);
+        stage(p_begin, 0);
+        fetch(p_begin + BP);
+        int buf = 0;
+        for (int64_t p0 = p_begin; p0 < p_end; p0 += BP) {
+            __syncthreads();                                        // chunk p0 is in `buf`; every wave is done with buf ^ 1
+            stage(p0 + BP, buf ^ 1);
+            fetch(p0 + 2 * BP);
+            const unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * IMG_A;
+#pragma unroll
+            for (int pb = 0; pb < BP / 16; ++pb) {
+                const SplitFrag ah = frag(ia, mb, pb), am = frag(ia + IMG_A, mb, pb), al = frag(ia + 2 * IMG_A, mb, pb);
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) {
+                    const SplitFrag bh = frag(ib, nb0 + j, pb), bm = frag(ib + IMG_B, nb0 + j, pb), bl = frag(ib + 2 * IMG_B, nb0 + j, pb);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bm.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bh.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bm.v, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[j], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+    }
+    // ---- flush: every accumulator register is 2 x 128 contiguous bytes of dW
+    const int m_base = mb * 32 + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const int n = (nb0 + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + (r & 3) + 8 * (r >> 2);
+            if (m < MM && n < NN) atomicAdd(g.dW + (int64_t)m * g.lddw + n, acc[j][r]);
+        }
+    }
+}
+
+template <int MM, int NN, int TNW, int DYM, int PKP, int BP>
+int launch_split_tn(WgradArgs g, hipStream_t s) {
+    constexpr int MB = (MM + 31) / 32, NB = (NN + 31) / 32, NW = MB * (NB / TNW);
+    constexpr int PA = (MB * 32 + 127) / 128, PB = (NB * 32 + 127) / 128, BUF = 3 * (PA + PB) * BP * 256;
+    constexpr size_t lds = 2 * (size_t)BUF + sizeof(float) * (4 * MB * 32 + 3 * NB * 32);
+    static_assert(lds <= 160 * 1024, "LDS");
+    if (g.dbias != nullptr || g.ws != nullptr || g.P % BP != 0) return PN2_EUNSUPPORTED;
+    auto kern = split_tn_kernel<MM, NN, TNW, DYM, PKP, BP>;
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
+    int64_t wgs = pn2_num_cus();
+    int64_t rows = pn2_cdiv(pn2_cdiv(g.P, wgs), BP) * BP;
+    if (PKP > 0 && rows % PKP != 0 && PKP % rows != 0) rows = pn2_cdiv(rows, PKP) * PKP;   // chunks never straddle a group: BP | PKP
+    g.rows_per_wg = rows;
+    wgs = pn2_cdiv(g.P, rows);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * NW), lds, s, g);
+    return pn2_launch_status();
+}
+
 template <int MM, int NN, int TNW, int DYM, bool XACT, int PKP, int BP>
 int launch_wgrad_full(WgradArgs g, hipStream_t s) {
     constexpr int MB = (MM + 31) / 32, NB = (NN + 31) / 32;
@@ -1264,6 +1873,22 @@ int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
     WgradArgs g{};
     g.Y = Y; g.ldy = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.coef = coef; g.X = X; g.ldx = ldx;
     g.x_aff = x_affine; g.dW = dW; g.lddw = lddw; g.dbias = dbias; g.P = P; g.M = M; g.N = N; g.lc = lc; g.ws = workspace;
+    if (pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_WGRAD) && dbias == nullptr && workspace == nullptr && P % 16 == 0) {
+#define SPLIT_WGRAD(MM, NN, TNW, PKP, BP)                                                                                \
+        if (M == MM && N == NN && P % BP == 0 && (PKP == 0 ? dZ != nullptr : (dZ == nullptr && Kpool == PKP)))          \
+            return launch_split_tn<MM, NN, TNW, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, PKP, BP>(g, s);
+        // (32-row chunks where the LDS holds them -- four column blocks per wave are 24 MFMAs per 16 rows: too short a barrier
+        // interval; same box: 196 x 128 dense 190 (fp32) / 216 (16-row chunks) / 157 us, 256 x 128 pooled 110 / 87 / 84)
+        SPLIT_WGRAD(256, 196, 7, 128, 16)
+        SPLIT_WGRAD(256, 196, 7, 64, 16)
+        SPLIT_WGRAD(256, 128, 4, 64, 32)
+        SPLIT_WGRAD(256, 128, 4, 128, 32)
+        SPLIT_WGRAD(196, 128, 4, 0, 32)
+        SPLIT_WGRAD(256, 128, 4, 64, 16)                            // (row counts that are no multiple of 32)
+        SPLIT_WGRAD(256, 128, 4, 128, 16)
+        SPLIT_WGRAD(196, 128, 4, 0, 16)
+#undef SPLIT_WGRAD
+    }
 #define WIDE_WGRAD(MM, NN, TNW, PKP, BP)                                                                                 \
     if (M == MM && N == NN && (PKP == 0 ? dZ != nullptr : (dZ == nullptr && Kpool == PKP)))                             \
         return launch_wgrad_full<MM, NN, TNW, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, true, PKP, BP>(g, s);
