@@ -131,10 +131,26 @@ STEP_MODEL_CFG5 = {("msg", 16): (118.13e9 / 524288, 3716e9 / 524288), ("ssg", 1)
 def make_step(workload, net, pts, labels, bucket):
     from pointnet12_amd.loss import nll_loss      # F.nll_loss (semseg.py:143) on the HIP library
     from pointnet12_amd import graph as _graph
-    # Where the next batch's geometry branch may start: between forward and backward when that chain (0.55 ms at 4096 points) is
-    # short against the backward pass it then runs under; at the top of the step when it is not (cfg2: the FPS chain IS the step;
-    # cfg5: 2.6 - 23 ms of FPS) -- measured: cfg2 0.68 -> 0.76 ms and cfg5 SSG 6.30 -> 6.40 ms with the late fork
-    late_fork = workload in ("msg", "ssg") and pts.shape[-1] <= 8192
+    # Where the next batch's geometry branch (FPS / ball query / 3-NN of the NEXT batch, 0.55 ms of small grids at 4096 points)
+    # starts inside the captured step.  Same-box A/B, ms per step (gpurun_out r5z, two repetitions each):
+    #     fork at      top          behind sa1    behind sa2    behind the loss   at sa2's backward   at sa1's backward
+    #     MSG          5.24 - 5.29  5.28 - 5.33   5.28 - 5.29   5.33 - 5.34       5.48 - 5.53         5.41 - 5.43
+    #     SSG          2.49 - 2.50  2.49          2.47          2.53              2.95                3.17 - 3.19
+    # (round 4 forked behind the loss: 5.84 -> 5.76 ms then.  The bf16-split GEMMs of this round are persistent workgroups that
+    # fill a CU's register file -- nothing co-runs with them -- and under the backward chain's small kernels the branch's FPS
+    # stretched the chain: rocprofv3 trace, tools/step_timeline.py.)  cfg2 / cfg5: the FPS chain is the step, top.
+    default_fork = {"msg": "top", "ssg": "sa2"}.get(workload, "top") if pts.shape[-1] <= 8192 else "top"
+    fork_at = os.environ.get("PN2_BENCH_FORK", default_fork)       # top | sa1 | sa2 | loss | sa2_bwd | sa1_bwd
+    late_fork = fork_at != "top" and workload in ("msg", "ssg")
+    if not late_fork:
+        fork_at = "top"
+    if fork_at in ("sa1", "sa2"):                 # behind that module's forward
+        getattr(net, fork_at).register_forward_hook(lambda m, i, o: _graph.fork_point())
+    if fork_at in ("sa1_bwd", "sa2_bwd"):         # where the backward pass reaches that module (the gradient of its output features)
+        def _hook_out(m, i, o):
+            if o[1].requires_grad:
+                o[1].register_hook(lambda g: (_graph.fork_point(), None)[1])
+        getattr(net, fork_at[:3]).register_forward_hook(_hook_out)
 
     def step():
         bucket.wait_reduced()                     # comm stream: the previous step's all-reduce (an event-wait node when captured)
@@ -145,10 +161,11 @@ def make_step(workload, net, pts, labels, bucket):
         else:
             lp = net(pts)
             loss = nll_loss(lp.reshape(-1, lp.shape[-1]), labels.reshape(-1))
-        if late_fork:
+        if late_fork and fork_at == "loss":
             _graph.fork_point()                   # a captured step starts the next batch's geometry branch here
         loss.backward()
         return loss
+    step.fork_in_step = late_fork                 # (GraphedStep: this step function calls graph.fork_point() itself)
     return step
 
 
@@ -587,7 +604,7 @@ def main():
             geometry = (lambda: net(pts[:, :3, :], pts[:, 3:, :])) if args.workload == "sa" else (lambda: net.features(pts))
         # (fork_in_step: the geometry branch starts at make_step's fork_point() where that pays -- see make_step)
         graphed = GraphedStep(compute, dev, geometry_fn=geometry,     # one hipGraph launch per step (failures raise)
-                              fork_in_step=args.workload in ("msg", "ssg") and n_points <= 8192)
+                              fork_in_step=getattr(compute, "fork_in_step", False))
     else:
         graphed = compute
 

@@ -323,6 +323,21 @@ def _recording():
     return _tape is not None and _tape.mode == "record"
 
 
+def _dest(*specs):
+    """Output tensors of the primitive being recorded, one per (shape, dtype) in ``specs``.  Recording ``into`` another tape's
+    items (the second graph of pointnet12_amd.graph's pair writes where the first one reads) the primitive is handed THOSE
+    tensors and its kernel writes them directly -- the first version computed into fresh tensors and copied: 23 extra launches
+    in every second step of MSG-SemSeg (rocprofv3 kernel trace: 161 against 138 kernels, +0.3 ms)."""
+    dst = None
+    if _tape is not None and _tape.mode == "record" and _tape.into is not None:
+        dst = _tape.into[len(_tape.items)]
+        dst = dst if isinstance(dst, tuple) else (dst,)
+        if len(dst) != len(specs) or any(tuple(d.shape) != tuple(sh) or d.dtype != dt or not d.is_contiguous()
+                                         for d, (sh, dt) in zip(dst, specs)):
+            dst = None                            # (a different call order / shape: _taped copies, as before)
+    return dst
+
+
 def _taped(compute):
     if _tape is None:
         return compute()
@@ -331,7 +346,8 @@ def _taped(compute):
         if _tape.into is not None:            # land the result in the tensors another graph replays from
             dst = _tape.into[len(_tape.items)]
             for d, x in zip(dst if isinstance(dst, tuple) else (dst,), v if isinstance(v, tuple) else (v,)):
-                d.copy_(x)
+                if d is not x:                # (not already written in place: see _dest)
+                    d.copy_(x)
             v = dst
         _tape.items.append(v)
         return v
@@ -361,7 +377,8 @@ def farthest_point_sample(xyz, npoint, start=None):
             raise IndexError("farthest_point_sample: start must hold B indices in [0, N)")   # free on host tensors;
             # device tensors are not read back (that would synchronise): the kernels clamp them into the cloud
     start = start.to(device=xyz.device, dtype=torch.int64).contiguous()
-    out = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
+    dst = _dest(((B, npoint), torch.int64))
+    out = dst[0] if dst else torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
     lib = _lib.load()
     nbytes = lib.pn2_fps_workspace_bytes(B, N, npoint)
     work = torch.empty(nbytes, device=xyz.device, dtype=torch.uint8) if nbytes else None
@@ -375,6 +392,13 @@ def _sampled_centres(xyz, fps_idx):
     branch gathers the next batch's centres, and the step's own chain is one launch per sampling stage shorter."""
     if _tape is not None and _tape.mode == "replay":
         return _taped(None)
+    B, N, C = xyz.shape
+    dst = _dest((tuple(fps_idx.shape) + (C,), torch.float32))
+    if dst and fps_idx.dtype == torch.int64 and fps_idx.is_contiguous():
+        xyz = _gpu_f32(xyz, "xyz")                # (index_points' launch, written where the other graph reads)
+        _check(_lib.load().pn2_gather_rows(_p(xyz), _p(fps_idx), B, N, C, fps_idx.numel() // B, _p(dst[0]), None, _lib.stream()),
+               "pn2_gather_rows")
+        return _taped(lambda: dst[0])
     return _taped(lambda: index_points(xyz, fps_idx, _checked=False).detach())
 
 
@@ -387,7 +411,8 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     S = new_xyz.shape[1]
     if nsample > N:
         raise RuntimeError("nsample (%d) > N (%d): the reference's mask assignment fails here too" % (nsample, N))
-    out = torch.empty(B, S, nsample, device=xyz.device, dtype=torch.int64)
+    dst = _dest(((B, S, nsample), torch.int64))
+    out = dst[0] if dst else torch.empty(B, S, nsample, device=xyz.device, dtype=torch.int64)
     r2 = float(np.float32(radius ** 2))
     lib = _lib.load()
     wb = lib.pn2_ball_query_workspace_bytes(B, N, S)          # > 0: the library wants to take the centres in spatial order
@@ -407,9 +432,13 @@ def three_nn(xyz1, xyz2):
     S = xyz2.shape[1]
     if S < 3:
         raise RuntimeError("three_nn needs S >= 3 (S == 2 raises in the reference as well)")
-    idx = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.int64)
-    dist = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
-    w = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+    dst = _dest(((B, N, 3), torch.int64), ((B, N, 3), torch.float32), ((B, N, 3), torch.float32))
+    if dst:
+        idx, dist, w = dst
+    else:
+        idx = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.int64)
+        dist = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+        w = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
     _check(_lib.load().pn2_three_nn(_p(xyz1), _p(xyz2), B, N, S, _p(idx), _p(dist), _p(w), _lib.stream()),
            "pn2_three_nn")
     return _taped(lambda: (idx, dist, w))
@@ -455,8 +484,9 @@ def _inverse_index(idx2d, T):
     def compute():
         B, M = idx2d.shape
         dev = idx2d.device
-        members = torch.empty(B, M, device=dev, dtype=torch.int32)
-        owners = torch.empty(B, M, device=dev, dtype=torch.int32)
+        dst = _dest(((B, M), torch.int32), ((B, M), torch.int32))
+        members = dst[0] if dst else torch.empty(B, M, device=dev, dtype=torch.int32)
+        owners = dst[1] if dst else torch.empty(B, M, device=dev, dtype=torch.int32)
         scratch = torch.empty(B, 2 * T + 1, device=dev, dtype=torch.int32)
         _check(_lib.load().pn2_invert_index(_p(idx2d), B, M, T, _p(members), _p(owners), _p(scratch), _lib.stream()),
                "pn2_invert_index")

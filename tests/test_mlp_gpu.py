@@ -330,6 +330,12 @@ def test_pool_in_gemm_epilogue_equals_the_pooling_pass(dev, P, pool, chans):
         bn.bias.data.uniform_(-0.5, 0.5, generator=gen)
     convs.to(dev), bns.to(dev)
     res = {}
+    # Bit equality of the two routes needs ONE arithmetic behind both: the narrow last layers have a pooled form on the bf16-split
+    # kernel for groups of 64 / 128 only (csrc/mlp_wide.hip, option PN2_SPLIT_NARROW), their plain form stays on the fp32 weight-
+    # resident kernel -- equally accurate, different last bits.  The option is pinned off here; the wide shapes below have both
+    # forms on the split kernel and are compared with it on.
+    narrow_was = _lib.options()["PN2_SPLIT_NARROW"]
+    _lib.set_option("PN2_SPLIT_NARROW", 0)
     for flag in (True, False):
         U.POOL_IN_EPILOGUE = flag
         try:
@@ -346,6 +352,9 @@ def test_pool_in_gemm_epilogue_equals_the_pooling_pass(dev, P, pool, chans):
                          [c[0] for c in calls])
         finally:
             U.POOL_IN_EPILOGUE = True
+            if flag is False:
+                _lib.set_option("PN2_SPLIT_NARROW", narrow_was)
+    _lib.set_option("PN2_SPLIT_NARROW", narrow_was)
     names_on, names_off = res[True][3], res[False][3]
     assert "pn2_conv1x1_fwd_pool" in names_on and "pn2_bn_pool_select" in names_on and "pn2_bn_relu_max" not in names_on
     assert "pn2_bn_relu_max" in names_off and "pn2_conv1x1_fwd_pool" not in names_off

@@ -12,7 +12,8 @@ lib = _lib.load(); raw = ctypes.CDLL(_lib.LIB_PATH)
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
 g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
-NAMES = ["barrier", "dma", "half1+xform", "wait", "epilogue", "half2"]
+NAMES = (["barrier", "dma", "half1+xform", "wait", "epilogue", "half2"] if os.environ.get("PN2_RING") == "1" else
+         ["barrier", "stage", "fetch", "mfma", "epilogue", "other"])         # ring_fwd_kernel / split_nt_kernel
 
 
 def r4(c):
@@ -40,6 +41,18 @@ def dump():
               + "  ".join("%s %4.1f%%" % (n, 100 * x / tot) for n, x in zip(NAMES, v.mean(0)[:6])))
 
 
+def dump_abs():
+    buf = (ctypes.c_ulonglong * (256 * 8 * 4))()
+    raw.pn2_debug_stamps_wide_abs(buf, 256 * 8 * 4)
+    a = np.array(buf, dtype=np.float64).reshape(256, 8, 4) / 100.0          # us
+    a = a[a[:, 0, 0] > 0]
+    t0 = a[:, :, 0].min()
+    a -= t0
+    f = lambda x: "%.1f / %.1f / %.1f" % (x.min(), np.median(x), x.max())
+    print("   absolute us after the first wave's entry (min / median / max over %d workgroups x waves): entry %s | loop start %s | loop end %s | exit %s"
+          % (len(a), f(a[:, :, 0]), f(a[:, :, 1]), f(a[:, :, 2]), f(a[:, :, 3])))
+
+
 for P, K, N in [(262144, 196, 256), (131072, 128, 256), (262144, 128, 196), (131072, 128, 128)]:
     X = torch.zeros(P, r4(K), device=dev); X[:, :K] = rnd(P, K)
     W, bias, Y = rnd(N, K), rnd(N), torch.empty(P, r4(N), device=dev)
@@ -50,3 +63,5 @@ for P, K, N in [(262144, 196, 256), (131072, 128, 256), (262144, 128, 196), (131
     torch.cuda.synchronize()
     print("fwd", (P, K, N))
     dump()
+    if os.environ.get("PN2_RING") != "1":
+        dump_abs()
