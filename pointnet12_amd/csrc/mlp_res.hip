@@ -18,6 +18,7 @@
 //     because dW is accumulated with atomics anyway) -- is dealt to the waves by a host-side LPT plan so every wave
 //     issues the same number of MFMAs.  dW accumulators stay in registers across all tiles of the workgroup.
 #include "mlp_loaders.h"
+#include "split_bf16.h"
 #include <algorithm>
 
 // mlp_wide.hip: the register-stationary forward (with the pooling extrema in its epilogue when Kpool > 0)
@@ -516,6 +517,298 @@ int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, 
     return pn2_launch_status();
 }
 
+// ----------------------------------------------------------------------------------------------- fused backward, bf16 pipe (round 5)
+// bwd_res_kernel's job -- dX = dY W masked by the previous ReLU with its BatchNorm-backward sums, dW += dY^T act(Y_prev), ONE pass
+// over dZ / Y / Y_prev -- with the fp32 products formed from exact three-way bf16 splits (split_bf16.h; mlp_wide.hip's
+// split_nt_kernel has the arithmetic and its measured error): 96 instead of 256 matrix-pipe cycles per 32 x 32 x 16 block.  On
+// v_mfma_f32_32x32x2_f32 these layers are matrix-pipe bound (128 x 96 at 1 M rows: 51.5 GFLOP = 330 us at the pipe's peak,
+// 540 us measured, against 270 us for its 1.34 GB at 5 TB/s); here they are bound by HBM.
+//   * 32-row chunks, double-buffered: dY and X = act(Y_prev) are transformed exactly as the fp32 kernel forms them, split, and
+//     stored as three bf16 images each in the dual-use layout of split_tn_kernel (rows of 128 channels, tr_img_off): dX reads
+//     dY along the rows (ds_read_b128), dW reads dY and X down the columns (ds_read_b64_tr_b16).  ONE barrier per chunk.
+//   * waves 0 .. CI_T - 1 own the chunk's dX tiles (their 32 columns of W pre-split in registers), the 32 x 32 tiles of dW are
+//     dealt to the other waves and stay in their accumulators for the whole launch.  The deal is not balanced to the MFMA (a
+//     dX tile is C_out / 32 units, a dW tile one) and does not need to be: the heaviest SIMD of 128 x 96 has 7 of the chunk's
+//     24 units, 2 700 matrix-pipe cycles per chunk = 165 us per launch, under the memory time.
+//   * the raw Y_prev chunk is kept in LDS as well (fp32): the mask and the sums of the dX epilogue need the pre-BatchNorm value.
+template <int CO_T, int CI_T, bool POOLED, bool MASKED>
+__global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw,
+                                                               int64_t chunks, float *dX, int ldxo, double *red_p, float *dW, int lddw) {
+    constexpr int Co = 32 * CO_T, Ci = 32 * CI_T, BP = 32, NT = 512, QD = Co / 4, QP = Ci / 4, LDP = Ci + 4;
+    constexpr int PANEL = BP * 256, BUF = 6 * PANEL;                // one 128-channel panel per piece: dY hi / mid / lo, X hi / mid / lo
+    constexpr int KBX = Co / 16;                                    // contraction blocks of a dX tile
+    constexpr int NDW = 8 - CI_T, NTILE = CO_T * CI_T, TW = (NTILE + NDW - 1) / NDW;     // dW tiles: waves CI_T .. 7, TW each at most
+    constexpr int IT_D = (BP * QD + NT - 1) / NT, IT_P = (BP * QP + NT - 1) / NT;
+    static_assert(!POOLED || NT % QD == 0, "pooled: one channel quad per thread");
+    unsigned char *lds_b = reinterpret_cast<unsigned char *>(res_lds);
+    float *Yps = res_lds + (2 * BUF) / 4;                           // [2][BP][LDP]: the raw Y_prev chunk
+    float *ctab = Yps + 2 * BP * LDP;                               // c0, q1, q0, mean of this layer: 4 * Co
+    float *xtab = ctab + 4 * Co;                                    // mean, scale, beta of the previous BatchNorm: 3 * Ci
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int G = gridDim.x;
+
+    RABS(wave, 0)
+    lazy_coef_prologue(dy.lc);
+    for (int i = t; i < 4 * Co; i += NT) ctab[i] = dy.coef[i];
+    if (MASKED)
+        for (int i = t; i < 3 * Ci; i += NT) xtab[i] = aff_p[i];
+
+    // ---- roles (the two kinds of wave run separate instantiations of the chunk loop: a dX wave's 96 fragment registers and a dW
+    // wave's 64 accumulator registers then share the register file instead of adding up)
+    const bool has_dx = wave < CI_T;
+    const int ecol = (has_dx ? wave : 0) * 32 + l31;                // the dX tile's column of this lane
+    // ---- staging: dY item i of thread t = quad q of row `row` (idx = t + 512 i; a thread without an i-th item repeats its last)
+    struct Raw { float4 y[IT_D]; float4 z[POOLED ? 1 : IT_D]; int4 a[1]; float4 p[IT_P]; };
+    Raw raw;
+    auto d_item = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QD) ? min(t + NT * i, BP * QD - 1) : t + NT * i; row = idx / QD; q = idx - row * QD; };
+    auto p_item = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QP) ? min(t + NT * i, BP * QP - 1) : t + NT * i; row = idx / QP; q = idx - row * QP; };
+    auto fetch = [&](int64_t chunk) {
+        const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;      // past the end: re-read the last chunk (never used)
+#pragma unroll
+        for (int i = 0; i < IT_D; ++i) {
+            int row, q;
+            d_item(i, row, q);
+            const unsigned o = (m0 + (unsigned)row) * (unsigned)dy.ld + 4u * (unsigned)q;
+            raw.y[i] = ld4(dy.Y + o);
+            if (!POOLED) raw.z[POOLED ? 0 : i] = ld4(dy.dZ + o);
+        }
+        if (POOLED) {                                               // the chunk lies inside ONE group (Kp a multiple of 32)
+            const unsigned o = (m0 >> dy.kshift) * (unsigned)dy.ldo + 4u * (unsigned)(t % QD);
+            raw.z[0] = ld4(dy.dZp + o);
+            raw.a[0] = ld4i(dy.arg + o);
+        }
+#pragma unroll
+        for (int i = 0; i < IT_P; ++i) {
+            int row, q;
+            p_item(i, row, q);
+            raw.p[i] = ld4(Yp + ((m0 + (unsigned)row) * (unsigned)ldp + 4u * (unsigned)q));
+        }
+    };
+    auto store_split = [&](unsigned char *img, int row, int q, const float4 v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2(v.x, v.y, h0, m0, l0);
+        split2(v.z, v.w, h1, m1, l1);
+        const unsigned o = tr_img_off(row, q >> 1) + 8u * (unsigned)(q & 1);
+        *reinterpret_cast<uint2 *>(img + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(img + o + PANEL) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2 *>(img + o + 2 * PANEL) = make_uint2(l0, l1);
+    };
+    auto stage = [&](int64_t chunk, int buf) {
+        unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * PANEL;
+        float *yp = Yps + buf * (BP * LDP);
+        const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;
+        const int kbase = POOLED ? (int)(m0 & ((1u << dy.kshift) - 1u)) : 0;
+#pragma unroll
+        for (int i = 0; i < IT_D; ++i) {
+            int row, q;
+            d_item(i, row, q);
+            const DyParams dp = dy_params_tab(ctab, Co, 4 * q, true);
+            float4 dz = raw.z[POOLED ? 0 : i];
+            if (POOLED) {
+                const int4 a = raw.a[0];
+                const int k = kbase + row;
+                dz.x = a.x == k ? dz.x : 0.f; dz.y = a.y == k ? dz.y : 0.f; dz.z = a.z == k ? dz.z : 0.f; dz.w = a.w == k ? dz.w : 0.f;
+            }
+            store_split(ia, row, q, dy_from(dz, raw.y[i], dp));
+        }
+#pragma unroll
+        for (int i = 0; i < IT_P; ++i) {
+            int row, q;
+            p_item(i, row, q);
+            float4 x = raw.p[i];
+            *reinterpret_cast<float4 *>(&yp[row * LDP + 4 * q]) = x;
+            if (MASKED) {
+                const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]), sc = *reinterpret_cast<const float4 *>(&xtab[Ci + 4 * q]);
+                const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * Ci + 4 * q]);
+                x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f); x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+                x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f); x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+            }
+            store_split(ib, row, q, x);
+        }
+    };
+    auto raw_landed = [&]() {                                       // (see split_nt_kernel: hipcc then waits for the requests, not for the stores)
+#pragma unroll
+        for (int i = 0; i < IT_D; ++i) {
+            asm volatile("" : "+v"(raw.y[i].x), "+v"(raw.y[i].y), "+v"(raw.y[i].z), "+v"(raw.y[i].w));
+            if (!POOLED) asm volatile("" : "+v"(raw.z[POOLED ? 0 : i].x), "+v"(raw.z[POOLED ? 0 : i].y), "+v"(raw.z[POOLED ? 0 : i].z), "+v"(raw.z[POOLED ? 0 : i].w));
+        }
+        if (POOLED) {
+            asm volatile("" : "+v"(raw.z[0].x), "+v"(raw.z[0].y), "+v"(raw.z[0].z), "+v"(raw.z[0].w));
+            asm volatile("" : "+v"(raw.a[0].x), "+v"(raw.a[0].y), "+v"(raw.a[0].z), "+v"(raw.a[0].w));
+        }
+#pragma unroll
+        for (int i = 0; i < IT_P; ++i) asm volatile("" : "+v"(raw.p[i].x), "+v"(raw.p[i].y), "+v"(raw.p[i].z), "+v"(raw.p[i].w));
+    };
+    // transposed fragment (split_tn_kernel's): channels 32 cblk + l31, rows 16 pb + 8 lh + 0 .. 7 of the chunk, of one piece image
+    const int g16 = lane >> 4, j16 = lane & 15, tq = j16 >> 2, tp = j16 & 3;
+    auto frag_t = [&](const unsigned char *img, int cblk, int pb) {
+        const int c0 = (cblk * 32 + 16 * (g16 & 1)) >> 3;
+        SplitFrag f;
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int row = 16 * pb + 8 * (g16 >> 1) + 4 * r2 + tq;
+            const unsigned o = tr_img_off(row, c0 + (tp >> 1)) + 8u * (unsigned)(tp & 1);
+            const pn2_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                reinterpret_cast<__attribute__((address_space(3))) pn2_s16x4 *>((__attribute__((address_space(3))) unsigned char *)(img) + o));
+            const uint2 u = __builtin_bit_cast(uint2, v);
+            f.u[2 * r2] = u.x; f.u[2 * r2 + 1] = u.y;
+        }
+        return f;
+    };
+
+    auto run = [&](auto dx_tag) {
+        constexpr bool DXW = decltype(dx_tag)::value;               // this wave owns a dX tile (else: dW tiles)
+        SplitFrag wh[DXW ? KBX : 1], wm[DXW ? KBX : 1], wl[DXW ? KBX : 1];         // W[co][ecol], co = 16 kb + 8 lh + 0 .. 7
+        float emu = 0.f, esc = 0.f, ebe = 0.f, eis = 0.f;
+        f32x16 accw[DXW ? 1 : TW];                                  // dW tile (wave - CI_T) + j NDW: rows 32 mb .., columns 32 nb ..
+        double st0 = 0.0, st1 = 0.0;
+        if (DXW) {
+            float v[KBX][8];
+#pragma unroll
+            for (int kb = 0; kb < KBX; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[kb][e] = W[(int64_t)(16 * kb + 8 * lh + e) * ldw + ecol];
+#pragma unroll
+            for (int kb = 0; kb < KBX; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(v[kb][2 * e], v[kb][2 * e + 1], wh[DXW ? kb : 0].u[e], wm[DXW ? kb : 0].u[e], wl[DXW ? kb : 0].u[e]);
+            if (MASKED) {
+                Affine a(aff_p, Ci);
+                emu = a.mean[ecol]; esc = a.scale[ecol]; ebe = a.beta[ecol]; eis = a.invstd[ecol];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accw[DXW ? 0 : j][r] = 0.f;
+        }
+        int64_t chunk = blockIdx.x;
+        fetch(chunk);
+        __syncthreads();                                            // the tables are in place
+        stage(chunk, 0);
+        fetch(chunk + G);
+        raw_landed();
+        int buf = 0;
+        RABS(wave, 1)
+        RSTAMP_DECL
+        while (chunk < chunks) {
+            __syncthreads();                                        // this chunk is staged in `buf`; every wave is done with buf ^ 1
+            RSTAMP(2)
+            stage(chunk + G, buf ^ 1);
+            RSTAMP(0)
+            fetch(chunk + 2 * (int64_t)G);
+            __builtin_amdgcn_sched_barrier(0);                      // (hipcc sinks the requests below the MFMAs otherwise: ISA of the first version)
+            RSTAMP(1)
+            const unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * PANEL;
+            if (!DXW) {
+                // ---- dW tiles of this wave: contraction over the chunk's 32 rows = two blocks
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int e = (wave - CI_T) + j * NDW;          // (uniform)
+                    if (e < NTILE) {
+                        const int mb = e / CI_T, nb = e - mb * CI_T;
+#pragma unroll
+                        for (int pb = 0; pb < BP / 16; ++pb) {
+                            const SplitFrag ah = frag_t(ia, mb, pb), am = frag_t(ia + PANEL, mb, pb), al = frag_t(ia + 2 * PANEL, mb, pb);
+                            const SplitFrag bh = frag_t(ib, nb, pb), bm = frag_t(ib + PANEL, nb, pb), bl = frag_t(ib + 2 * PANEL, nb, pb);
+                            f32x16 &c = accw[DXW ? 0 : j];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bm.v, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bh.v, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bm.v, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, c, 0, 0, 0);
+                        }
+                    }
+                }
+                RSTAMP(3)
+            } else {
+                // ---- dX tile: rows of the chunk x columns 32 wave .., contraction over C_out
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < KBX; ++kb) {
+                    const unsigned o = tr_img_off(l31, 2 * kb + lh);
+                    SplitFrag ah, am, al;
+                    ah.q = *reinterpret_cast<const uint4 *>(ia + o);
+                    am.q = *reinterpret_cast<const uint4 *>(ia + o + PANEL);
+                    al.q = *reinterpret_cast<const uint4 *>(ia + o + 2 * PANEL);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, wh[DXW ? kb : 0].v, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wl[DXW ? kb : 0].v, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wm[DXW ? kb : 0].v, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wh[DXW ? kb : 0].v, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wm[DXW ? kb : 0].v, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wh[DXW ? kb : 0].v, acc, 0, 0, 0);
+                }
+                RSTAMP(3)
+                // (no use of the request registers here: the stores below are unconditional in this instantiation, hipcc counts
+                // them, and the next chunk's staging waits with vmcnt(16) -- for the requests, not for the stores' acknowledgements)
+                const float *yq = Yps + buf * (BP * LDP) + (4 * lh) * LDP + ecol;
+                float *xb = dX + ((size_t)chunk * BP + 4 * lh) * (unsigned)ldxo + ecol;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    float dz = acc[r];
+                    if (MASKED) {
+                        const float y = yq[row * LDP];
+                        dz = bn_act(y, emu, esc, ebe) > 0.f ? dz : 0.f;
+                        s0 += dz;
+                        s1 = __builtin_fmaf(dz, (y - emu) * eis, s1);
+                    }
+                    PN2_STREAM_STORE(dz, xb + (size_t)row * (unsigned)ldxo);
+                }
+                if (MASKED) { st0 += (double)s0; st1 += (double)s1; }
+                RSTAMP(4)
+            }
+            chunk += G;
+            buf ^= 1;
+        }
+        RSTAMP_FLUSH(wave)
+        RABS(wave, 2)
+        // ---- flush (as bwd_res_kernel): dW tiles, the dX column's two reductions
+        if (!DXW) {
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const int e = (wave - CI_T) + j * NDW;
+                if (e < NTILE) {
+                    const int mb = e / CI_T, nb = e - mb * CI_T;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        atomicAdd(dW + (int64_t)(mb * 32 + acc_row(r, lh)) * lddw + nb * 32 + l31, accw[DXW ? 0 : j][r]);
+                }
+            }
+        } else if (MASKED && red_p != nullptr) {
+            st0 += __shfl_xor(st0, 32, 64);
+            st1 += __shfl_xor(st1, 32, 64);
+            if (lh == 0) {
+                double *rep = red_p + (size_t)(blockIdx.x % PN2_STAT_REPLICAS) * 2 * Ci;
+                atomicAdd(rep + ecol, st0);
+                atomicAdd(rep + Ci + ecol, st1);
+            }
+        }
+    };
+    if (has_dx) run(pn2_true{}); else run(pn2_false{});             // (grid <= chunks: every workgroup has a first chunk)
+    RABS(wave, 3)
+}
+
+template <int CO_T, int CI_T, bool POOLED, bool MASKED>
+int launch_split_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
+                         double *red_p, float *dW, int lddw, hipStream_t s) {
+    constexpr int Co = 32 * CO_T, Ci = 32 * CI_T;
+    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 4 * Co + 3 * Ci);
+    static_assert(lds <= 160 * 1024, "LDS");
+    if ((reinterpret_cast<uintptr_t>(dy.Y) & 15) != 0 || (reinterpret_cast<uintptr_t>(Yp) & 15) != 0) return PN2_EUNSUPPORTED;
+    auto kern = split_bwd_res_kernel<CO_T, CI_T, POOLED, MASKED>;
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
+    const int64_t chunks = tiles * (RES_BM / 32), cap = pn2_num_cus();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(512), lds, s, dy, Yp, ldp, aff_p, W, ldw, chunks, dX, ldxo,
+                       red_p, dW, lddw);
+    return pn2_launch_status();
+}
+
 // The (C_out, C_in) pairs the networks of the model zoo actually run on long row counts, per variant -- every instantiation
 // is a 2 000-line kernel; anything else goes to the streamed dgrad + wgrad pair (the entry point does that by itself).
 //   dense, masked  (hidden layers):        32x32, 64x64, 96x64, 128x128
@@ -530,6 +823,28 @@ int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, 
 // there (70 vs 71 us, 111 vs 123 us): taken from 262 144 rows on (the dense scans of cfg5).
 int dispatch_bwd_res(int Kpool, bool masked, int Co, int Ci, ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W,
                      int ldw, int64_t tiles, float *dX, int ldxo, double *red_p, float *dW, int lddw, hipStream_t s) {
+    if (pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_RES)) {
+        // the same pairs on the bf16 pipe (pooled: groups of 32 rows or a multiple -- a 32-row chunk lies inside one group)
+#define PN2_SPLIT_RES_CASE(CO, CI, POOLED, MASKED)                                                                        \
+        if (Co == CO && Ci == CI) {                                                                                        \
+            const int rc = launch_split_bwd_res<CO / 32, CI / 32, POOLED, MASKED>(dy, Yp, ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, s); \
+            if (rc != PN2_EUNSUPPORTED) return rc;                                                                         \
+        }
+        // (32 x 32 and 64 x 32 stay on the fp32 kernels: two or three waves of eight have matrix work there, the chunk is one
+        // memory latency long either way -- same box, us at 524 288 rows: 63 -> 77 and 79 -> 99; PN2_SPLIT_RES=2 takes them too)
+        const bool all = pn2_opt(PN2_OPT_SPLIT_RES) >= 2;
+        if (Kpool == 0 && masked) {
+            if (all) { PN2_SPLIT_RES_CASE(32, 32, false, true) }
+            PN2_SPLIT_RES_CASE(64, 64, false, true) PN2_SPLIT_RES_CASE(96, 64, false, true)
+            if (tiles >= 4096) { PN2_SPLIT_RES_CASE(128, 128, false, true) }
+        } else if (Kpool == 0) {
+            if (tiles >= 4096) { PN2_SPLIT_RES_CASE(128, 128, false, false) }
+        } else if (masked && Kpool % 32 == 0) {
+            if (all) { PN2_SPLIT_RES_CASE(64, 32, true, true) }
+            PN2_SPLIT_RES_CASE(128, 64, true, true) PN2_SPLIT_RES_CASE(128, 96, true, true)
+        }
+#undef PN2_SPLIT_RES_CASE
+    }
     if (Kpool == 0 && masked) {
         PN2_RES_CASE(32, 32, 0, true) PN2_RES_CASE(64, 64, 0, true) PN2_RES_CASE(96, 64, 0, true)
         if (tiles >= 4096) { PN2_RES_CASE(128, 128, 0, true) }

@@ -20,6 +20,7 @@
 //
 // Whole BM-row tiles only; the entry points of mlp.hip hand a ragged tail to the streamed kernels.
 #include "mlp_loaders.h"
+#include "split_bf16.h"
 
 namespace {
 
@@ -864,29 +865,11 @@ int launch_ring_fwd(const RegwArgs &g, hipStream_t s) {
 //     ([piece][row][128 bytes], the 16-byte slot of (k block, half-wave) XOR-swizzled by (row >> 1) & 7: the sixteen rows of a
 //     ds_read_b128 service group cover sixteen distinct bank slots), double-buffered, one barrier per chunk;
 //   * epilogues as the fp32 kernels': the accumulator layout of 32x32x16 is that of 32x32x2.
-typedef __bf16 pn2_bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 pn2_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float pn2_f32x2 __attribute__((ext_vector_type(2)));
-union SplitFrag { pn2_bf16x8 v; unsigned u[4]; uint4 q; };
-
-// two fp32 values -> three packed bf16 pairs (v_cvt_pk_bf16_f32, v_and / v_lshl, v_pk_add_f32: nine instructions)
-__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo) {
-    pn2_f32x2 v = {a, b};
-    const pn2_bf16x2 h = __builtin_convertvector(v, pn2_bf16x2);
-    v = v - __builtin_convertvector(h, pn2_f32x2);
-    const pn2_bf16x2 m = __builtin_convertvector(v, pn2_bf16x2);
-    v = v - __builtin_convertvector(m, pn2_f32x2);
-    const pn2_bf16x2 l = __builtin_convertvector(v, pn2_bf16x2);
-    hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
-}
-
 // KS = 2 (contraction lengths whose W slice does not fit one wave's registers: K = 256): TWO waves share a column block, each
 // holds the W fragments of two of every chunk's four k blocks and accumulates its half of the contraction; at the end of a tile
 // the pair swaps one row block each through LDS, so that each wave finishes (adds, masks, stores, reduces) one of the two.
 // gridDim.y column groups of NCB blocks each (N = 196 with K = 256: 4 + 4 blocks; the staging of a tile is then done by two
 // workgroups -- its rows come from HBM once and from L2 / MALL the second time).
-struct pn2_true { static constexpr bool value = true; };
-struct pn2_false { static constexpr bool value = false; };
 
 template <int K4, int NCB, int RS, int TM, int MODE, int EPI, bool BNN, int PKP, bool NX, int KS>
 __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) void split_nt_kernel(const RegwArgs g) {
@@ -1821,12 +1804,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 // the programming guide's dual-use image (b) -- off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) --
 // and the fragments come back through ds_read_b64_tr_b16 (the hardware's 4 x 16 transpose: lane 4 q + p of a 16-lane group
 // supplies the address of block row q, elements 4 p .. 4 p + 3; lane i receives column i): two reads per fragment, conflict-free.
-typedef short pn2_s16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned tr_img_off(int row, int ch) {      // byte offset of 16-byte chunk ch of row `row` inside a panel
-    return (unsigned)(256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))));
-}
-
 template <int MM, int NN, int TNW, int DYM, int PKP, int BP>          // BP: rows per chunk = BP / 16 contraction blocks
 __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) void split_tn_kernel(const WgradArgs g) {
     constexpr int MB = (MM + 31) / 32, NB = (NN + 31) / 32, WN = NB / TNW, NW = MB * WN, NT = 64 * NW;

@@ -47,7 +47,7 @@ def dump_abs():
     print("   workgroup exit (max over its waves), sorted: " + " ".join("%.0f" % x for x in np.sort(a[:, :, 3].max(1))))
 
 
-for P, Cl, Cp, Kp in [(1048576, 128, 96, 128), (1048576, 96, 64, 0), (524288, 128, 64, 64), (524288, 64, 64, 0)]:
+for P, Cl, Cp, Kp in [(1048576, 128, 96, 128), (1048576, 96, 64, 0), (524288, 128, 64, 64), (524288, 64, 64, 0), (524288, 32, 32, 0)]:
     Y, Yp = rnd(P, Cl), rnd(P, Cp)
     coef, affp = affine(Cl), affine(Cp)
     Wt = rnd(Cl, Cp)
@@ -61,7 +61,7 @@ for P, Cl, Cp, Kp in [(1048576, 128, 96, 128), (1048576, 96, 64, 0), (524288, 12
     for _ in range(3):
         assert lib.pn2_conv1x1_bwd(*dz, p(Y), Cl, p(coef), p(Wt), Cp, p(Yp), Cp, p(affp), p(dX), Cp, p(red), p(dW), Cp, P, Cl, Cp, None, st) == 0
     print("bwd", (P, Cl, Cp, Kp))
-    dump(["finish", "fetch", "barrier1", "compute", "barrier2", "", "", ""])
+    dump(["stage/finish", "fetch", "barrier", "mfma/compute", "epilogue/barrier2", "", "", ""])
     dump_abs()
     del Y, Yp, dX
 for P, K, N in [(1048576, 96, 128), (1048576, 64, 96)]:
