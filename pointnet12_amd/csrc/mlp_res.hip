@@ -544,6 +544,9 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     float *Yps = res_lds + (2 * BUF) / 4;                           // [2][BP][LDP]: the raw Y_prev chunk
     float *ctab = Yps + 2 * BP * LDP;                               // c0, q1, q0, mean of this layer: 4 * Co
     float *xtab = ctab + 4 * Co;                                    // mean, scale, beta of the previous BatchNorm: 3 * Ci
+    // WL_LDS (C_out = 128 with C_in < 128): a dX wave's `lo` fragments -- the operand of one MFMA in six -- live in LDS, 8 KiB per
+    // wave, written and read by that wave alone: 32 registers for the second accumulator (split_nt_kernel does the same at K = 196)
+    constexpr bool WL_LDS = CO_T == 4 && CI_T < 4;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
     const int G = gridDim.x;
 
@@ -559,10 +562,14 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     const int ecol = (has_dx ? wave : 0) * 32 + l31;                // the dX tile's column of this lane
     // ---- staging: dY item i of thread t = quad q of row `row` (idx = t + 512 i; a thread without an i-th item repeats its last)
     struct Raw { float4 y[IT_D]; float4 z[POOLED ? 1 : IT_D]; int4 a[1]; float4 p[IT_P]; };
-    Raw raw;
+    // D2: two register sets, chunk j's requests live in set j & 1 and go out two chunks ahead of their use.  (C_out = 128: one set
+    // -- a dX wave holds 96 fragment registers there, and its chunk is longer than a memory latency anyway.)
+    constexpr bool D2 = CO_T < 4;
+    constexpr bool DX2 = CO_T * CI_T < 16;                          // two alternating dX accumulators (128 x 128: no registers for them, no LDS for WL_LDS)
+    Raw raw0, raw1;
     auto d_item = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QD) ? min(t + NT * i, BP * QD - 1) : t + NT * i; row = idx / QD; q = idx - row * QD; };
     auto p_item = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QP) ? min(t + NT * i, BP * QP - 1) : t + NT * i; row = idx / QP; q = idx - row * QP; };
-    auto fetch = [&](int64_t chunk) {
+    auto fetch = [&](Raw &raw, int64_t chunk) {
         const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;      // past the end: re-read the last chunk (never used)
 #pragma unroll
         for (int i = 0; i < IT_D; ++i) {
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
         *reinterpret_cast<uint2 *>(img + o + PANEL) = make_uint2(m0, m1);
         *reinterpret_cast<uint2 *>(img + o + 2 * PANEL) = make_uint2(l0, l1);
     };
-    auto stage = [&](int64_t chunk, int buf) {
+    auto stage = [&](Raw &raw, int64_t chunk, int buf) {
         unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * PANEL;
         float *yp = Yps + buf * (BP * LDP);
         const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
             store_split(ib, row, q, x);
         }
     };
-    auto raw_landed = [&]() {                                       // (see split_nt_kernel: hipcc then waits for the requests, not for the stores)
+    auto raw_landed = [&](Raw &raw) {                                       // (see split_nt_kernel: hipcc then waits for the requests, not for the stores)
 #pragma unroll
         for (int i = 0; i < IT_D; ++i) {
             asm volatile("" : "+v"(raw.y[i].x), "+v"(raw.y[i].y), "+v"(raw.y[i].z), "+v"(raw.y[i].w));
@@ -658,9 +665,11 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
 
     auto run = [&](auto dx_tag) {
         constexpr bool DXW = decltype(dx_tag)::value;               // this wave owns a dX tile (else: dW tiles)
-        SplitFrag wh[DXW ? KBX : 1], wm[DXW ? KBX : 1], wl[DXW ? KBX : 1];         // W[co][ecol], co = 16 kb + 8 lh + 0 .. 7
+        SplitFrag wh[DXW ? KBX : 1], wm[DXW ? KBX : 1], wl[DXW && !WL_LDS ? KBX : 1];       // W[co][ecol], co = 16 kb + 8 lh + 0 .. 7
+        uint4 *wl_lds = reinterpret_cast<uint4 *>(xtab + 3 * Ci + (Ci % 4 ? 4 - Ci % 4 : 0)) + (size_t)(DXW ? wave : 0) * KBX * 64 + lane;
         float emu = 0.f, esc = 0.f, ebe = 0.f, eis = 0.f;
-        f32x16 accw[DXW ? 1 : TW];                                  // dW tile (wave - CI_T) + j NDW: rows 32 mb .., columns 32 nb ..
+        // dW tile (wave - CI_T) + j NDW: rows 32 mb .., columns 32 nb ..
+        f32x16 accw[DXW ? 1 : TW];
         double st0 = 0.0, st1 = 0.0;
         if (DXW) {
             float v[KBX][8];
@@ -669,9 +678,11 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[kb][e] = W[(int64_t)(16 * kb + 8 * lh + e) * ldw + ecol];
 #pragma unroll
-            for (int kb = 0; kb < KBX; ++kb)
+            for (int kb = 0; kb < KBX; ++kb) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split2(v[kb][2 * e], v[kb][2 * e + 1], wh[DXW ? kb : 0].u[e], wm[DXW ? kb : 0].u[e], wl[DXW ? kb : 0].u[e]);
+                for (int e = 0; e < 4; ++e) split2(v[kb][2 * e], v[kb][2 * e + 1], wh[DXW ? kb : 0].u[e], wm[DXW ? kb : 0].u[e], wl[DXW && !WL_LDS ? kb : 0].u[e]);
+                if (WL_LDS) wl_lds[kb * 64] = wl[0].q;
+            }
             if (MASKED) {
                 Affine a(aff_p, Ci);
                 emu = a.mean[ecol]; esc = a.scale[ecol]; ebe = a.beta[ecol]; eis = a.invstd[ecol];
@@ -683,50 +694,75 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
                 for (int r = 0; r < 16; ++r) accw[DXW ? 0 : j][r] = 0.f;
         }
         int64_t chunk = blockIdx.x;
-        fetch(chunk);
+        fetch(raw0, chunk);
         __syncthreads();                                            // the tables are in place
-        stage(chunk, 0);
-        fetch(chunk + G);
-        raw_landed();
+        stage(raw0, chunk, 0);
+        if (D2) {
+            fetch(raw1, chunk + G);
+            fetch(raw0, chunk + 2 * (int64_t)G);
+            raw_landed(raw1);
+        } else {
+            fetch(raw0, chunk + G);
+        }
+        raw_landed(raw0);
         int buf = 0;
         RABS(wave, 1)
         RSTAMP_DECL
-        while (chunk < chunks) {
+        // one chunk: stage the next one (its requests went out two chunks ago -- with one chunk of distance the 32 x 32 and 64 x 32
+        // pairs, whose chunk is shorter than a memory latency, waited for them: 63 -> 77 us at 524 288 rows), refill its register
+        // set, multiply this one
+        auto iter = [&](Raw &raw) {
             __syncthreads();                                        // this chunk is staged in `buf`; every wave is done with buf ^ 1
             RSTAMP(2)
-            stage(chunk + G, buf ^ 1);
+            stage(raw, chunk + G, buf ^ 1);
             RSTAMP(0)
-            fetch(chunk + 2 * (int64_t)G);
+            fetch(raw, chunk + (D2 ? 3 : 2) * (int64_t)G);
             __builtin_amdgcn_sched_barrier(0);                      // (hipcc sinks the requests below the MFMAs otherwise: ISA of the first version)
             RSTAMP(1)
             const unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * PANEL;
             if (!DXW) {
-                // ---- dW tiles of this wave: contraction over the chunk's 32 rows = two blocks
+                // ---- dW tiles of this wave: contraction over the chunk's 32 rows = two blocks.  Two tiles at a time, their MFMAs
+                // alternating: back-to-back MFMAs on ONE accumulator each wait for the one before (8 passes + the pipeline; in-kernel
+                // stamps of the first version: 41 - 52 cycles per MFMA issued)
+                auto frags = [&](int tile, int pb, SplitFrag (&f)[6]) {
+                    const int mb = tile / CI_T, nb = tile - mb * CI_T;
+                    f[0] = frag_t(ia, mb, pb); f[1] = frag_t(ia + PANEL, mb, pb); f[2] = frag_t(ia + 2 * PANEL, mb, pb);
+                    f[3] = frag_t(ib, nb, pb); f[4] = frag_t(ib + PANEL, nb, pb); f[5] = frag_t(ib + 2 * PANEL, nb, pb);
+                };
+                // the six products of a block, smallest terms first: (A piece, B piece) = (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {3, 5, 4, 3, 4, 3};
+                constexpr int JS = TW == 3 ? 1 : 2;                  // (three tiles per wave -- 128 x 96 -- have no registers for a pair's operands)
 #pragma unroll
-                for (int j = 0; j < TW; ++j) {
-                    const int e = (wave - CI_T) + j * NDW;          // (uniform)
-                    if (e < NTILE) {
-                        const int mb = e / CI_T, nb = e - mb * CI_T;
+                for (int j = 0; j < TW; j += JS) {
+                    const int e0 = (wave - CI_T) + j * NDW, e1 = e0 + NDW;                  // (uniform)
+                    const bool two = JS == 2 && j + 1 < TW && e1 < NTILE;
+                    if (e0 < NTILE) {
 #pragma unroll
                         for (int pb = 0; pb < BP / 16; ++pb) {
-                            const SplitFrag ah = frag_t(ia, mb, pb), am = frag_t(ia + PANEL, mb, pb), al = frag_t(ia + 2 * PANEL, mb, pb);
-                            const SplitFrag bh = frag_t(ib, nb, pb), bm = frag_t(ib + PANEL, nb, pb), bl = frag_t(ib + 2 * PANEL, nb, pb);
-                            f32x16 &c = accw[DXW ? 0 : j];
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bm.v, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bh.v, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bm.v, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, c, 0, 0, 0);
+                            SplitFrag f0[6], f1[6];
+                            frags(e0, pb, f0);
+                            if (two) {
+                                frags(e1, pb, f1);
+#pragma unroll
+                                for (int q = 0; q < 6; ++q) {
+                                    accw[DXW ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[PA[q]].v, f0[PB[q]].v, accw[DXW ? 0 : j], 0, 0, 0);
+                                    accw[DXW || j + 1 >= TW ? 0 : j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[PA[q]].v, f1[PB[q]].v, accw[DXW || j + 1 >= TW ? 0 : j + 1], 0, 0, 0);
+                                }
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 6; ++q)
+                                    accw[DXW ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[PA[q]].v, f0[PB[q]].v, accw[DXW ? 0 : j], 0, 0, 0);
+                            }
                         }
                     }
                 }
                 RSTAMP(3)
             } else {
-                // ---- dX tile: rows of the chunk x columns 32 wave .., contraction over C_out
-                f32x16 acc;
+                // ---- dX tile: rows of the chunk x columns 32 wave .., contraction over C_out (two accumulators, alternating: one
+                // chain of 6 C_out / 16 dependent MFMAs issued at 41 - 52 cycles apiece, in-kernel stamps of the first versions)
+                f32x16 acc, acc2;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 #pragma unroll
                 for (int kb = 0; kb < KBX; ++kb) {
                     const unsigned o = tr_img_off(l31, 2 * kb + lh);
@@ -735,35 +771,60 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
                     am.q = *reinterpret_cast<const uint4 *>(ia + o + PANEL);
                     al.q = *reinterpret_cast<const uint4 *>(ia + o + 2 * PANEL);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, wh[DXW ? kb : 0].v, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wl[DXW ? kb : 0].v, acc, 0, 0, 0);
+                    f32x16 &d = DX2 ? acc2 : acc;
+                    SplitFrag wlo;
+                    if (WL_LDS) wlo.q = wl_lds[kb * 64]; else wlo = wl[DXW && !WL_LDS ? kb : 0];
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wlo.v, d, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wm[DXW ? kb : 0].v, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wh[DXW ? kb : 0].v, acc, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wh[DXW ? kb : 0].v, d, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wm[DXW ? kb : 0].v, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wh[DXW ? kb : 0].v, acc, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wh[DXW ? kb : 0].v, d, 0, 0, 0);
                 }
+#ifdef PN2_STAMP
+                { float a0_ = acc[0] + acc2[0]; asm volatile("" : "+v"(a0_)); }           // (the stamp then sees the MFMAs complete, not issued)
+#endif
                 RSTAMP(3)
                 // (no use of the request registers here: the stores below are unconditional in this instantiation, hipcc counts
                 // them, and the next chunk's staging waits with vmcnt(16) -- for the requests, not for the stores' acknowledgements)
                 const float *yq = Yps + buf * (BP * LDP) + (4 * lh) * LDP + ecol;
-                float *xb = dX + ((size_t)chunk * BP + 4 * lh) * (unsigned)ldxo + ecol;
+                float yv[16];
+                if (MASKED) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yv[r] = yq[((r & 3) + 8 * (r >> 2)) * LDP];      // immediate offsets, one wait
+                }
+                // one 64-bit base per chunk and a running 32-bit offset (sixteen row pointers carried across the loop were 32 registers)
+                float *xb = dX + ((size_t)chunk * BP + 4 * lh) * (unsigned)ldxo;
+                unsigned offx = (unsigned)ecol;
+                asm volatile("" : "+v"(offx));
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2);
-                    float dz = acc[r];
+                    float dz = DX2 ? acc[r] + acc2[r] : acc[r];
                     if (MASKED) {
-                        const float y = yq[row * LDP];
+                        const float y = yv[r];
                         dz = bn_act(y, emu, esc, ebe) > 0.f ? dz : 0.f;
                         s0 += dz;
                         s1 = __builtin_fmaf(dz, (y - emu) * eis, s1);
                     }
-                    PN2_STREAM_STORE(dz, xb + (size_t)row * (unsigned)ldxo);
+#if defined(PN2_EXP_NOSTORE)
+                    if (dz == 1.2345e-33f) xb[offx] = dz;
+#elif defined(PN2_EXP_PLAINSTORE)
+                    xb[offx] = dz;
+#else
+                    PN2_STREAM_STORE(dz, xb + offx);
+#endif
+                    offx += ((r & 3) == 3 ? 5u : 1u) * (unsigned)ldxo;       // rows (r & 3) + 8 (r >> 2): +1 +1 +1 +5
                 }
                 if (MASKED) { st0 += (double)s0; st1 += (double)s1; }
                 RSTAMP(4)
             }
             chunk += G;
             buf ^= 1;
+        };
+        while (chunk < chunks) {
+            iter(D2 ? raw1 : raw0);
+            if (chunk >= chunks) break;
+            iter(raw0);
         }
         RSTAMP_FLUSH(wave)
         RABS(wave, 2)
@@ -797,7 +858,8 @@ template <int CO_T, int CI_T, bool POOLED, bool MASKED>
 int launch_split_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
                          double *red_p, float *dW, int lddw, hipStream_t s) {
     constexpr int Co = 32 * CO_T, Ci = 32 * CI_T;
-    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 4 * Co + 3 * Ci);
+    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 4 * Co + 3 * Ci) +
+                           (CO_T == 4 && CI_T < 4 ? (size_t)CI_T * (Co / 16) * 1024 : 0);      // (the kernel's WL_LDS region)
     static_assert(lds <= 160 * 1024, "LDS");
     if ((reinterpret_cast<uintptr_t>(dy.Y) & 15) != 0 || (reinterpret_cast<uintptr_t>(Yp) & 15) != 0) return PN2_EUNSUPPORTED;
     auto kern = split_bwd_res_kernel<CO_T, CI_T, POOLED, MASKED>;
