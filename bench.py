@@ -36,10 +36,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 # C-ABI GEMM entry point -> kernel families of tools/pmc_traffic.py that serve it
 GEMM_FAMILIES = {"pn2_conv1x1_bwd_pair": ["bwd_pair_kernel"],
-                 "pn2_conv1x1_wgrad": ["gemm_tn_kernel", "wgrad_skinny_kernel", "wgrad_first_cf_kernel", "wgrad_full_kernel", "wgrad_reduce_kernel"],
-                 "pn2_conv1x1_dgrad": ["gemm_nt_kernel<dgrad>", "regw_nt_kernel<dgrad>", "fewrow_nt_kernel<dgrad>"],
-                 "pn2_conv1x1_bwd": ["gemm_bwd_fused_kernel"],
-                 "pn2_conv1x1_fwd": ["gemm_nt_kernel<fwd>", "fwd_res_kernel", "regw_nt_kernel<fwd>", "fewrow_nt_kernel<fwd>"]}
+                 "pn2_conv1x1_wgrad": ["gemm_tn_kernel", "wgrad_skinny_kernel", "wgrad_first_cf_kernel", "wgrad_full_kernel", "wgrad_reduce_kernel",
+                                       "split_tn_kernel"],
+                 "pn2_conv1x1_dgrad": ["gemm_nt_kernel<dgrad>", "regw_nt_kernel<dgrad>", "fewrow_nt_kernel<dgrad>", "split_nt_kernel<dgrad>"],
+                 "pn2_conv1x1_bwd": ["gemm_bwd_fused_kernel"],     # (bwd_res_kernel + split_bwd_res_kernel: tools/pmc_traffic.py)
+                 "pn2_conv1x1_fwd": ["gemm_nt_kernel<fwd>", "fwd_res_kernel", "regw_nt_kernel<fwd>", "fewrow_nt_kernel<fwd>", "split_nt_kernel<fwd>"]}
 
 WORKLOADS = {
     "msg": "PointNet2 MSG SemSeg (SetAbstractionMsg 3 radii + FeaturePropagation), B=16x4096x(3+6), fwd+bwd",

@@ -58,12 +58,23 @@ stats cfg5_msg $CFG5_MSG --steps 5 --warmup 2
 # 4. A/B lines of the round's switches (same box, back to back, twice)
 : > $O/ab_switches.txt
 for rep in 1 2; do
-  for v in "PN2_RING=0" "PN2_RING=1" "PN2_LAZY_BN=0" "PN2_LAZY_BN=1" "PN2_WIDE_POOL=0" "PN2_WIDE_POOL=1" "PN2_BWD_PAIR=0" "PN2_BWD_PAIR=1" "PN2_GEO_FORK_LATE=0" "PN2_GEO_FORK_LATE=1"; do
+  for v in "PN2_SPLIT=0" "PN2_SPLIT=1" "PN2_SPLIT_RES=0" "PN2_SPLIT_RES=1" "PN2_SPLIT_RES=2" "PN2_SPLIT_NARROW=0" "PN2_SPLIT_WGRAD=0" "PN2_SPLIT_K256=0" \
+           "PN2_BENCH_FORK=top" "PN2_BENCH_FORK=sa2" "PN2_BENCH_FORK=loss" "PN2_RING=1" "PN2_LAZY_BN=0" "PN2_WIDE_POOL=0" "PN2_BWD_PAIR=0"; do
     for w in msg ssg; do
       env $v python3 bench.py --workload $w --no-cpu-baseline --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], d['ms_per_step'])" $v $w >> $O/ab_switches.txt
     done
   done
 done
+
+# 5. the captured step as the chip ran it: rocprofv3 kernel trace -> per-step wall time, queues, time attributed per kernel family
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/trace_msg -o t -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 20 --warmup 5 > /dev/null 2> $O/trace_msg.err )
+python3 tools/step_timeline.py $(find $O/trace_msg -name "*kernel_trace.csv" | head -1) --dump 1 > $O/step_timeline_msg.txt 2>&1
+rm -rf $O/trace_msg
+# 6. in-kernel stamps of the bf16-split kernels (a STAMP build beside the product library: tools/exp/build_variant.sh stamp "" 1)
+if [ -f pointnet12_amd/libpn2_hip_stamp.so ]; then
+  PN2_LIB_PATH=pointnet12_amd/libpn2_hip_stamp.so python3 tools/stamp_wide.py > $O/stamp_split_nt.txt 2>&1
+  PN2_SPLIT_RES=2 PN2_LIB_PATH=pointnet12_amd/libpn2_hip_stamp.so python3 tools/stamp_res.py > $O/stamp_split_bwd_res.txt 2>&1
+fi
 
 tools/exp/mfma_peak > $O/mfma_peak.txt 2>&1
 [ -x tools/exp/mfma_shape ] && tools/exp/mfma_shape > $O/mfma_shape.txt 2>&1

@@ -19,8 +19,12 @@ def family(name):
     fam = m.group(1) if m else name
     if fam in ("gemm_nt_kernel", "fewrow_nt_kernel"):
         fam += "<" + ("fwd" if "EpiFwd" in name else "dgrad") + ">"
-    if fam == "bwd_res_kernel":
+    if fam in ("bwd_res_kernel", "split_bwd_res_kernel"):   # the fused data + weight gradient (fp32 pipe / bf16x3 split)
         fam = "gemm_bwd_fused_kernel"
+    if fam == "split_nt_kernel":                 # template arguments: K4, NCB, RS, TM, MODE, EPI (0 = forward), ...
+        targs = re.search(r"split_nt_kernel<([^>]*)>", name)
+        epi = targs.group(1).split(",")[5].strip() if targs else "0"
+        fam += "<fwd>" if epi == "0" else "<dgrad>"
     if fam == "regw_nt_kernel":                  # template arguments: K4, NCB, RS, TM, KC, MODE, EPI (0 = forward), ...
         targs = re.search(r"regw_nt_kernel<([^>]*)>", name)
         epi = targs.group(1).split(",")[6].strip() if targs else "0"
