@@ -882,7 +882,7 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
     constexpr int FPOOL = EPI == EPI_FWD ? PKP : 0;
     constexpr int SUB = FPOOL > BM ? FPOOL / BM : 1;                // tiles per pooling group (a group spans SUB consecutive tiles)
     constexpr int KBW = KB / KS;                                    // k blocks whose W fragments this wave holds
-    static_assert(K4 % 4 == 0 && KBW <= 13, "W slice: 12 registers per k block");
+    static_assert(K4 % 4 == 0 && KBW <= 13, "W slice: 12 registers per k block (8 from 13 blocks on: WL_LDS)");
     static_assert(FPOOL == 0 || (RS == 1 && (BM % FPOOL == 0 || FPOOL % BM == 0) && FPOOL % 32 == 0), "forward pooling geometry");
     static_assert(!POOLED || (PKP > 0 && (PKP % BM == 0 || BM % PKP == 0)), "pooled dY: groups and tiles nest");
     unsigned char *lds_b = reinterpret_cast<unsigned char *>(wide_lds);
@@ -902,6 +902,9 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
     // item's vector instructions (sched_group_barrier)
 #ifndef PN2_SPLIT_ORDER
 #define PN2_SPLIT_ORDER 2
+#endif
+#ifndef PN2_SPLIT_PV_EARLY
+#define PN2_SPLIT_PV_EARLY 1
 #endif
     const bool late_stager = PN2_SPLIT_ORDER == 1 && NW >= 8 && wave >= NW / 2;                             // (uniform)
     // N not a multiple of 32 (196): only the last column block is ragged -- the others store without a column predicate (64
@@ -931,7 +934,10 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
 
     // ---- staging: item i of thread t covers the float4 quad q = idx % 16 of row idx / 16 of a chunk (idx = t + NT i)
     constexpr int QI = BM * 16, A_IT = (QI + NT - 1) / NT;
-    struct Raw { float4 y[A_IT]; float4 z[DY ? A_IT : 1]; int4 a[POOLED ? A_IT : 1]; };
+    // ONEZ (pooled dY, the tile inside one group of the max-pool, all staging before all requests): a thread's items lie in one
+    // channel quad (NT is a multiple of 16) -- ONE (dZp, arg) quad per chunk serves them all
+    constexpr bool ONEZ = POOLED && KS == 2 && PKP % BM == 0;
+    struct Raw { float4 y[A_IT]; float4 z[DY ? (ONEZ ? 1 : A_IT) : 1]; int4 a[POOLED ? (ONEZ ? 1 : A_IT) : 1]; };
     Raw raw;
     const int64_t tiles = g.tiles;
     const int G = gridDim.x;
@@ -955,11 +961,11 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
         const unsigned kk = k < K4 ? (unsigned)k : (unsigned)(K4 - 4);            // (zeroed when staged)
         const unsigned m = tl * BM + (unsigned)row;
         raw.y[i] = ld4(g.A + row_off(m, g.lda) + kk);
-        if (MODE == MODE_DYDENSE) raw.z[DY ? i : 0] = ld4(g.dZ + row_off(m, g.ldz) + kk);
-        if (POOLED) {
+        if (MODE == MODE_DYDENSE) raw.z[DY && !ONEZ ? i : 0] = ld4(g.dZ + row_off(m, g.ldz) + kk);
+        if (POOLED && (!ONEZ || i == 0)) {
             const unsigned grp = m / (unsigned)(PKP > 0 ? PKP : 1);
-            raw.z[DY ? i : 0] = ld4(g.dZp + row_off(grp, g.ldo) + kk);
-            raw.a[POOLED ? i : 0] = ld4i(g.arg + row_off(grp, g.ldo) + kk);
+            raw.z[DY && !ONEZ ? i : 0] = ld4(g.dZp + row_off(grp, g.ldo) + kk);
+            raw.a[POOLED && !ONEZ ? i : 0] = ld4i(g.arg + row_off(grp, g.ldo) + kk);
         }
     };
     auto fetch = [&](int64_t tile_, int c) {
@@ -988,12 +994,20 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
         const int idx = (NT * (i + 1) > QI) ? min(t + NT * i, QI - 1) : t + NT * i;
         const int row = idx >> 4, q = idx & 15;
         const int k = c * KC + 4 * q;
+        // The transform of an item must not rise above the barrier into the chunk that REQUESTED it: it is register-only work, and
+        // hipcc put the max-pool's select directly behind the loads (saving four registers) -- with an s_waitcnt for requests a
+        // few instructions old, a memory latency per chunk (in-kernel stamps of the K = 256 data gradients: "fetch" 23 % of the
+        // loop).  A volatile use of the item's registers here keeps it on this side.
+        // (the data gradients only: on the forward kernels the same pin is neutral to 16 % slower -- 96 -> 128 pooled, two workgroups per CU)
+        if (DY) asm volatile("" : "+v"(raw.y[i].x), "+v"(raw.y[i].y), "+v"(raw.y[i].z), "+v"(raw.y[i].w));
+        if (DY) asm volatile("" : "+v"(raw.z[DY && !ONEZ ? i : 0].x), "+v"(raw.z[DY && !ONEZ ? i : 0].y), "+v"(raw.z[DY && !ONEZ ? i : 0].z), "+v"(raw.z[DY && !ONEZ ? i : 0].w));
+        if (POOLED) asm volatile("" : "+v"(raw.a[POOLED && !ONEZ ? i : 0].x), "+v"(raw.a[POOLED && !ONEZ ? i : 0].y), "+v"(raw.a[POOLED && !ONEZ ? i : 0].z), "+v"(raw.a[POOLED && !ONEZ ? i : 0].w));
         const float4 x = raw.y[i];
         float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
         if (DY) {
-            dz = raw.z[DY ? i : 0];
+            dz = raw.z[DY && !ONEZ ? i : 0];
             if (POOLED) {
-                const int4 a = raw.a[POOLED ? i : 0];
+                const int4 a = raw.a[POOLED && !ONEZ ? i : 0];
                 const int kk = (int)((tl * BM + (unsigned)row) % (unsigned)(PKP > 0 ? PKP : 1));
                 dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f; dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
             }
@@ -1100,8 +1114,8 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             asm volatile("" : "+v"(raw.y[i].x), "+v"(raw.y[i].y), "+v"(raw.y[i].z), "+v"(raw.y[i].w));
-            if (DY) asm volatile("" : "+v"(raw.z[DY ? i : 0].x), "+v"(raw.z[DY ? i : 0].y), "+v"(raw.z[DY ? i : 0].z), "+v"(raw.z[DY ? i : 0].w));
-            if (POOLED) asm volatile("" : "+v"(raw.a[POOLED ? i : 0].x), "+v"(raw.a[POOLED ? i : 0].y), "+v"(raw.a[POOLED ? i : 0].z), "+v"(raw.a[POOLED ? i : 0].w));
+            if (DY && (!ONEZ || i == 0)) asm volatile("" : "+v"(raw.z[DY && !ONEZ ? i : 0].x), "+v"(raw.z[DY && !ONEZ ? i : 0].y), "+v"(raw.z[DY && !ONEZ ? i : 0].z), "+v"(raw.z[DY && !ONEZ ? i : 0].w));
+            if (POOLED && (!ONEZ || i == 0)) asm volatile("" : "+v"(raw.a[POOLED && !ONEZ ? i : 0].x), "+v"(raw.a[POOLED && !ONEZ ? i : 0].y), "+v"(raw.a[POOLED && !ONEZ ? i : 0].z), "+v"(raw.a[POOLED && !ONEZ ? i : 0].w));
         }
     };
     raw_landed();                                                   // (the loop header then has nothing pending on either edge)
@@ -1122,12 +1136,29 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         const int64_t tile_next = tile_of(seq + 1);
+        // PV_EARLY (mask epilogue): the sixteen values of the previous layer's output this lane masks with are requested at the
+        // top of the tile's LAST chunk, a chunk of MFMAs ahead of the epilogue that waited for them (a memory latency per tile)
+        constexpr bool PV_EARLY = EPI == EPI_MASK && TM / KS == 1 && PN2_SPLIT_PV_EARLY;
+        float pvq[PV_EARLY ? 16 : 1];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             WSTAMP(5)
             __syncthreads();                                        // chunk c is staged in `buf`; every wave is done with buf ^ 1
             WSTAMP(0)
             const bool last = c == NCH - 1;
+            if (PV_EARLY && last) {
+                const unsigned row0 = (unsigned)tile * BM + rs * TM * 32 + 4 * lh;
+                const float *pb = g.prevY + row_off(row0, g.ldp);
+                const bool colv = NX || n < N4;                      // (no predicate around the request: a pad column re-reads column 0)
+                unsigned offp = colv ? (unsigned)n : 0u;
+                asm volatile("" : "+v"(offp));
+                if (KS == 2) offp += (unsigned)(32 * ks) * (unsigned)g.ldp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pvq[PV_EARLY ? r : 0] = pb[offp];
+                    offp += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldp;
+                }
+            }
             const int64_t t1 = last ? tile_next : tile;             // staged now (fetched one step ago)
             const int c1 = last ? 0 : c + 1;
             const bool last1 = c1 == NCH - 1;
@@ -1288,7 +1319,8 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
                     float pv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        pv[r] = (ALLC || n < N4) ? pb[offp] : 0.f;
+                        if (PV_EARLY) pv[r] = (ALLC || n < N4) ? pvq[PV_EARLY ? r : 0] : 0.f;
+                        else pv[r] = (ALLC || n < N4) ? pb[offp] : 0.f;
                         offp += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldp;
                     }
 #pragma unroll

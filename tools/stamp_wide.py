@@ -65,3 +65,29 @@ for P, K, N in [(262144, 196, 256), (131072, 128, 256), (262144, 128, 196), (131
     dump()
     if os.environ.get("PN2_RING") != "1":
         dump_abs()
+
+# the data gradients on the same kernel (split_nt_kernel, EPI_MASK): dense dZ, or the max-pool's sparse dZp / arg (groups of Kp rows)
+if os.environ.get("PN2_RING") != "1":
+    for P, Cl, Cp, Kp in [(262144, 256, 196, 128), (131072, 256, 128, 64), (262144, 196, 128, 0), (131072, 128, 128, 0)]:
+        Y = torch.zeros(P, r4(Cl), device=dev); Y[:, :Cl] = rnd(P, Cl)
+        Yp = torch.zeros(P, r4(Cp), device=dev); Yp[:, :Cp] = rnd(P, Cp)
+        coef, affp = affine(Cl), affine(Cp)
+        Wt = rnd(Cl, Cp)
+        if Kp:
+            G = P // Kp
+            dOut = torch.zeros(G, r4(Cl), device=dev); dOut[:, :Cl] = rnd(G, Cl)
+            arg = torch.randint(0, Kp, (G, r4(Cl)), device=dev, dtype=torch.int32, generator=g)
+            dz = (None, 0, p(dOut), r4(Cl), p(arg), Kp)
+        else:
+            dZ = torch.zeros(P, r4(Cl), device=dev); dZ[:, :Cl] = rnd(P, Cl)
+            dz = (p(dZ), r4(Cl), None, 0, None, 0)
+        dX = torch.empty(P, r4(Cp), device=dev)
+        red = torch.zeros(8 * 2 * Cp, device=dev, dtype=torch.float64)
+        for _ in range(5):
+            assert lib.pn2_conv1x1_dgrad(*dz, p(Y), r4(Cl), p(coef), p(Wt), Cp, p(Yp), r4(Cp), p(affp), p(dX), r4(Cp), p(red), P, Cl, Cp,
+                                         None, None, st) == 0
+        torch.cuda.synchronize()
+        print("dgrad", (P, Cl, Cp, Kp))
+        dump()
+        dump_abs()
+        del Y, Yp, dX
