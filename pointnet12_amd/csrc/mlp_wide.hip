@@ -1427,7 +1427,7 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
                 if (PKP == 0) return launch_split<((KK + 3) & ~3), NN, NCB, RS, TM, MODE_PLAIN, EPI_FWD, false, 0>(g, s);    \
             }                                                                                                            \
         }
-        if (P >= 98304) { SPLIT_FWD(128, 128, 4, 2, 1, 0) }          // (eight waves with one row block each: 64-row tiles)
+        if (P >= pn2_opt(PN2_OPT_SPLIT_MIN_ROWS_128)) { SPLIT_FWD(128, 128, 4, 2, 1, 0) }          // (eight waves with one row block each: 64-row tiles)
         SPLIT_FWD(128, 256, 8, 1, 2, 0)
         SPLIT_FWD(128, 196, 7, 1, 2, 0)
         SPLIT_FWD(196, 256, 8, 1, 2, 0)
@@ -1521,7 +1521,7 @@ int pn2_wide_dgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
             return launch_split<((KK + 3) & ~3), NN, NCB, RS, TM, MODE_DYDENSE, EPI_MASK, true, 0>(g, s);                \
         }
         // (two raw streams per row: eight waves with one row block each keep the in-flight set at 16 registers)
-        SPLIT_DGRAD(128, 128, 4, 2, 1, 98304)
+        SPLIT_DGRAD(128, 128, 4, 2, 1, pn2_opt(PN2_OPT_SPLIT_MIN_ROWS_128))
         SPLIT_DGRAD(196, 128, 4, 2, 1, 0)
 #undef SPLIT_DGRAD
     }
@@ -1953,16 +1953,23 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
         return f;
     };
 
+    WABS(wave, 0)
     if (p_begin < p_end) {
         __syncthreads();                                            // tables, zeroed images
         fetch(p_begin);
         stage(p_begin, 0);
         fetch(p_begin + BP);
         int buf = 0;
+        WABS(wave, 1)
+        WSTAMP_DECL
         for (int64_t p0 = p_begin; p0 < p_end; p0 += BP) {
+            WSTAMP(5)
             __syncthreads();                                        // chunk p0 is in `buf`; every wave is done with buf ^ 1
+            WSTAMP(0)
             stage(p0 + BP, buf ^ 1);
+            WSTAMP(1)
             fetch(p0 + 2 * BP);
+            WSTAMP(2)
             const unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * IMG_A;
 #pragma unroll
             for (int pb = 0; pb < BP / 16; ++pb) {
@@ -1978,8 +1985,11 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[j], 0, 0, 0);
                 }
             }
+            WSTAMP(3)
             buf ^= 1;
         }
+        if (wave < 8) { WSTAMP_FLUSH(wave) }
+        WABS(wave, 2)
     }
     // ---- flush: every accumulator register is 2 x 128 contiguous bytes of dW
     const int m_base = mb * 32 + 4 * lh;

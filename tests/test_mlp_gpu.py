@@ -196,6 +196,50 @@ def test_eval_mode_with_grad(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P,pool,chans", [(262144, 128, [9, 64, 96, 128]), (262144, 64, [9, 64, 64, 128]), (131072, 32, [9, 32, 32, 64]),
+                                          (131072 + 64, 0, [12, 64, 64, 96]), (262144, 0, [128, 128, 128, 64])])
+def test_bf16_split_kernels_against_the_fp32_pipe(dev, P, pool, chans):
+    """Round 5: the same stack through the fp32-pipe kernels (PN2_SPLIT=0: v_mfma_f32_32x32x2_f32, an fp32 fma chain) and through the
+    bf16x3 split kernels (split_nt / split_tn / split_bwd_res: six bf16 MFMA products of exact three-way operand splits) -- outputs,
+    every saved pre-BN activation and every gradient agree to rounding (1e-5 of the tensor's largest entry; gradients 5e-5: their
+    BatchNorm-backward sums run over up to 262 144 rows), and the split path must actually have been taken (its results differ in
+    the last bits -- bit-equal tensors would mean the option did nothing)."""
+    gen = torch.Generator().manual_seed(P + pool)
+    c_in = chans[0]
+    rows = (torch.randn(P, c_in, generator=gen) * 2 + 0.5).to(dev)
+    convs = nn.ModuleList([nn.Conv2d(a, b, 1) for a, b in zip(chans[:-1], chans[1:])]).to(dev)
+    bns = nn.ModuleList([nn.BatchNorm2d(b) for b in chans[1:]]).to(dev)
+    gw = None
+    res = {}
+    old = {k: _lib.options()[k] for k in ("PN2_SPLIT", "PN2_SPLIT_RES")}
+    try:
+        for arm, (sp, sr) in {"fp32": (0, 0), "split": (1, 2)}.items():
+            _lib.set_option("PN2_SPLIT", sp)
+            _lib.set_option("PN2_SPLIT_RES", sr)
+            for bn in bns:
+                bn.reset_running_stats()
+            x = rows.clone().requires_grad_(True)
+            out = U.shared_mlp(x, c_in, convs, bns, pool, True)
+            L = len(chans) - 1
+            acts = [y.detach().clone() for y in out.grad_fn.saved_tensors[3:3 + L]]
+            if gw is None:
+                gw = torch.randn(out.shape, generator=gen).to(dev)
+            grads = torch.autograd.grad((out * gw).sum(), [x] + list(convs.parameters()) + list(bns.parameters()))
+            res[arm] = ([out.detach().clone()] + acts, [t.clone() for t in grads])
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+    differs = False
+    for a, b in zip(res["fp32"][0], res["split"][0]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+        differs = differs or not torch.equal(a, b)
+    for a, b in zip(res["fp32"][1], res["split"][1]):
+        assert float((a - b).abs().max()) <= 5e-5 * max(float(a.abs().max()), 1e-6)
+        differs = differs or not torch.equal(a, b)
+    assert differs, "PN2_SPLIT changed nothing: the bf16-split kernels did not run on this stack"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,C,weighted,ignored", [(65536, 13, False, False), (1000, 19, True, True), (7, 5, False, True),
                                                   (300001, 50, True, False)])
 def test_nll_loss_matches_aten(dev, R, C, weighted, ignored):

@@ -1,5 +1,6 @@
 export TMPDIR=/tmp
-O=gpurun_out/r5aj
+O=gpurun_out/r5am
 mkdir -p $O
 PN2_LIB_PATH=pointnet12_amd/libpn2_hip_stamp.so timeout 300 python tools/stamp_wide.py > $O/stamp.txt 2>&1
-grep -A11 "^dgrad" $O/stamp.txt | cut -c1-220
+grep -A10 "^wgrad" $O/stamp.txt | cut -c1-220
+tail -5 $O/stamp.txt | cut -c1-300

@@ -91,3 +91,26 @@ if os.environ.get("PN2_RING") != "1":
         dump()
         dump_abs()
         del Y, Yp, dX
+
+# the full-tile weight gradients (split_tn_kernel)
+if os.environ.get("PN2_RING") != "1":
+    for P, Cl, Cp, Kp in [(262144, 256, 196, 128), (131072, 256, 128, 64), (262144, 196, 128, 0)]:
+        Y = torch.zeros(P, r4(Cl), device=dev); Y[:, :Cl] = rnd(P, Cl)
+        X = torch.zeros(P, r4(Cp), device=dev); X[:, :Cp] = rnd(P, Cp)
+        coef, affx = affine(Cl), affine(Cp)
+        if Kp:
+            G = P // Kp
+            dOut = torch.zeros(G, r4(Cl), device=dev); dOut[:, :Cl] = rnd(G, Cl)
+            arg = torch.randint(0, Kp, (G, r4(Cl)), device=dev, dtype=torch.int32, generator=g)
+            dz = (None, 0, p(dOut), r4(Cl), p(arg), Kp)
+        else:
+            dZ = torch.zeros(P, r4(Cl), device=dev); dZ[:, :Cl] = rnd(P, Cl)
+            dz = (p(dZ), r4(Cl), None, 0, None, 0)
+        dW = torch.zeros(Cl, Cp, device=dev)
+        for _ in range(5):
+            assert lib.pn2_conv1x1_wgrad(*dz, p(Y), r4(Cl), p(coef), p(X), r4(Cp), p(affx), p(dW), Cp, None, P, Cl, Cp, None, st) == 0
+        torch.cuda.synchronize()
+        print("wgrad", (P, Cl, Cp, Kp))
+        dump()
+        dump_abs()
+        del Y, X
