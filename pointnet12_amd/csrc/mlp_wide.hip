@@ -906,6 +906,9 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
 #ifndef PN2_SPLIT_PV_EARLY
 #define PN2_SPLIT_PV_EARLY 1
 #endif
+#ifndef PN2_SPLIT_TN_WOVEN
+#define PN2_SPLIT_TN_WOVEN 1
+#endif
     const bool late_stager = PN2_SPLIT_ORDER == 1 && NW >= 8 && wave >= NW / 2;                             // (uniform)
     // N not a multiple of 32 (196): only the last column block is ragged -- the others store without a column predicate (64
     // predicated stores per tile are 64 branches: the epilogue of 128 -> 196 was 31 % of its loop)
@@ -1871,29 +1874,6 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
     constexpr int ITA = (BP * QA + NT - 1) / NT, ITB = (BP * QB + NT - 1) / NT;
     struct Raw { float4 y[ITA]; float4 z[POOLED ? 1 : ITA]; int4 a[1]; float4 x[ITB]; };
     Raw raw;
-    auto a_item = [&](int i, int &row, int &q) { const int idx = t + NT * i; row = idx / QA; q = idx - row * QA; return idx < BP * QA; };
-    auto b_item = [&](int i, int &row, int &q) { const int idx = t + NT * i; row = idx / QB; q = idx - row * QB; return idx < BP * QB; };
-    auto fetch = [&](int64_t p0) {
-        const int64_t pb = p0 < p_end ? p0 : p_begin;              // past the end: re-read valid rows (zeroed when staged)
-#pragma unroll
-        for (int i = 0; i < ITA; ++i) {
-            int row, q;
-            if (!a_item(i, row, q)) continue;
-            raw.y[i] = ld4(g.Y + (size_t)(pb + row) * (unsigned)g.ldy + 4 * q);
-            if (!POOLED) raw.z[POOLED ? 0 : i] = ld4(g.dZ + (size_t)(pb + row) * (unsigned)g.ldy + 4 * q);
-        }
-        if (POOLED) {
-            const size_t go = (size_t)(pb / (PKP > 0 ? PKP : 1)) * (unsigned)g.ldo + 4u * (unsigned)(t % QA);
-            raw.z[0] = ld4(g.dZp + go);
-            raw.a[0] = ld4i(g.arg + go);
-        }
-#pragma unroll
-        for (int i = 0; i < ITB; ++i) {
-            int row, q;
-            if (!b_item(i, row, q)) continue;
-            raw.x[i] = ld4(g.X + (size_t)(pb + row) * (unsigned)g.ldx + 4 * q);
-        }
-    };
     // a float4 of channels 4 q .. 4 q + 3 of row `row`: three 8-byte stores (4 bf16 each) into the piece images
     auto store_split = [&](unsigned char *img, int img_bytes, int row, int q, float4 v) {
         unsigned h0, m0, l0, h1, m1, l1;
@@ -1905,36 +1885,68 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
         *reinterpret_cast<uint2 *>(img + o + img_bytes) = make_uint2(m0, m1);
         *reinterpret_cast<uint2 *>(img + o + 2 * img_bytes) = make_uint2(l0, l1);
     };
+    // ---- staging item by item, branch-free (a thread without an i-th item repeats its last: the same value to the same place; no
+    // lane-dependent predicate around a request).  In the loop one item of the next chunk -- transform, split, image writes, then
+    // its request two chunks ahead -- follows every tile's MFMAs (split_nt_kernel's order: the matrix pipe works through the
+    // tile while the wave stages).
+    auto a_it = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QA) ? min(t + NT * i, BP * QA - 1) : t + NT * i; row = idx / QA; q = idx - row * QA; };
+    auto b_it = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QB) ? min(t + NT * i, BP * QB - 1) : t + NT * i; row = idx / QB; q = idx - row * QB; };
+    auto fetch_a = [&](int i, int64_t p0) {
+        const int64_t pb = p0 < p_end ? p0 : p_begin;
+        int row, q;
+        a_it(i, row, q);
+        raw.y[i] = ld4(g.Y + (size_t)(pb + row) * (unsigned)g.ldy + 4 * q);
+        if (!POOLED) raw.z[POOLED ? 0 : i] = ld4(g.dZ + (size_t)(pb + row) * (unsigned)g.ldy + 4 * q);
+        if (POOLED && i == ITA - 1) {                               // (one quad per chunk: behind the LAST item that used the previous one)
+            const size_t go = (size_t)(pb / (PKP > 0 ? PKP : 1)) * (unsigned)g.ldo + 4u * (unsigned)(t % QA);
+            raw.z[0] = ld4(g.dZp + go);
+            raw.a[0] = ld4i(g.arg + go);
+        }
+    };
+    auto fetch_b = [&](int i, int64_t p0) {
+        const int64_t pb = p0 < p_end ? p0 : p_begin;
+        int row, q;
+        b_it(i, row, q);
+        raw.x[i] = ld4(g.X + (size_t)(pb + row) * (unsigned)g.ldx + 4 * q);
+    };
+    auto stage_a = [&](int i, int64_t p0, int buf) {
+        unsigned char *ia = lds_b + buf * BUF;
+        int row, q;
+        a_it(i, row, q);
+        const DyParams dp = dy_params_tab(ctab, MB * 32, 4 * q, true);
+        float4 dz = raw.z[POOLED ? 0 : i];
+        if (POOLED) {
+            const int4 a = raw.a[0];
+            const int kk = (int)((unsigned)p0 & (unsigned)(PKP - 1)) + row;
+            dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f; dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
+        }
+        float4 v = dy_from(dz, raw.y[i], dp);
+        if (!(p0 < p_end)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        store_split(ia, IMG_A, row, q, v);
+    };
+    auto stage_b = [&](int i, int64_t p0, int buf) {
+        unsigned char *ib = lds_b + buf * BUF + 3 * IMG_A;
+        int row, q;
+        b_it(i, row, q);
+        const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]), sc = *reinterpret_cast<const float4 *>(&xtab[NB * 32 + 4 * q]);
+        const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * NB * 32 + 4 * q]);
+        float4 x = raw.x[i];
+        x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f); x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+        x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f); x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+        if (!(p0 < p_end)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        store_split(ib, IMG_B, row, q, x);
+    };
+    auto fetch = [&](int64_t p0) {
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) fetch_a(i, p0);
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) fetch_b(i, p0);
+    };
     auto stage = [&](int64_t p0, int buf) {
-        const bool live = p0 < p_end;
-        unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * IMG_A;
 #pragma unroll
-        for (int i = 0; i < ITA; ++i) {
-            int row, q;
-            if (!a_item(i, row, q)) continue;
-            const DyParams dp = dy_params_tab(ctab, MB * 32, 4 * q, true);
-            float4 dz = raw.z[POOLED ? 0 : i];
-            if (POOLED) {
-                const int4 a = raw.a[0];
-                const int kk = (int)((unsigned)p0 & (unsigned)(PKP - 1)) + row;       // the chunk lies inside one group
-                dz.x = a.x == kk ? dz.x : 0.f; dz.y = a.y == kk ? dz.y : 0.f; dz.z = a.z == kk ? dz.z : 0.f; dz.w = a.w == kk ? dz.w : 0.f;
-            }
-            float4 v = dy_from(dz, raw.y[i], dp);
-            if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            store_split(ia, IMG_A, row, q, v);
-        }
+        for (int i = 0; i < ITA; ++i) stage_a(i, p0, buf);
 #pragma unroll
-        for (int i = 0; i < ITB; ++i) {
-            int row, q;
-            if (!b_item(i, row, q)) continue;
-            const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]), sc = *reinterpret_cast<const float4 *>(&xtab[NB * 32 + 4 * q]);
-            const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * NB * 32 + 4 * q]);
-            float4 x = raw.x[i];
-            x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f); x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
-            x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f); x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
-            if (!live) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            store_split(ib, IMG_B, row, q, x);
-        }
+        for (int i = 0; i < ITB; ++i) stage_b(i, p0, buf);
     };
     // transposed fragment: channels cblk * 32 + l31, rows 16 pb + 8 lh + 0 .. 7 of the chunk, of one piece image
     const int g16 = lane >> 4, j16 = lane & 15, tq = j16 >> 2, tp = j16 & 3;
@@ -1966,10 +1978,12 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
             WSTAMP(5)
             __syncthreads();                                        // chunk p0 is in `buf`; every wave is done with buf ^ 1
             WSTAMP(0)
-            stage(p0 + BP, buf ^ 1);
-            WSTAMP(1)
-            fetch(p0 + 2 * BP);
-            WSTAMP(2)
+            if (!PN2_SPLIT_TN_WOVEN) {
+                stage(p0 + BP, buf ^ 1);
+                WSTAMP(1)
+                fetch(p0 + 2 * BP);
+                WSTAMP(2)
+            }
             const unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * IMG_A;
 #pragma unroll
             for (int pb = 0; pb < BP / 16; ++pb) {
@@ -1983,6 +1997,17 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bh.v, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bm.v, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[j], 0, 0, 0);
+                    if (PN2_SPLIT_TN_WOVEN) {
+                        constexpr int NIT = ITA + ITB, STEPS = (BP / 16) * TNW;
+                        const int step = pb * TNW + j;
+#pragma unroll
+                        for (int i = 0; i < NIT; ++i)
+                            if ((i * STEPS) / NIT == step) {
+                                if (i < ITA) { stage_a(i, p0 + BP, buf ^ 1); fetch_a(i, p0 + 2 * BP); }
+                                else { stage_b(i - ITA, p0 + BP, buf ^ 1); fetch_b(i - ITA, p0 + 2 * BP); }
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             WSTAMP(3)
