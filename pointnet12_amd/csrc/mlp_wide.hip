@@ -2016,8 +2016,20 @@ __global__ __launch_bounds__(64 * ((MM + 31) / 32) * (((NN + 31) / 32) / TNW)) v
         if (wave < 8) { WSTAMP_FLUSH(wave) }
         WABS(wave, 2)
     }
-    // ---- flush: every accumulator register is 2 x 128 contiguous bytes of dW
+    // ---- flush: every accumulator register is 2 x 128 contiguous bytes of dW -- atomics, or (caller scratch: pn2_conv1x1_wgrad_ws)
+    // the workgroup's slab as plain stores for wgrad_reduce_kernel to add up (in-kernel stamps: the loop is 180 us of this
+    // kernel's 260 at 256 x 196 -- the rest is 256 workgroups x 50 176 device-scope atomics)
     const int m_base = mb * 32 + 4 * lh;
+    if (g.ws != nullptr) {
+        float *slab = g.ws + (size_t)blockIdx.x * (MB * 32) * (NB * 32);
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) {
+            const int n = (nb0 + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(m_base + (r & 3) + 8 * (r >> 2)) * (NB * 32) + n] = acc[j][r];
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
         const int n = (nb0 + j) * 32 + l31;
@@ -2035,7 +2047,7 @@ int launch_split_tn(WgradArgs g, hipStream_t s) {
     constexpr int PA = (MB * 32 + 127) / 128, PB = (NB * 32 + 127) / 128, BUF = 3 * (PA + PB) * BP * 256;
     constexpr size_t lds = 2 * (size_t)BUF + sizeof(float) * (4 * MB * 32 + 3 * NB * 32);
     static_assert(lds <= 160 * 1024, "LDS");
-    if (g.dbias != nullptr || g.ws != nullptr || g.P % BP != 0) return PN2_EUNSUPPORTED;
+    if (g.dbias != nullptr || g.P % BP != 0) return PN2_EUNSUPPORTED;
     auto kern = split_tn_kernel<MM, NN, TNW, DYM, PKP, BP>;
     static Pn2PerDevice raised;
     if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
@@ -2045,6 +2057,14 @@ int launch_split_tn(WgradArgs g, hipStream_t s) {
     g.rows_per_wg = rows;
     wgs = pn2_cdiv(g.P, rows);
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * NW), lds, s, g);
+    if (g.ws != nullptr) {                                          // (second phase as launch_wgrad_full's)
+        const int rows_pad = MB * 32, ldn = NB * 32;
+        const unsigned gx = (unsigned)pn2_cdiv((int64_t)rows_pad * (ldn / 4), 256);
+        unsigned gy = (unsigned)(4 * pn2_num_cus() / gx);
+        if (gy < 1) gy = 1;
+        if (gy > (unsigned)wgs) gy = (unsigned)wgs;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, s, g.ws, (int)wgs, rows_pad, ldn, g.M, g.N, g.dW, g.lddw);
+    }
     return pn2_launch_status();
 }
 
@@ -2090,7 +2110,7 @@ int pn2_wide_wgrad(const float *dZ, int ldz, const float *dZp, int ldo, const in
     WgradArgs g{};
     g.Y = Y; g.ldy = ldy; g.dZ = dZ; g.ldz = ldz; g.dZp = dZp; g.arg = arg; g.ldo = ldo; g.coef = coef; g.X = X; g.ldx = ldx;
     g.x_aff = x_affine; g.dW = dW; g.lddw = lddw; g.dbias = dbias; g.P = P; g.M = M; g.N = N; g.lc = lc; g.ws = workspace;
-    if (pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_WGRAD) && dbias == nullptr && workspace == nullptr && P % 16 == 0) {
+    if (pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_WGRAD) && dbias == nullptr && P % 16 == 0) {
 #define SPLIT_WGRAD(MM, NN, TNW, PKP, BP)                                                                                \
         if (M == MM && N == NN && P % BP == 0 && (PKP == 0 ? dZ != nullptr : (dZ == nullptr && Kpool == PKP)))          \
             return launch_split_tn<MM, NN, TNW, PKP == 0 ? MODE_DYDENSE : MODE_DYPOOLED, PKP, BP>(g, s);
