@@ -898,9 +898,9 @@ int dispatch_bwd_res(int Kpool, bool masked, int Co, int Ci, ResDy dy, const flo
         if (Kpool == 0 && masked) {
             if (all) { PN2_SPLIT_RES_CASE(32, 32, false, true) }
             PN2_SPLIT_RES_CASE(64, 64, false, true) PN2_SPLIT_RES_CASE(96, 64, false, true)
-            if (tiles >= 4096) { PN2_SPLIT_RES_CASE(128, 128, false, true) }
+            if (tiles >= pn2_opt(PN2_OPT_SPLIT_RES_MIN_TILES_128)) { PN2_SPLIT_RES_CASE(128, 128, false, true) }
         } else if (Kpool == 0) {
-            if (tiles >= 4096) { PN2_SPLIT_RES_CASE(128, 128, false, false) }
+            if (tiles >= pn2_opt(PN2_OPT_SPLIT_RES_MIN_TILES_128)) { PN2_SPLIT_RES_CASE(128, 128, false, false) }
         } else if (masked && Kpool % 32 == 0) {
             if (all) { PN2_SPLIT_RES_CASE(64, 32, true, true) }
             PN2_SPLIT_RES_CASE(128, 64, true, true) PN2_SPLIT_RES_CASE(128, 96, true, true)
@@ -1253,8 +1253,9 @@ extern "C" int pn2_bwd_res_supported(int64_t P, int C_out, int C_in, int Kpool, 
     if (P * (int64_t)std::max(C_out, C_in) >= (1LL << 32)) return 0;     // 32-bit element offsets inside the fused kernel
     const int64_t tiles = P / RES_BM;
     const auto is = [&](int co, int ci) { return C_out == co && C_in == ci; };
-    if (Kpool == 0 && masked) return is(32, 32) || is(64, 64) || is(96, 64) || (tiles >= 4096 && is(128, 128));
-    if (Kpool == 0) return tiles >= 4096 && is(128, 128);
+    const int64_t min128 = (pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_RES)) ? std::min<int64_t>(4096, pn2_opt(PN2_OPT_SPLIT_RES_MIN_TILES_128)) : 4096;
+    if (Kpool == 0 && masked) return is(32, 32) || is(64, 64) || is(96, 64) || (tiles >= min128 && is(128, 128));
+    if (Kpool == 0) return tiles >= min128 && is(128, 128);
     if (masked && Kpool % 64 == 0) return is(128, 64) || is(128, 96);
     if (masked && Kpool == 32) return is(64, 32) || is(128, 64);
     return 0;

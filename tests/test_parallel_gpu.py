@@ -187,8 +187,12 @@ def test_bench_self_launch_one_rank_through_torchrun(dev):
     env = dict(os.environ, PN2_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
+    import socket
+    with socket.socket() as sk:                   # a free port of this box (a fixed one collided with a lingering rendezvous twice
+        sk.bind(("127.0.0.1", 0))                 # in the round-5 evidence runs, where the suite follows two dozen bench launches)
+        port = sk.getsockname()[1]
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                        "--master-addr", "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "1", "--steps", "3", "--warmup", "2", "--workload", "ssg", "--no-cpu-baseline", "--no-roofline"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]

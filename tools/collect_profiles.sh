@@ -83,7 +83,7 @@ if [ -z "$QUICK" ]; then
   python3 tools/bench_infer.py > $O/infer_single_cloud.jsonl 2> $O/infer.err
   python3 tools/bench_fps.py > $O/fps_probe.txt 2> $O/fps.err
   python3 tools/bench_ball.py > $O/ball_query_cfg5.txt 2> $O/ball.err
-  python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/tests_gpu.txt
+  python3 -m pytest tests -m gpu -q > $O/tests_gpu_full.txt 2>&1; (grep "^E  " $O/tests_gpu_full.txt | head -20; tail -5 $O/tests_gpu_full.txt) > $O/tests_gpu.txt
   cp gpurun_out/parity_stages.json $O/parity_stages.json 2>/dev/null
   cp gpurun_out/parity_fullsize.json $O/parity_fullsize.json 2>/dev/null
 fi
