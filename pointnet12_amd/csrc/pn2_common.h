@@ -65,7 +65,7 @@ static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
     X(SPLIT_K256, 1) /* ... the pooled data gradients with C_out = 256 (contraction split over wave pairs) */ \
     X(SPLIT_NARROW, 1) /* ... also on the narrow sa1 forward layers the weight-resident kernels served */ \
     X(SPLIT_RES, 1) /* ... and the fused data + weight gradient of the narrow long layers (split_bwd_res_kernel) */ \
-    X(SPLIT_RES_MIN_TILES_128, 4096) /* ... its 128 x 128 pair from this many 64-row tiles on (below: the streamed pair kernel) */ \
+    X(SPLIT_RES_MIN_TILES_128, 1024) /* ... its 128 x 128 pair from this many 64-row tiles on (below: the streamed pair kernel) */ \
     X(SPLIT_MIN_ROWS_128, 98304) /* ... 128 -> 128 forward / data gradient from this many rows on (below: the streamed fp32 kernels) */ \
     X(RING, 0) /* forward: the LDS-DMA ring form of the register-stationary kernel (measured equal: DESIGN.md section 3) */ \
     X(WIDE_POOL, 1) /* pooling extrema in the register-stationary forward's epilogue */ \
