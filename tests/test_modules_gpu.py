@@ -339,9 +339,12 @@ def test_prefetched_geometry_graph_matches_eager(dev):
             losses.append(float(step()))
         seqs.append((losses, bucket.flat.clone()))
     (la, ga), (lb, gb), (lc, gc) = seqs
-    assert np.allclose(la, lb, rtol=0, atol=2e-5), (la, lb)
+    # (a wrong start draw or a stale tape samples other points and moves the loss by 1e-2 and more; the three schedules differ in
+    # the ORDER of the statistics atomics, which now and then flips a pooled arg-max and moves the loss of these small clouds in
+    # the fifth digit -- one full-suite run in five of round 5 tripped a 2e-5 bound here and passed when repeated)
+    assert np.allclose(la, lb, rtol=0, atol=2e-4), (la, lb)
     assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
-    assert np.allclose(la, lc, rtol=0, atol=2e-5), (la, lc)
+    assert np.allclose(la, lc, rtol=0, atol=2e-4), (la, lc)
     assert abs(float(ga.norm()) - float(gc.norm())) <= 5e-3 * float(ga.norm())
 
 
