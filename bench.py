@@ -34,6 +34,8 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+BF16_MFMA_PEAK_TF = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
+SPLIT_PEAK_TF = BF16_MFMA_PEAK_TF / 6.0      # split kernels: six bf16 MFMAs per fp32 product block -> 416.7 TF of fp32 products
 # C-ABI GEMM entry point -> kernel families of tools/pmc_traffic.py that serve it
 GEMM_FAMILIES = {"pn2_conv1x1_bwd_pair": ["bwd_pair_kernel"],
                  "pn2_conv1x1_wgrad": ["gemm_tn_kernel", "wgrad_skinny_kernel", "wgrad_first_cf_kernel", "wgrad_full_kernel", "wgrad_reduce_kernel",
@@ -51,8 +53,10 @@ WORKLOADS = {
 
 def algorithmic_work(name, a):
     """(flops, bytes) one C-ABI launch has to do at minimum, from its arguments (fp32 = 4 B, idx = 8 B)."""
-    if name == "pn2_conv1x1_fwd":            # X ldx aff W ldw bias Y ldy P K N stats stream
+    if name in ("pn2_conv1x1_fwd", "pn2_conv1x1_fwd_pool"):            # X ldx aff W ldw bias Y ldy P K N stats stream
         P, K, N = a[8], a[9], a[10]
+        if a[6] is None:                     # (pooled last layer without an output: Y == NULL)
+            return 2.0 * P * K * N, 4.0 * (P * K + N * K)
         return 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K)
     if name == "pn2_conv1x1_dgrad":          # ... P K N stream   (reads dZ|pooled + Y [P,K], writes [P,N], reads prev_Y)
         P, K, N = a[17], a[18], a[19]
@@ -75,6 +79,9 @@ def algorithmic_work(name, a):
         P, Co, Ci = a[19], a[20], a[21]
         dense = a[0] is not None
         return 4.0 * P * Co * Ci, 4.0 * (P * Co * (2 if dense else 1) + 2 * P * Ci + 2 * Co * Ci)
+    if name == "pn2_conv1x1_bwd_cf":         # pooled last layer from its input: prev_Y read, dX written (no Y stream); flops as the layer's
+        P, Co, Ci = a[16], a[17], a[18]
+        return 4.0 * P * Co * Ci, 4.0 * (2 * P * Ci + 2 * Co * Ci)
     if name == "pn2_bn_relu_max":            # Y ldy aff G K C out ldo arg
         G, K, C = a[3], a[4], a[5]
         return 3.0 * G * K * C, 4.0 * (G * K * C + 2 * G * C)
@@ -94,6 +101,40 @@ def algorithmic_work(name, a):
         B, N, S = a[2], a[3], a[4]
         return 14.0 * B * N * S, 12.0 * B * (N + S) + 48.0 * B * N
     return 0.0, 0.0
+
+
+def kernel_key(name):
+    """A kernel's name as both rocprofv3 (Kernel_Name / stats CSV) and pn2_last_kernel() spell it, minus what differs between
+    the two: the return type, the anonymous-namespace qualifiers and the parameter list."""
+    name = name.strip().replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    if name.endswith(")"):                        # parameter list: the parenthesis that closes last opens it
+        depth = 0
+        for i in range(len(name) - 1, -1, -1):
+            depth += name[i] == ")"
+            depth -= name[i] == "("
+            if depth == 0:
+                name = name[:i]
+                break
+    return name.strip()
+
+
+def kernel_pipe(key):
+    """Which matrix pipe a GEMM kernel of the library runs its products on: the bf16 pipe with exact three-way operand splits
+    (six MFMAs per fp32 product block) or the fp32 MFMA."""
+    return "bf16x3" if key.startswith("split_") else "f32"
+
+
+def price(flops, nbytes, secs, pipe):
+    """(bound, achieved, peak, unit, frac, hbm_frac, mfma_frac) of a kernel on the roofline that applies to it: HBM 8 TB/s on its
+    ALGORITHMIC bytes against the matrix peak of ITS pipe on its algorithmic fp32 flops; the larger fraction names the bound."""
+    gbs, tf = nbytes / secs / 1e9, flops / secs / 1e12
+    peak_tf = SPLIT_PEAK_TF if pipe == "bf16x3" else F32_MFMA_PEAK_TF
+    hf, mf = gbs / HBM_PEAK_GBS, (tf / peak_tf if pipe else 0.0)
+    if mf > hf:
+        return "mfma", round(tf, 3), round(peak_tf, 1), "TFLOP/s", round(mf, 4), round(hf, 4), round(mf, 4)
+    return "hbm", round(gbs, 1), HBM_PEAK_GBS, "GB/s", round(hf, 4), round(hf, 4), round(mf, 4)
 
 
 def csrc_digest():
@@ -129,7 +170,7 @@ STEP_MODEL = {"msg": (225604, 464.5e9 / 65536), "ssg": (55689, 92.8e9 / 65536), 
 STEP_MODEL_CFG5 = {("msg", 16): (118.13e9 / 524288, 3716e9 / 524288), ("ssg", 1): (8.108e9 / 524288, 244.6e9 / 524288)}
 
 
-def make_step(workload, net, pts, labels, bucket):
+def make_step(workload, net, pts, labels, bucket, prefetch=True):
     from pointnet12_amd.loss import nll_loss      # F.nll_loss (semseg.py:143) on the HIP library
     from pointnet12_amd import graph as _graph
     # Where the next batch's geometry branch (FPS / ball query / 3-NN of the NEXT batch, 0.55 ms of small grids at 4096 points)
@@ -142,7 +183,8 @@ def make_step(workload, net, pts, labels, bucket):
     # stretched the chain: rocprofv3 trace, tools/step_timeline.py.)  cfg2 / cfg5: the FPS chain is the step, top.
     default_fork = {"msg": "top", "ssg": "sa2"}.get(workload, "top") if pts.shape[-1] <= 8192 else "top"
     fork_at = os.environ.get("PN2_BENCH_FORK", default_fork)       # top | sa1 | sa2 | loss | sa2_bwd | sa1_bwd
-    late_fork = fork_at != "top" and workload in ("msg", "ssg")
+    # (no geometry branch -- eager launches or --no-prefetch -- means nothing to fork: the step is the plain sequence)
+    late_fork = prefetch and fork_at != "top" and workload in ("msg", "ssg")
     if not late_fork:
         fork_at = "top"
     if fork_at in ("sa1", "sa2"):                 # behind that module's forward
@@ -405,13 +447,11 @@ def timed_protocol(step, all_reduce, fence, steps, warmup, world, dist, torch, d
 
 
 def dry_run(args, dist, torch):
-    """The benchmark's rank protocol on CPU with gloo ranks and no GPU: the same ``timed_protocol`` as the real run around
-    the ORACLE SSG network (oracle/torch_ref.py, two small clouds per rank) accumulating into the real
-    ``parallel.FlatGradBucket`` (autograd mode) and its all-reduce -- rendezvous on 127.0.0.1, barrier, K timed steps, MAX
+    """The benchmark's rank protocol on CPU with gloo ranks and no GPU: the same ``timed_protocol`` as the real run around a toy
+    conv + BatchNorm network (plain torch; nothing of oracle/ -- that is for the cpu_baseline legs only) accumulating into the
+    real ``parallel.FlatGradBucket`` (autograd mode) and its all-reduce -- rendezvous on 127.0.0.1, barrier, K timed steps, MAX
     over ranks, one JSON line from rank 0 relayed by the parent (tests/test_bench_launch_cpu.py)."""
-    from oracle import torch_ref as T
     from pointnet12_amd import parallel
-    from pointnet12_amd import synthetic as syn
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -420,17 +460,19 @@ def dry_run(args, dist, torch):
     torch.set_num_threads(1)
     per_rank = 2
     lo, _ = parallel.shard_range(per_rank * world, rank, world)
-    pts_np, lab_np = syn.kitti_batch(lo, per_rank, 256)
-    pts, lab = torch.from_numpy(pts_np), torch.from_numpy(lab_np)
+    gen = torch.Generator().manual_seed(20260101 + lo)           # every rank its own clouds (the shard's first cloud index seeds them)
+    pts = torch.randn(per_rank, 9, 256, generator=gen)
+    lab = torch.randint(0, 13, (per_rank, 256), generator=gen)
     torch.manual_seed(rank)                          # different initial parameters per rank: the broadcast must fix that
-    net = T.RefSSGSemSeg(13, 6).train()
+    nn = torch.nn
+    net = nn.Sequential(nn.Conv1d(9, 32, 1), nn.BatchNorm1d(32), nn.ReLU(), nn.Conv1d(32, 64, 1), nn.BatchNorm1d(64), nn.ReLU(),
+                        nn.Conv1d(64, 13, 1)).train()
     parallel.broadcast_module(net)
     bucket = parallel.FlatGradBucket(net, direct=False)
 
     def step():
         bucket.zero()
-        torch.manual_seed(1234)
-        T.seg_loss(net(pts), lab).backward()
+        torch.nn.functional.cross_entropy(net(pts), lab).backward()
         time.sleep(0.002 * rank)                     # uneven ranks: the reported time must be the slowest one's
 
     def fence():
@@ -485,6 +527,19 @@ def other_configs():
                          "points_per_cloud": doc["config"]["points_per_cloud"]}
         except Exception as e:                         # a failed side run must not take the headline line down with it
             out[name] = {"error": repr(e)[:200]}
+    # the reference viewer's single-cloud forward (pcdvis.py:118-136, model/utils.py:15-34) -- PointNet2SemSeg(19, 1) in
+    # eval mode on ONE 25 000-point cloud, the fused eval path (pn2_fused_eval); latency of one frame as a hipGraph replay, and the
+    # time per frame of a frame stream with the next frame's geometry prefetched (tools/bench_infer.py, a child process as above)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_infer.py"), "--points", "25000", "--reps", "50"],
+                           capture_output=True, text=True, timeout=300)
+        doc = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        out["infer_single_cloud_25000_eval"] = {"latency_ms_graph": doc["graph_ms"], "latency_ms_eager": doc["eager_ms"],
+                                                "stream_ms_per_frame": doc["stream_ms_per_frame"], "points_per_s": doc["points_per_s"],
+                                                "workload": "PointNet2SemSeg(19, 1) eval forward, 1 x 25000 x 4 (pcdvis.py:118-136)",
+                                                "fps_ms": doc["kernels_ms"].get("pn2_fps")}
+    except Exception as e:
+        out["infer_single_cloud_25000_eval"] = {"error": repr(e)[:200]}
     return out
 
 
@@ -508,6 +563,9 @@ def main():
                     help="compute each batch's FPS/ball-query/3-NN inside its own step instead of one step ahead")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="headline run only: skip the short runs of the other BASELINE.json configurations (other_configs)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="testing only: every rank uses GPU 0 (a one-GPU box exercising the N > 1 RCCL path, if RCCL accepts two ranks "
+                         "on one device)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU only: exercise the launch / rendezvous / max-over-ranks timing / JSON relay with gloo ranks "
                          "and no GPU work (tests/test_bench_launch_cpu.py)")
@@ -525,7 +583,7 @@ def main():
     from pointnet12_amd import synthetic as syn
 
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
@@ -596,7 +654,8 @@ def main():
         if two_bucket:
             bucket.use_two_buckets(list(net.sa1.parameters()))
             bucket.arm(net.sa1)
-    compute = make_step(args.workload, net, pts, labels, bucket)     # zero grads + forward + loss + backward
+    compute = make_step(args.workload, net, pts, labels, bucket,     # zero grads + forward + loss + backward
+                        prefetch=not (args.no_graph or args.no_prefetch))
     if not args.no_graph:
         from pointnet12_amd.graph import GraphedStep
         torch.manual_seed(4321)
@@ -605,7 +664,7 @@ def main():
             geometry = (lambda: net(pts[:, :3, :], pts[:, 3:, :])) if args.workload == "sa" else (lambda: net.features(pts))
         # (fork_in_step: the geometry branch starts at make_step's fork_point() where that pays -- see make_step)
         graphed = GraphedStep(compute, dev, geometry_fn=geometry,     # one hipGraph launch per step (failures raise)
-                              fork_in_step=getattr(compute, "fork_in_step", False))
+                              fork_in_step=getattr(compute, "fork_in_step", False) and geometry is not None)
     else:
         graphed = compute
 
@@ -638,65 +697,42 @@ def main():
             finally:
                 _pu.MSG_SCALE_STREAMS = _saved_streams
             torch.cuda.synchronize()
-            agg = {}
+            agg, per_kernel = {}, {}
             ncall = len(calls) // prof_steps
             # a launch's duration = the median over the prof_steps passes (every pass issues the same launches in the
             # same order); eager issue leaves idle gaps in which the clocks wander, single samples are +-10 %
-            raw = [e0.elapsed_time(e1) for (_, _, e0, e1) in calls]
+            raw = [c[2].elapsed_time(c[3]) for c in calls]
             med = [float(np.median([raw[s_ * ncall + j] for s_ in range(prof_steps)])) for j in range(ncall)]
-            for i, (name, a, e0, e1) in enumerate(calls):
+
+            def book(table, key, ms, fl, by, **extra):
+                d = table.setdefault(key, dict(ms=0.0, n=0, fl=0.0, by=0.0, **extra))
+                d["ms"] += ms; d["n"] += 1; d["fl"] += fl; d["by"] += by
+            for i, (name, a, e0, e1, kern) in enumerate(calls):
                 ms = med[i % ncall]
-                if name == "pn2_conv1x1_fwd_pool":     # the same GEMM (same leading arguments) with the pooling extrema in its epilogue
-                    name = "pn2_conv1x1_fwd"
-                if name == "pn2_conv1x1_wgrad_ws":     # the same weight gradient (same leading arguments) with caller scratch
-                    name = "pn2_conv1x1_wgrad"
-                if name == "pn2_ball_query_ws":        # the same query (same leading arguments) with caller scratch
-                    name = "pn2_ball_query"
-                if name == "pn2_conv1x1_wgrad_cf":     # a first layer's weight gradient (closed-form BatchNorm terms): same family
-                    fl, by = algorithmic_work(name, a)
-                    d = agg.setdefault("pn2_conv1x1_wgrad", [0.0, 0, 0.0, 0.0])
-                    d[0] += ms; d[1] += 1; d[2] += fl; d[3] += by
-                    continue
                 split = name == "pn2_conv1x1_bwd_pair_split"     # the pair entry point ran as dgrad + wgrad launches: booked half / half
                 fl, by = algorithmic_work("pn2_conv1x1_bwd_pair" if split else name, a)
+                # per KERNEL (the template instantiation the launcher says it enqueued: the name rocprofv3 prints) -- what `roofline`
+                # prices; launches of one instantiation on several layer shapes add up, as in the profiler's per-name statistics
+                if kern and not split:
+                    book(per_kernel, kernel_key(kern), ms, fl, by, entry=name)
+                # per ENTRY POINT (C ABI), as rounds 1-5 listed them under "kernels"
+                ename = {"pn2_conv1x1_fwd_pool": "pn2_conv1x1_fwd", "pn2_conv1x1_wgrad_ws": "pn2_conv1x1_wgrad", "pn2_ball_query_ws": "pn2_ball_query",
+                         "pn2_conv1x1_wgrad_cf": "pn2_conv1x1_wgrad"}.get(name, name)
                 if split:
                     for half in ("pn2_conv1x1_dgrad", "pn2_conv1x1_wgrad"):
-                        d = agg.setdefault(half, [0.0, 0, 0.0, 0.0])
-                        d[0] += ms / 2
-                        d[1] += 1
-                        d[2] += fl / 2
-                        d[3] += by / 2
+                        book(agg, half, ms / 2, fl / 2, by / 2)
                     continue
                 if args.detail and i >= len(calls) - ncall:
                     dims = [x for x in a if isinstance(x, int) and 0 < x < (1 << 31)][:8]
-                    print("%-22s %8.1f us %7.2f TF %8.1f GB/s  %s" % (name, ms * 1e3, fl / ms / 1e9 if ms else 0,
-                                                                      by / ms / 1e6 if ms else 0, dims), file=sys.stderr)
-                d = agg.setdefault(name, [0.0, 0, 0.0, 0.0])
-                d[0] += ms
-                d[1] += 1
-                d[2] += fl
-                d[3] += by
-        kernels = {k: {"ms_per_step": round(v[0] / prof_steps, 4), "launches_per_step": v[1] // prof_steps,
-                       "gflop_per_step": round(v[2] / prof_steps / 1e9, 3), "mb_per_step": round(v[3] / prof_steps / 1e6, 2)}
-                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
-        # the roofline object prices the entry point with the most device time among those that move bytes / do flops;
-        # pn2_fps is a chain of npoint dependent iterations (latency-bound by construction) and
-        # pn2_invert_index a counting sort of the neighbour index; both belong to the geometry that the graph
-        # prefetches on a side stream under the MLP kernels: listed under "kernels", not priced here
-        top, v = max(((k, x) for k, x in agg.items() if k not in ("pn2_fps", "pn2_invert_index")), key=lambda kv: kv[1][0])
-        secs = v[0] / 1e3
-        tf = v[2] / secs / 1e12
-        gbs = v[3] / secs / 1e9
-        # GEMM entry points: the bound that is closer to its peak prices the kernel; everything else moves bytes
-        if top.startswith("pn2_conv1x1") and tf / F32_MFMA_PEAK_TF >= gbs / HBM_PEAK_GBS:
-            roofline = {"kernel": top, "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(tf / F32_MFMA_PEAK_TF, 4), "traffic": None}
-        else:
-            roofline = {"kernel": top, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
-        # HBM traffic of that kernel family from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes), per launch.
-        # The file carries the digest of the kernel sources it was collected with: a stale file is not quoted.
+                    print("%-22s %8.1f us %7.2f TF %8.1f GB/s  %s  %s" % (name, ms * 1e3, fl / ms / 1e9 if ms else 0,
+                                                                          by / ms / 1e6 if ms else 0, dims, kernel_key(kern) if kern else ""), file=sys.stderr)
+                book(agg, ename, ms, fl, by)
+        kernels = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["n"] // prof_steps,
+                       "gflop_per_step": round(v["fl"] / prof_steps / 1e9, 3), "mb_per_step": round(v["by"] / prof_steps / 1e6, 2)}
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        # HBM traffic per kernel from the committed PMC passes (tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes), per launch.  The file carries the digest of the
+        # kernel sources it was collected with: a stale file is not quoted.
         import glob
         # one file per measured configuration: <workload> for the 4096-point configs, <workload>_n<points> for the dense scans
         pmc_key = args.workload if n_points == 4096 else "%s_n%d" % (args.workload, n_points)
@@ -707,42 +743,46 @@ def main():
             pmc_doc = json.load(open(cands[-1]))
             pmc_fresh = pmc_doc.get("csrc_sha256") == csrc_digest()
 
-        def pmc_traffic(entry):
-            """HBM bytes per launch of an entry point's kernel families from the digest-checked PMC file, or None."""
-            if not (pmc_doc and pmc_fresh):
-                return None
-            hit = [pmc_doc.get("families", {}).get(f) for f in GEMM_FAMILIES.get(entry, [])]
-            hit = [h for h in hit if h]
-            if not hit:
-                return None
-            return round(sum(h["hbm_bytes_per_step"] for h in hit) / sum(h["launches_per_step"] for h in hit))
+        def pmc_traffic(key):
+            """HBM bytes per launch of a kernel from the digest-checked PMC file, or None."""
+            hit = (pmc_doc or {}).get("kernels", {}).get(key) if pmc_fresh else None
+            return round(hit["hbm_bytes_per_launch"]) if hit else None
 
-        if top in GEMM_FAMILIES:
-            roofline["traffic"] = pmc_traffic(top)
-            if roofline["traffic"] is not None:
-                roofline["traffic_note"] = "HBM bytes per launch, PMC (profiles/%s, kernel families %s); algorithmic bytes per launch %d" % (
-                    pmc_name, " + ".join(GEMM_FAMILIES[top]), round(v[3] / v[1]))
-            elif pmc_doc:
-                roofline["traffic_note"] = "profiles/%s was collected with other kernel sources (digest differs): not quoted" % pmc_name
-        # all four GEMM entry points, weakest first: the line must not look healthier than its worst big kernel
-        fam_rows = []
-        for entry in GEMM_FAMILIES:
-            x = agg.get(entry)
-            if not x or x[0] <= 0:
+        # The roofline, per KERNEL: algorithmic bytes and fp32 flops of its launches (from their arguments) over their HIP-event time,
+        # against HBM 8 TB/s and against the matrix peak of the pipe the kernel runs on -- fp32 MFMA 157.3 TF, or 2500 / 6 = 416.7 TF
+        # of fp32 products for the bf16x3 split kernels (six bf16 MFMAs per product block).  The larger fraction names the bound; a
+        # fraction above 1 would mean the byte / flop model is wrong and fails the run.
+        rows = []
+        for key, v in per_kernel.items():
+            if v["ms"] <= 0 or (v["fl"] <= 0 and v["by"] <= 0):
                 continue
-            e_tf, e_gbs = x[2] / (x[0] / 1e3) / 1e12, x[3] / (x[0] / 1e3) / 1e9
-            fam_rows.append({"name": entry, "ms_per_step": round(x[0] / prof_steps, 4), "launches_per_step": x[1] // prof_steps,
-                             "TFLOPs": round(e_tf, 2), "frac": round(e_tf / F32_MFMA_PEAK_TF, 4), "alg_GBs": round(e_gbs, 1),
-                             "hbm_frac": round(e_gbs / HBM_PEAK_GBS, 4), "alg_bytes": round(x[3] / x[1]),
-                             "traffic": pmc_traffic(entry)})
-        roofline["families"] = sorted(fam_rows, key=lambda r: r["frac"])
-        if split_on:
-            roofline["arithmetic_note"] = ("achieved = ALGORITHMIC fp32 flops (2 P K N per product) / device time, peak = the fp32 MFMA peak "
-                                           "157.3 TF; the wide layers inside these families issue six bf16 MFMAs per fp32 product block (bf16 "
-                                           "dense peak 2500 TF) and are HBM-bound: a family can therefore exceed what fp32 MFMA alone allows")
-        roofline["avg_launch_us"] = round(v[0] / v[1] * 1e3, 2)
-        roofline["launches"] = v[1] // prof_steps
-        roofline["device_ms_all_kernels_per_step"] = round(sum(x[0] for x in agg.values()) / prof_steps, 3)
+            bound, ach, peak, unit, frac, hf, mf = price(v["fl"], v["by"], v["ms"] / 1e3, kernel_pipe(key))
+            rows.append({"kernel": key, "pipe": kernel_pipe(key), "entry": v["entry"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                         "frac": frac, "hbm_frac": hf, "mfma_frac": mf, "avg_us": round(v["ms"] / v["n"] * 1e3, 2),
+                         "launches_per_step": v["n"] // prof_steps, "ms_per_step": round(v["ms"] / prof_steps, 4),
+                         "alg_bytes": round(v["by"] / v["n"]), "alg_gflop": round(v["fl"] / v["n"] / 1e9, 3), "pmc_bytes": pmc_traffic(key)})
+        over = [r_ for r_ in rows if r_["frac"] > 1.0]
+        if over:
+            raise SystemExit("roofline fraction above 1 (byte / flop model wrong): %s" % over)
+        if rows:
+            top = max(rows, key=lambda r_: r_["ms_per_step"])
+            roofline = {k: top[k] for k in ("kernel", "pipe", "entry", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "mfma_frac",
+                                            "avg_us", "launches_per_step", "alg_bytes", "alg_gflop")}
+            roofline["traffic"] = top["pmc_bytes"]
+            roofline["avg_launch_us"] = top["avg_us"]
+            roofline["launches"] = top["launches_per_step"]
+            if top["pmc_bytes"] is not None:
+                roofline["traffic_note"] = "HBM bytes per launch, PMC (profiles/%s); algorithmic bytes per launch %d" % (pmc_name, top["alg_bytes"])
+            elif pmc_doc and not pmc_fresh:
+                roofline["traffic_note"] = "profiles/%s was collected with other kernel sources (digest differs): not quoted" % pmc_name
+            roofline["note"] = ("the GEMM kernel (template instantiation, rocprofv3's name) with the most device time in an eager serial pass: "
+                                "achieved = algorithmic bytes (or fp32 flops) of its launches / their HIP-event time; peak = HBM 8 TB/s, or the "
+                                "matrix peak of its pipe (f32: 157.3 TF; bf16x3 split kernels: 2500 / 6 = 416.7 TF of fp32 products); the larger "
+                                "fraction is the bound.  Geometry (pn2_fps: a dependent-iteration chain on the prefetch branch) is listed under "
+                                "`kernels`, not priced here")
+            roofline["kernels"] = sorted(rows, key=lambda r_: r_["frac"])            # weakest first
+        roofline = roofline or {}
+        roofline["device_ms_all_kernels_per_step"] = round(sum(x["ms"] for x in agg.values()) / prof_steps, 3)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PN2_ABI_VERSION 10
+#define PN2_ABI_VERSION 11
 
 /* Per-channel fp64 reduction buffers ("stats", "red") are PN2_STAT_REPLICAS interleaved copies of
  * double[2*C] (sum, then second moment): workgroups add into copy (workgroup index % replicas) so the
@@ -100,13 +100,33 @@ typedef struct pn2_bn_coef_lazy {
 
 int pn2_version(void);
 const char *pn2_error_string(int code);
+/* Diagnostics (ABI 11): the kernel template instantiation the CALLING THREAD's most recent GEMM entry point enqueued, spelled as
+ * rocprofv3 prints it ("(anonymous namespace)::split_bwd_res_kernel<4, 3, true, true>"), or NULL.  Thread-local; the launchers
+ * store a pointer, nothing in the library reads it: bench.py prices every launch of its instrumented pass per KERNEL with it. */
+const char *pn2_last_kernel(void);
+void pn2_clear_last_kernel(void);
 
 /* Dispatch / tuning options (ABI 10).  Which kernel family takes a layer, tile overrides, A/B switches of measured
  * experiments: one process-wide table of ints, every default the measured winner (the list with defaults and meanings:
- * PN2_OPTION_LIST in pointnet12_amd/csrc/pn2_common.h).  No option changes RESULTS beyond fp32 summation order.  `name` is
+ * PN2_OPTION_LIST in pointnet12_amd/csrc/pn2_common.h).  `name` is
  * the option's name with or without its "PN2_" prefix ("PN2_RING", "WIDE_MIN_ROWS", ...).  An option takes effect with the
  * next call; set options before work is enqueued from several threads.  pn2_option_name(i): name of option i, NULL past the
- * end (enumeration).  Unknown name: PN2_EINVAL. */
+ * end (enumeration).  Unknown name: PN2_EINVAL.
+ *
+ * NUMERICS CONTRACT.  Every option but the two groups below changes results by fp32 summation order at most.  The exceptions
+ * choose the ARITHMETIC a GEMM layer runs in, and are ON by default:
+ *   SPLIT (with SPLIT_WGRAD, SPLIT_K256, SPLIT_NARROW, SPLIT_RES, SPLIT_MIN_ROWS_128, SPLIT_RES_MIN_TILES_128 selecting layers):
+ *     1 = the long layers (from 65 536 rows) form every fp32 product from EXACT three-way bf16 splits of both operands
+ *     (x = hi + mid + lo, 8 + 8 + 8 significand bits) as six v_mfma_f32_32x32x16_bf16 products accumulated in fp32; the three
+ *     dropped cross terms are <= 2^-24 |a b| each.  Error against fp64: <= that of the sequential fp32 fma chain of
+ *     v_mfma_f32_32x32x2_f32 it replaces (2.9e-6 vs 5.3e-6 at K = 128, profiles/r05_split_gemm_probe.txt), same 1e-5 contract.
+ *     PRECONDITION: finite operands with |x| < 2^127 (bf16 rounds a larger |x| to inf and the residual becomes NaN where the
+ *     fp32 pipe gives a finite product), and pieces below 2^-126 are flushed (the lo piece of |x| < 2^-110 is lost: relative
+ *     error up to 2^-16 on such operands).  Activations, weights and gradients of a BatchNorm network sit 30 binades inside both.
+ *     0 = v_mfma_f32_32x32x2_f32 everywhere (an exact fp32 fma chain per output element).
+ *   POOL_CF: 1 = a pooled last layer of 128 x 96 (2: also 128 x 64) never writes its pre-BN output; its backward is evaluated from the
+ *     layer's input (pn2_conv1x1_bwd_cf: the same function, another rounding order; fp64-checked to 3e-6).
+ * A caller that needs one arithmetic across library versions sets these explicitly. */
 int pn2_set_option(const char *name, int value);
 int pn2_get_option(const char *name, int *value);
 const char *pn2_option_name(int index);
@@ -253,6 +273,9 @@ int pn2_bn_finalize(const double *stats, int64_t P, int C, const float *gamma, c
  * pn2_bn_relu_max is not needed.  Returns PN2_EUNSUPPORTED (nothing launched) when the shape is outside the resident kernels
  * (see pn2_res_supported; also needs P % 32 == 0, Kpool == 16 or Kpool % 32 == 0): call pn2_conv1x1_fwd + pn2_bn_relu_max
  * then. */
+/* Y == NULL (ABI 11): the pre-BN output is not written at all -- statistics and extrema only.  Taken by the bf16-pipe forms of the
+ * forward alone (PN2_EUNSUPPORTED otherwise: call again with a Y); the layer's backward then runs on the layer's INPUT:
+ * pn2_pool_bwd_reduce_rec + pn2_conv1x1_bwd_cf below, where pn2_conv1x1_bwd_cf_supported() says so. */
 int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
                          int ldy, int64_t P, int K, int N, double *stats, int Kpool, const float *gamma, float *pool_ws,
                          const pn2_bn_lazy *in_lazy, pn2_stream_t stream);
@@ -286,6 +309,16 @@ int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int3
 int pn2_pool_bwd_reduce_ld(const float *dOut, int ld_dout, const float *out, int ldo, const int32_t *arg, const float *Y, int ldy,
                            const float *affine, int64_t G, int K, int C, float *dZp, double *red, const pn2_bn_coef_tail *tail,
                            pn2_stream_t stream);
+/* pn2_pool_bwd_reduce_ld for a pooled last layer whose pre-BN output was never written (pn2_conv1x1_fwd_pool with Y == NULL): the
+ * value at the recorded row comes from pool_ws (the {value, row} records of that forward; `out` / `arg` from pn2_bn_pool_select of
+ * the same records) -- exact for every gamma, no gather.  A channel whose folded scale is exactly 0 routes to row 0 of its group,
+ * whose value the record does not hold: recomputed from the layer's input, y = bias[c] + W[c, :] . relu(bn(prev_Y[g K, :]))
+ * (W [C, C_in] pitch ldw, prev_Y pitch ld_prev with its affine block of pitch round4(C_in)).  Same outputs as
+ * pn2_pool_bwd_reduce_ld. */
+int pn2_pool_bwd_reduce_rec(const float *dOut, int ld_dout, const float *out, int ldo, const int32_t *arg, const float *pool_ws,
+                            const float *affine, int64_t G, int K, int C, float *dZp, double *red, const float *W, int ldw,
+                            const float *bias, const float *prev_Y, int ld_prev, const float *prev_affine, int C_in,
+                            pn2_stream_t stream);
 /* Backward, dense (FP) last layer: dZ = dOut * (out > 0) written to dZ [P, ldz] (its pad columns
  * C .. round4(C)-1 are written as zeros); same reductions, same precondition on `out` (= max(fma(Y - mean, scale, beta), 0)). */
 int pn2_relu_bwd_reduce(const float *dOut, int ldo, const float *out, const float *Y, int ldy, const float *affine,
@@ -358,6 +391,26 @@ int pn2_conv1x1_bwd_pair(const float *dZ, int ldz, const float *dZp, int ldo, co
                          const float *prev_affine, float *dXout, int ldxo, double *prev_red, const float *X, int ldx,
                          const float *x_affine, float *dW, int lddw, int64_t P, int C_out, int C_in,
                          const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
+
+/* pn2_conv1x1_bwd of the LAST layer of a pooled shared MLP (model/pointnet_util.py:197-199, :254-256: conv + BN + ReLU + max over
+ * Kpool rows) WITHOUT that layer's pre-BN output (ABI 11).  dZ is sparse there (one row per group and channel: dZp / arg as
+ * pn2_pool_bwd_reduce_rec wrote them) and the dense part of dY = c0 dZ + q1 (y - mean) + q0 is affine in y = W x + b, hence in the
+ * layer's input x = relu(bn(prev_Y)), which the pass reads anyway:
+ *     dXout = ([D | X] [diag(c0) W ; W^T diag(q1) W] + (q1 (b - mean) + q0)^T W) masked by the previous ReLU, reductions into prev_red;
+ *     dW   += c0 o (D^T X) + q1 o (W (X^T X) + (b - mean) (1^T X)) + q0 (1^T X)
+ * -- the same function of the same inputs as pn2_conv1x1_bwd (fp32 rounding differs: tests/test_mlp_gpu.py holds both to fp64),
+ * 4 P (2 C_in) bytes instead of 4 P (C_out + 2 C_in), and the forward writes no Y (pn2_conv1x1_fwd_pool with Y == NULL).
+ * Partial products leave as one slab per workgroup and are summed in a fixed order: dW is run-to-run identical.
+ * bias: the conv bias [C_out].  scratch: pn2_conv1x1_bwd_cf_scratch_bytes(C_out, C_in) bytes, 256-byte aligned, contents need
+ * not be initialised.  Training-mode BatchNorm, prev_affine != NULL.  pn2_conv1x1_bwd_cf_supported(): 1 where the call runs
+ * (128 x 96 and 128 x 64 with Kpool a power of two >= 32, from pn2_res_supported()'s row count on, library options SPLIT /
+ * SPLIT_RES / POOL_CF on); PN2_EUNSUPPORTED otherwise. */
+int pn2_conv1x1_bwd_cf_supported(int64_t P, int C_out, int C_in, int Kpool);
+int64_t pn2_conv1x1_bwd_cf_scratch_bytes(int C_out, int C_in);
+int pn2_conv1x1_bwd_cf(const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *coef, const float *W, int ldw,
+                       const float *bias, const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
+                       double *prev_red, float *dW, int lddw, int64_t P, int C_out, int C_in,
+                       const pn2_bn_coef_lazy *coef_lazy, float *scratch, pn2_stream_t stream);
 
 /* Fused backward of one layer for the narrow, long layers (csrc/mlp_res.hip): dgrad AND wgrad in ONE pass over dZ / Y /
  * prev_Y -- autograd of model/pointnet_util.py:197,254,312 for conv + BatchNorm + ReLU.  dY is formed once per row

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpn2_oracle.so")
+_SO = os.environ.get("PN2_ORACLE_SO") or os.path.join(_HERE, "libpn2_oracle.so")     # (override: the sanitizer build, oracle/Makefile `asan`)
 
 
 def build(force=False):

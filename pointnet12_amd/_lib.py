@@ -17,6 +17,8 @@ _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_
 SIGNATURES = {
     "pn2_version": (_i, []),
     "pn2_error_string": (ctypes.c_char_p, [_i]),
+    "pn2_last_kernel": (ctypes.c_char_p, []),
+    "pn2_clear_last_kernel": (None, []),
     "pn2_set_option": (_i, [ctypes.c_char_p, _i]),
     "pn2_get_option": (_i, [ctypes.c_char_p, _vp]),
     "pn2_option_name": (ctypes.c_char_p, [_i]),
@@ -44,6 +46,7 @@ SIGNATURES = {
     "pn2_bn_relu_max": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_pool_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_pool_bwd_reduce_ld": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "pn2_pool_bwd_reduce_rec": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "pn2_relu_bwd_reduce": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "pn2_bn_bwd_coef": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "pn2_conv1x1_dgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp,
@@ -61,6 +64,9 @@ SIGNATURES = {
     "pn2_bwd_res_supported": (_i, [_i64, _i, _i, _i, _i]),
     "pn2_conv1x1_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                              _i64, _i, _i, _vp, _vp]),
+    "pn2_conv1x1_bwd_cf_supported": (_i, [_i64, _i, _i, _i]),
+    "pn2_conv1x1_bwd_cf_scratch_bytes": (_i64, [_i, _i]),
+    "pn2_conv1x1_bwd_cf": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "pn2_fused_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "pn2_invert_index": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_three_interp_bwd_seg": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -76,7 +82,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PN2_EUNSUPPORTED = -3            # include/pn2.h
 PN2_OK_SPLIT = 1                 # pn2_conv1x1_bwd_pair: done as two launches
 DWX_REPLICAS = 32        # PN2_DWX_REPLICAS of include/pn2.h
@@ -136,7 +142,7 @@ class _Timed:
         fn = getattr(_raw, name)
         if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_set_option", "pn2_get_option", "pn2_option_name", "pn2_fps_workspace_bytes",
                                                    "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_bwd_res_supported", "pn2_conv1x1_wgrad_workspace_bytes",
-                                                   "pn2_conv1x1_wgrad_cf_scratch_bytes",
+                                                   "pn2_conv1x1_wgrad_cf_scratch_bytes", "pn2_conv1x1_bwd_cf_supported", "pn2_conv1x1_bwd_cf_scratch_bytes", "pn2_last_kernel", "pn2_clear_last_kernel",
                                                    "pn2_ball_query_workspace_bytes"):
             return fn
 
@@ -145,18 +151,21 @@ class _Timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             h = args[-1]
             s = torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream()
+            _raw.pn2_clear_last_kernel()
             a.record(s)
             rc = fn(*args)
             b.record(s)
             if rc != PN2_EUNSUPPORTED:         # (a refused shape launched nothing: the caller takes its other route)
                 # (pn2_conv1x1_bwd_pair that ran as two launches is booked under a name of its own: bench.py splits it)
-                _profile.append((name + "_split" if (name == "pn2_conv1x1_bwd_pair" and rc == PN2_OK_SPLIT) else name, args, a, b))
+                kern = _raw.pn2_last_kernel()      # the GEMM launchers say which template instantiation they enqueued (or None)
+                _profile.append((name + "_split" if (name == "pn2_conv1x1_bwd_pair" and rc == PN2_OK_SPLIT) else name, args, a, b,
+                                 kern.decode() if kern else None))
             return rc
         return timed
 
 
 class call_profile:
-    """``with call_profile() as calls:`` -> list of (entry point, args, start, end) for every C-ABI call made
+    """``with call_profile() as calls:`` -> list of (entry point, args, start, end, kernel name or None) for every C-ABI call made
     inside; ``start.elapsed_time(end)`` after a synchronize gives that launch's device time in ms."""
 
     def __enter__(self):
@@ -188,8 +197,8 @@ def load():
         fn.argtypes = args
     if lib.pn2_version() != ABI_VERSION:
         raise Pn2Error("libpn2_hip.so ABI version %d, expected %d -- rebuild it" % (lib.pn2_version(), ABI_VERSION))
+    forward_env_options(lib)         # (before the library is published: a malformed PN2_<OPTION> raises on EVERY load, not only the first)
     _lib = _raw = lib
-    forward_env_options(lib)
     return lib
 
 
@@ -219,9 +228,12 @@ def forward_env_options(lib):
         v = os.environ.get(name)
         if v is not None:
             try:
-                lib.pn2_set_option(name.encode(), int(v))
+                value = int(v)
             except ValueError:
                 raise Pn2Error("%s=%r is not an integer" % (name, v))
+            rc = lib.pn2_set_option(name.encode(), value)
+            if rc != 0:
+                raise Pn2Error("pn2_set_option(%s, %d) failed: %d" % (name, value, rc))
 
 
 def check(rc, what):

@@ -1,6 +1,8 @@
 // Version / error-string entry points of the C ABI.
 #include "pn2_common.h"
 
+#include <cxxabi.h>
+#include <stdlib.h>
 #include <string.h>
 
 int pn2_option_table[PN2_OPT_COUNT] = {
@@ -8,6 +10,8 @@ int pn2_option_table[PN2_OPT_COUNT] = {
     PN2_OPTION_LIST(PN2_X)
 #undef PN2_X
 };
+
+thread_local const void *pn2_last_kernel_fn = nullptr;
 
 namespace {
 const char *const kOptionNames[PN2_OPT_COUNT] = {
@@ -42,6 +46,26 @@ int pn2_get_option(const char *name, int *value) {
 const char *pn2_option_name(int index) { return index >= 0 && index < PN2_OPT_COUNT ? kOptionNames[index] : nullptr; }
 
 int pn2_version(void) { return PN2_ABI_VERSION; }
+
+const char *pn2_last_kernel(void) {
+    // the runtime knows the device-side (mangled) name behind a kernel's host stub; demangled it is what rocprofv3 prints
+    static thread_local char buf[1024];
+    const void *fn = pn2_last_kernel_fn;
+    if (fn == nullptr) return nullptr;
+    const char *mangled = hipKernelNameRefByPtr(fn, nullptr);
+    if (mangled == nullptr) return nullptr;
+    int status = 0;
+    size_t len = 0;
+    char *dem = abi::__cxa_demangle(mangled, nullptr, &len, &status);
+    const char *src = (status == 0 && dem) ? dem : mangled;
+    size_t n = strlen(src);
+    if (n >= sizeof(buf)) n = sizeof(buf) - 1;
+    memcpy(buf, src, n);
+    buf[n] = 0;
+    free(dem);
+    return buf;
+}
+void pn2_clear_last_kernel(void) { pn2_last_kernel_fn = nullptr; }
 
 const char *pn2_error_string(int code) {
     switch (code) {

@@ -45,10 +45,14 @@ __device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float n
 // index -- one ds_max_u64 per wave on a shared LDS word and ONE barrier (three words in rotation).
 // pointnet_util.py:77-83.
 // ---------------------------------------------------------------------------------------------
-template <int THREADS, int PPT, bool XYZ_LDS>
+// PIECE (round 6, option FPS_PIECE: the launch-cadence experiment of HISTORY.md): the npoint iterations as several launches of
+// `it1 - it0` iterations each -- the running distances and the current sample travel between the launches through a workspace
+// (md_ws [B][PPT][THREADS] floats, far_ws [B] ints).  Same arithmetic in the same order: bit-identical indices.
+template <int THREADS, int PPT, bool XYZ_LDS, bool PIECE = false>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ xyz, int N,
                                                       const int64_t *__restrict__ start, int npoint,
-                                                      int64_t *__restrict__ out) {
+                                                      int64_t *__restrict__ out, int it0 = 0, int it1 = 0,
+                                                      float *__restrict__ md_ws = nullptr, int *__restrict__ far_ws = nullptr) {
     constexpr int NW = THREADS / 64;
     extern __shared__ float4 fps_lds[];
     float4 *cloud = fps_lds;                                                     // [N] when XYZ_LDS
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         int j = t + i * THREADS;
         if (j < N) {
             px[i] = p[3 * j]; py[i] = p[3 * j + 1]; pz[i] = p[3 * j + 2];
-            md[i] = 1e10f;
+            md[i] = (PIECE && it0 > 0) ? md_ws[((size_t)b * PPT + i) * THREADS + t] : 1e10f;
             if (XYZ_LDS) cloud[j] = make_float4(px[i], py[i], pz[i], 0.f);
         } else {
             px[i] = py[i] = pz[i] = 0.f;
@@ -76,8 +80,10 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
 
     // an out-of-range start (only the Python `start=` override can produce one) must not index past the cloud
     int far = (int)(start[b] < 0 ? 0 : (start[b] >= N ? N - 1 : start[b]));
+    if (PIECE && it0 > 0) far = far_ws[b];
     int64_t *o = out + (size_t)b * npoint;
-    for (int it = 0; it < npoint; ++it) {
+    const int it_begin = PIECE ? it0 : 0, it_end = PIECE ? (it1 < npoint ? it1 : npoint) : npoint;
+    for (int it = it_begin; it < it_end; ++it) {
         if (t == 0) o[it] = far;
         float cx, cy, cz;
         if (XYZ_LDS) {
@@ -134,6 +140,11 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
             key = *cur;
         }
         far = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    }
+    if (PIECE && it_end < npoint) {                   // hand the state to the next launch
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) md_ws[((size_t)b * PPT + i) * THREADS + t] = md[i];
+        if (t == 0) far_ws[b] = far;
     }
 }
 
@@ -751,6 +762,19 @@ int launch_fps(const float *xyz, int B, int N, const int64_t *start, int npoint,
 
 // Spatial (Morton-cell) ordering of the query centres of one cloud for ball_query_kernel: bounding box, 4096-cell histogram,
 // scan and fill in LDS -- one workgroup per cloud, any S (the order array lives in global memory).
+template <int THREADS, int PPT>
+int launch_fps_pieces(const float *xyz, int B, int N, const int64_t *start, int npoint, int64_t *out, void *work, int piece, hipStream_t s) {
+    const size_t lds = sizeof(float4) * (size_t)N + 4 * sizeof(unsigned long long);
+    float *md_ws = reinterpret_cast<float *>(work);
+    int *far_ws = reinterpret_cast<int *>(md_ws + (size_t)B * PPT * THREADS);
+    static Pn2PerDevice raised;
+    if (lds > 64 * 1024 && pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&fps_kernel<THREADS, PPT, true, true>), raised) != PN2_OK) return PN2_ELAUNCH;
+    for (int it0 = 0; it0 < npoint; it0 += piece)
+        hipLaunchKernelGGL((fps_kernel<THREADS, PPT, true, true>), dim3(B), dim3(THREADS), lds, s, xyz, N, start, npoint, out, it0, it0 + piece, md_ws,
+                           far_ws);
+    return pn2_launch_status();
+}
+
 __global__ __launch_bounds__(1024) void bq_order_kernel(const float *__restrict__ new_xyz, int S, int *__restrict__ order) {
     __shared__ int hist[FPS_NC];
     __shared__ int wsum[16];
@@ -1027,6 +1051,7 @@ int64_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     int ppt, W;
     fps_coop_plan(B, N, &ppt, &W);
     if (W) return (int64_t)B * npoint * W * (int64_t)sizeof(FpsSlot);
+    if (N > 2048 && N <= 4096 && pn2_opt(PN2_OPT_FPS_PIECE) > 0) return (int64_t)B * (512 * 8 * 4 + 4);     // the pieced form's state
     return N > fps_single_max() ? (int64_t)B * N * 4 : 0;
 }
 
@@ -1057,7 +1082,11 @@ int pn2_fps(const float *xyz, int B, int N, const int64_t *start, int npoint, in
         if (N <= 26624) return launch_fps_pruned<1024, 26>(xyz, B, N, start, npoint, out_idx, s);   // (24+: the row-level kernel)
         return launch_fps_pruned<1024, 28>(xyz, B, N, start, npoint, out_idx, s);
     }
-    if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, start, npoint, out_idx, s);
+    if (N <= 4096) {
+        const int piece = pn2_opt(PN2_OPT_FPS_PIECE);
+        if (piece > 0 && npoint > piece && work != nullptr) return launch_fps_pieces<512, 8>(xyz, B, N, start, npoint, out_idx, work, piece, s);
+        return launch_fps<512, 8>(xyz, B, N, start, npoint, out_idx, s);
+    }
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, start, npoint, out_idx, s);
     if (N <= fps_single_max()) {

@@ -530,6 +530,7 @@ int launch_nt(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipStream
             }
         }
     }
+    PN2_NOTE_KERNEL(gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi, ACCS, ROT>);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WR, WC, MINB, DEPTH, BNN, VEC, ALoad, Epi, ACCS, ROT>), dim3(gx, tiles_n), dim3(NTHREADS),
                        (size_t)ALoad::kTab * K4 * sizeof(float), s, aload, bm, P, K4, N, epi, n_lo);
     return pn2_launch_status();
@@ -786,9 +787,9 @@ bool launch_fewrow(ALoad aload, BMat bm, int64_t P, int K4, int N, Epi epi, hipS
     int ks = tiles * 4 <= 4 * pn2_num_cus() ? 4 : tiles * 2 <= 4 * pn2_num_cus() ? 2 : 1;
     if (force_ks) ks = force_ks;
     const dim3 grid((unsigned)(tiles * ks / 4));
-    if (ks == 4) hipLaunchKernelGGL((fewrow_nt_kernel<4, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi);
-    else if (ks == 2) hipLaunchKernelGGL((fewrow_nt_kernel<2, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi);
-    else hipLaunchKernelGGL((fewrow_nt_kernel<1, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi);
+    if (ks == 4) { PN2_NOTE_KERNEL(fewrow_nt_kernel<4, BNN, ALoad, Epi>); hipLaunchKernelGGL((fewrow_nt_kernel<4, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi); }
+    else if (ks == 2) { PN2_NOTE_KERNEL(fewrow_nt_kernel<2, BNN, ALoad, Epi>); hipLaunchKernelGGL((fewrow_nt_kernel<2, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi); }
+    else { PN2_NOTE_KERNEL(fewrow_nt_kernel<1, BNN, ALoad, Epi>); hipLaunchKernelGGL((fewrow_nt_kernel<1, BNN, ALoad, Epi>), grid, dim3(NTHREADS), dyn, s, aload, bm, K4, N, epi); }
     *rc = pn2_launch_status();
     return true;
 }
@@ -1149,6 +1150,7 @@ int launch_skinny(const float *dZ, int ldz, const float *Y, int ldy, const float
     const int64_t cap = (int64_t)pn2_num_cus() * 2 / gy;      // two resident workgroups per CU; each ends with M*N atomics
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
+    PN2_NOTE_KERNEL(wgrad_skinny_kernel<NQ>);
     hipLaunchKernelGGL((wgrad_skinny_kernel<NQ>), dim3((unsigned)gx, gy), dim3(256), 0, s, dZ, ldz, Y, ldy, coef, ldc, X, ldx, P, M, N,
                        cg_log2, dW, lddw, dbias, lc);
     return pn2_launch_status();
@@ -1167,6 +1169,7 @@ int launch_tn(DyLoad dyload, XLoad xload, int64_t P, int M, int N, float *dW, in
     if (split > 65535) split = 65535;
     int64_t chunk = pn2_cdiv(pn2_cdiv(P, split), WG_BP) * WG_BP;
     split = pn2_cdiv(P, chunk);
+    PN2_NOTE_KERNEL(gemm_tn_kernel<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad, KS, TD, ACCS>);
     hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WG_BP, WR, WC, MINB, DyLoad, XLoad, KS, TD, ACCS>), dim3(tm, tn, (unsigned)split), dim3(NTHREADS), 0, s,
                        dyload, xload, P, chunk, M, N, dW, lddw, dbias);
     return pn2_launch_status();
@@ -1207,10 +1210,12 @@ bool launch_bwd_pair(const PairJob &j, ALoad aload, BMat bm, int64_t P, int K4, 
     const size_t dyn = (size_t)ALoad::kTab * K4 * sizeof(float);
     if constexpr (masked) {
         const LoadBnReluFixed xl{j.X, j.ldx, j.x_aff, zero_page_dev()};
+        PN2_NOTE_KERNEL(bwd_pair_kernel<BM, BN, BK, WR, WC, VEC, ALoad, Epi, LoadBnReluFixed>);
         hipLaunchKernelGGL((bwd_pair_kernel<BM, BN, BK, WR, WC, VEC, ALoad, Epi, LoadBnReluFixed>), dim3(total), dim3(NTHREADS), dyn, s, aload, bm, P,
                            K4, N, epi, (int)nt_gx, (int)nt_gy, xl, chunk, j.M, j.N, j.dW, j.lddw, (int)tm, (int)tn, (int)split);
     } else {
         const LoadPlain xl{j.X, j.ldx, zero_page_dev()};
+        PN2_NOTE_KERNEL(bwd_pair_kernel<BM, BN, BK, WR, WC, VEC, ALoad, Epi, LoadPlain>);
         hipLaunchKernelGGL((bwd_pair_kernel<BM, BN, BK, WR, WC, VEC, ALoad, Epi, LoadPlain>), dim3(total), dim3(NTHREADS), dyn, s, aload, bm, P, K4,
                            N, epi, (int)nt_gx, (int)nt_gy, xl, chunk, j.M, j.N, j.dW, j.lddw, (int)tm, (int)tn, (int)split);
     }
@@ -1446,6 +1451,63 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
         atomicAdd(rep + C + c, a1);
     }
     if (ct.ticket != nullptr && tail_is_last_block(ct.ticket, gridDim.x * gridDim.y)) run_coef_tail(ct, red, C, 256);
+}
+
+// The same for a pooled last layer whose pre-BN output was never written (pn2_conv1x1_fwd_pool with Y = NULL): the value at the
+// maximum, y*, is what the forward's epilogue recorded next to the row (rec[g, c] = {y*, row}; the minimum where the folded scale is
+// negative) -- a coalesced read instead of the gather, and exact for every gamma.  A channel whose folded scale is exactly 0 routes
+// its gradient to row 0 of the group (pn2_bn_pool_select), whose y the record does not hold: recomputed here from the layer's input,
+// y = b[c] + W[c, :] . relu(bn(prevY[g K, :])) -- a dot product per (group, channel), on a path only a zero BatchNorm weight takes.
+__global__ __launch_bounds__(256) void pool_bwd_reduce_rec_kernel(const float *__restrict__ dOut, int ldg, int ldo, const float *__restrict__ out,
+                                                                  const int32_t *__restrict__ arg, const float2 *__restrict__ rec, int ldr,
+                                                                  const float *__restrict__ aff, int lda, int64_t G, int K, int C,
+                                                                  float *__restrict__ dZp, double *__restrict__ red, const float *__restrict__ W,
+                                                                  int ldw, const float *__restrict__ bias, const float *__restrict__ prevY, int ldp,
+                                                                  const float *__restrict__ prev_aff, int Ci) {
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < lda) {                                   // pad columns included: dZp's pad lanes must be zero
+        Affine a(aff, lda);
+        const bool real = c < C;
+        const float mu = real ? a.mean[c] : 0.f, is = real ? a.invstd[c] : 0.f;
+        const bool zero_scale = real && a.scale[c] == 0.f;
+        const int64_t stride = (int64_t)gridDim.y * 4;
+        for (int64_t g0 = (int64_t)blockIdx.y * 4 + gl; g0 < G; g0 += 4 * stride) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u * stride;
+                if (g >= G) break;
+                const float o = real ? out[g * ldo + c] : 0.f;
+                const float dz = real ? dOut[g * ldg + c] : 0.f;
+                float y = real ? rec[g * ldr + c].x : 0.f;
+                const bool on = o > 0.f;
+                if (on && zero_scale) {
+                    Affine pa(prev_aff, (Ci + 3) & ~3);
+                    const float *xr = prevY + (g * K) * ldp;
+                    float acc = bias[c];
+                    for (int j = 0; j < Ci; ++j)
+                        acc = __builtin_fmaf(W[(int64_t)c * ldw + j], fmaxf(bn_act(xr[j], pa.mean[j], pa.scale[j], pa.beta[j]), 0.f), acc);
+                    y = acc;
+                }
+                dZp[g * ldo + c] = on ? dz : 0.f;
+                if (on) {
+                    s0 += (double)dz;
+                    s1 += (double)(dz * ((y - mu) * is));
+                }
+            }
+        }
+    }
+    sh[0][gl][cl] = s0; sh[1][gl][cl] = s1;
+    __syncthreads();
+    if (gl == 0 && c < C) {
+        double a0 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+        double a1 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        double *rep = red + (size_t)(blockIdx.y % PN2_STAT_REPLICAS) * 2 * C;
+        atomicAdd(rep + c, a0);
+        atomicAdd(rep + C + c, a1);
+    }
 }
 
 // Dense last layer (FP): dZ = dOut * (out > 0), same two reductions.
@@ -1821,6 +1883,19 @@ int pn2_pool_bwd_reduce_ld(const float *dOut, int ld_dout, const float *out, int
     return pn2_launch_status();
 }
 
+int pn2_pool_bwd_reduce_rec(const float *dOut, int ld_dout, const float *out, int ldo, const int32_t *arg, const float *pool_ws,
+                            const float *affine, int64_t G, int K, int C, float *dZp, double *red, const float *W, int ldw, const float *bias,
+                            const float *prev_Y, int ld_prev, const float *prev_affine, int C_in, pn2_stream_t stream) {
+    PN2_CHECK_ARG(dOut && out && arg && pool_ws && affine && dZp && red && W && bias && prev_Y && prev_affine && G > 0 && K > 0 && C > 0 &&
+                  C_in > 0 && ldo >= ((C + 3) & ~3) && ld_dout >= C && ldw >= C_in && ld_prev >= C_in);
+    int64_t gy = pn2_cdiv(G, 4 * 4);
+    if (gy > 1024) gy = 1024;
+    hipLaunchKernelGGL(pool_bwd_reduce_rec_kernel, dim3((unsigned)pn2_cdiv((C + 3) & ~3, 64), (unsigned)gy), dim3(256), 0, pn2_s(stream), dOut,
+                       ld_dout, ldo, out, arg, reinterpret_cast<const float2 *>(pool_ws), C, affine, (C + 3) & ~3, G, K, C, dZp, red, W, ldw, bias,
+                       prev_Y, ld_prev, prev_affine, C_in);
+    return pn2_launch_status();
+}
+
 int pn2_pool_bwd_reduce(const float *dOut, int ldo, const float *out, const int32_t *arg, const float *Y, int ldy,
                         const float *affine, int64_t G, int K, int C, float *dZp, double *red, const pn2_bn_coef_tail *tail,
                         pn2_stream_t stream) {
@@ -1920,7 +1995,7 @@ int pn2_conv1x1_wgrad_cf(const float *dZ, int ldz, const float *coef, const floa
     hipStream_t s = pn2_s(stream);
     const int ldc = round4(M);
 #define PN2_CF_CASE(NBV)                                                                                                               \
-    case NBV: hipLaunchKernelGGL((wgrad_first_cf_kernel<NBV, U>), dim3((unsigned)grid), dim3(256), 0, s, dZ, ldz, coef, ldc, X, ldx, P, N, \
+    case NBV: PN2_NOTE_KERNEL(wgrad_first_cf_kernel<NBV, U>); hipLaunchKernelGGL((wgrad_first_cf_kernel<NBV, U>), dim3((unsigned)grid), dim3(256), 0, s, dZ, ldz, coef, ldc, X, ldx, P, N, \
                                  W, ldw, bias, part, mom, ticket, dW, lddw, lc); break;
     switch (M / 16) {
         PN2_CF_CASE(1) PN2_CF_CASE(2) PN2_CF_CASE(3) PN2_CF_CASE(4) PN2_CF_CASE(5) PN2_CF_CASE(6) PN2_CF_CASE(7) PN2_CF_CASE(8)

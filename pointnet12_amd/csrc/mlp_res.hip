@@ -512,6 +512,7 @@ int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, 
     if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(&bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF, NTHR>), raised) != PN2_OK)
         return PN2_ELAUNCH;
     const int64_t cap = (int64_t)pn2_num_cus() * (512 / NTHR);     // one 8-wave workgroup per CU, or two of four waves
+    PN2_NOTE_KERNEL(bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF, NTHR>);
     hipLaunchKernelGGL((bwd_res_kernel<CO_T, CI_T, POOL, MASKED, DEPTH, DBUF, NTHR>), dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(NTHR), lds, s, dy, Yp,
                        ldp, aff_p, W, ldw, tiles, dX, ldxo, red_p, dW, lddw, plan);
     return pn2_launch_status();
@@ -866,8 +867,463 @@ int launch_split_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p,
     static Pn2PerDevice raised;
     if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
     const int64_t chunks = tiles * (RES_BM / 32), cap = pn2_num_cus();
+    PN2_NOTE_KERNEL(kern);
     hipLaunchKernelGGL(kern, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(512), lds, s, dy, Yp, ldp, aff_p, W, ldw, chunks, dX, ldxo,
                        red_p, dW, lddw);
+    return pn2_launch_status();
+}
+
+// ----------------------------------------------------------------------------------------------- pooled last layer from its INPUT (round 6)
+// The backward of the LAST layer of a set-abstraction MLP (conv + BN + ReLU + max over groups of Kp rows) without that layer's
+// pre-BN output Y -- which the forward then never writes (pn2_conv1x1_fwd_pool with Y = NULL: statistics and pooling extrema come
+// out of the GEMM epilogue).  dZ is sparse there (one row per group and channel, D[p, c] = dZp[g, c] where p is the recorded
+// arg-max row), and the dense part of dY = c0 D + q1 (y - mean) + q0 is affine in y = W x + b, hence in the layer's input
+// x = relu(bn(Y_prev)), which the pass reads anyway:
+//     dX = [D | X] W2 + h      W2 = [diag(c0) W ; M],  M = W^T diag(q1) W  [Ci x Ci],  h = (q1 (b - mean) + q0)^T W     (cf_prep_kernel)
+//     dW = c0 o (D^T X) + q1 o (W (X^T X) + (b - mean) sx^T) + q0 sx^T,   sx = sum_p x_p                              (cf_finish_kernel)
+// split_bwd_res_kernel's chunk loop with these changes: no Y stream (bytes 4 P (2 C_in) instead of 4 P (C_out + 2 C_in)); the D image
+// is a select of the group's pre-split dZp quad (no BatchNorm arithmetic, no split per row); waves 0 .. CI_T - 1 own the dX tiles
+// and do NOTHING else (contraction over C_out + C_in: their fragment registers fill the file, the stagers' request registers do not
+// fit beside them); the other waves stage and own the tiles of T = X^T [D | X] (C_in x (C_out + C_in); Gram tiles below the
+// diagonal are mirrored at the flush), dealt so that the four SIMDs carry the same number of MFMAs.  T and sx leave as one slab per
+// workgroup (plain stores, summed in fixed order by cf_finish_kernel: no atomics, no zeroed scratch, run-to-run identical).
+// Roles by wave: 0 .. CI_T - 1 own the dX tiles; wave CI_T owns the GRAM part of T (all tiles X_i^T X_j, i <= j: the CI_T blocks of X
+// are read once per contraction block and serve as A and as B operands); waves CI_T + 1 .. CI_T + CO_T own one D COLUMN of T each
+// (tiles X_i^T D_nb, i < CI_T: the B fragments of D_nb are read once) and, with any wave left over, do all the staging.  (First
+// version: tiles dealt one by one to all non-dX waves, each tile reading its own six fragment sets -- the T waves sat on the LDS.
+// Ablation of that version, us at 1 M rows of 128 x 96: all 497, no T tiles 327, no staging 360, no dX MFMAs 433, no epilogue 460.)
+template <int CO_T, int CI_T>
+__global__ __launch_bounds__(512, 1) void split_bwd_cf_kernel(const float *dZp, const int32_t *arg, int ldo, int kshift, const float *W2 /* [Co + Ci][Ci], then h[Ci] */,
+                                                              const float *Yp, int ldp, const float *aff_p, int64_t chunks, float *dX, int ldxo, double *red_p,
+                                                              float *slab) {
+    constexpr int Co = 32 * CO_T, Ci = 32 * CI_T, BP = 32, QD = Co / 4, QP = Ci / 4, LDP = Ci + 4;
+    constexpr int PANEL = BP * 256, BUF = 6 * PANEL;                // D hi / mid / lo, X hi / mid / lo (one 128-channel panel per piece)
+    constexpr int KBX = Co / 16, KBM = Ci / 16, KBT = KBX + KBM;    // contraction blocks of a dX tile: D W', then X M
+    constexpr int NS = 8 - CI_T - 1, NTS = 64 * NS;                 // staging waves (CI_T + 1 .. 7) and their threads
+    constexpr int NGT = CI_T * (CI_T + 1) / 2, LDT = Co + Ci + 4;   // Gram tiles; slab: T[Ci][LDT], column Co + Ci = sx
+    static_assert(NS >= CO_T, "one staging wave per D column");
+    constexpr int RPP = NTS / QD, IT_D = (BP + RPP - 1) / RPP, IT_P = (BP * QP + NTS - 1) / NTS;
+    static_assert(NTS % QD == 0, "one channel quad of D per staging thread");
+    unsigned char *lds_b = reinterpret_cast<unsigned char *>(res_lds);
+    float *Yps = res_lds + (2 * BUF) / 4;                           // [2][BP][LDP]: the raw Y_prev chunk
+    float *xtab = Yps + 2 * BP * LDP;                               // mean, scale, beta of the previous BatchNorm: 3 * Ci
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
+    const int G = gridDim.x;
+    RABS(wave, 0)
+    for (int i = t; i < 3 * Ci; i += 512) xtab[i] = aff_p[i];
+
+    const bool has_dx = wave < CI_T, is_gram = wave == CI_T;
+    const int ecol = (has_dx ? wave : 0) * 32 + l31;
+    const int ts = wave <= CI_T ? 0 : t - 64 * (CI_T + 1);          // staging thread index
+    struct Raw { float4 z; int4 a; float4 p[IT_P]; };
+    Raw raw;
+    auto p_item = [&](int i, int &row, int &q) { const int idx = (NTS * (i + 1) > BP * QP) ? min(ts + NTS * i, BP * QP - 1) : ts + NTS * i; row = idx / QP; q = idx - row * QP; };
+    auto fetch = [&](int64_t chunk) {
+        const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;      // past the end: re-read the last chunk (never used)
+        const unsigned o = (m0 >> kshift) * (unsigned)ldo + 4u * (unsigned)(ts % QD);   // the chunk lies inside ONE group
+        raw.z = ld4(dZp + o);
+        raw.a = ld4i(arg + o);
+#pragma unroll
+        for (int i = 0; i < IT_P; ++i) {
+            int row, q;
+            p_item(i, row, q);
+            raw.p[i] = ld4(Yp + ((m0 + (unsigned)row) * (unsigned)ldp + 4u * (unsigned)q));
+        }
+    };
+    auto store_split = [&](unsigned char *img, int row, int q, const float4 v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2(v.x, v.y, h0, m0, l0);
+        split2(v.z, v.w, h1, m1, l1);
+        const unsigned o = tr_img_off(row, q >> 1) + 8u * (unsigned)(q & 1);
+        *reinterpret_cast<uint2 *>(img + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(img + o + PANEL) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2 *>(img + o + 2 * PANEL) = make_uint2(l0, l1);
+    };
+    auto stage = [&](int64_t chunk, int buf) {
+        unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * PANEL;
+        float *yp = Yps + buf * (BP * LDP);
+        const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;
+        const int kbase = (int)(m0 & ((1u << kshift) - 1u));
+        {   // D: the group's dZp quad, split ONCE; a row takes the pieces of the channels whose maximum sits in it, zeros elsewhere
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split2(raw.z.x, raw.z.y, h0, m0_, l0);
+            split2(raw.z.z, raw.z.w, h1, m1, l1);
+            const int q = ts % QD, r0 = ts / QD;
+            const int4 a = raw.a;
+#pragma unroll
+            for (int i = 0; i < IT_D; ++i) {
+                const int row = (RPP * (i + 1) > BP) ? min(r0 + RPP * i, BP - 1) : r0 + RPP * i;
+                const int k = kbase + row;
+                const unsigned k0 = (a.x == k ? 0x0000ffffu : 0u) | (a.y == k ? 0xffff0000u : 0u);
+                const unsigned k1 = (a.z == k ? 0x0000ffffu : 0u) | (a.w == k ? 0xffff0000u : 0u);
+                const unsigned o = tr_img_off(row, q >> 1) + 8u * (unsigned)(q & 1);
+                *reinterpret_cast<uint2 *>(ia + o) = make_uint2(h0 & k0, h1 & k1);
+                *reinterpret_cast<uint2 *>(ia + o + PANEL) = make_uint2(m0_ & k0, m1 & k1);
+                *reinterpret_cast<uint2 *>(ia + o + 2 * PANEL) = make_uint2(l0 & k0, l1 & k1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT_P; ++i) {
+            int row, q;
+            p_item(i, row, q);
+            float4 x = raw.p[i];
+            *reinterpret_cast<float4 *>(&yp[row * LDP + 4 * q]) = x;
+            const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]), sc = *reinterpret_cast<const float4 *>(&xtab[Ci + 4 * q]);
+            const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * Ci + 4 * q]);
+            x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f); x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
+            x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f); x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+            store_split(ib, row, q, x);
+        }
+    };
+    auto raw_landed = [&]() {
+        asm volatile("" : "+v"(raw.z.x), "+v"(raw.z.y), "+v"(raw.z.z), "+v"(raw.z.w));
+        asm volatile("" : "+v"(raw.a.x), "+v"(raw.a.y), "+v"(raw.a.z), "+v"(raw.a.w));
+#pragma unroll
+        for (int i = 0; i < IT_P; ++i) asm volatile("" : "+v"(raw.p[i].x), "+v"(raw.p[i].y), "+v"(raw.p[i].z), "+v"(raw.p[i].w));
+    };
+    const int g16 = lane >> 4, j16 = lane & 15, tq = j16 >> 2, tp = j16 & 3;
+    auto frag_t = [&](const unsigned char *img, int cblk, int pb) {
+        const int c0 = (cblk * 32 + 16 * (g16 & 1)) >> 3;
+        SplitFrag f;
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int row = 16 * pb + 8 * (g16 >> 1) + 4 * r2 + tq;
+            const unsigned o = tr_img_off(row, c0 + (tp >> 1)) + 8u * (unsigned)(tp & 1);
+            const pn2_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                reinterpret_cast<__attribute__((address_space(3))) pn2_s16x4 *>((__attribute__((address_space(3))) unsigned char *)(img) + o));
+            const uint2 u = __builtin_bit_cast(uint2, v);
+            f.u[2 * r2] = u.x; f.u[2 * r2 + 1] = u.y;
+        }
+        return f;
+    };
+
+    if (has_dx) {
+        // ------------------------------------------------------------------------------------------------ dX waves
+        // W2[k][ecol], k = 16 kb + 8 lh + 0 .. 7: hi / mid in registers; lo of the D W' blocks in LDS (8 KiB per wave, written and
+        // read by this wave alone), lo of the X M blocks in registers
+        SplitFrag wh[KBT], wm[KBT], wl[KBM];
+        uint4 *wl_lds = reinterpret_cast<uint4 *>(xtab + 3 * Ci + (Ci % 4 ? 4 - Ci % 4 : 0)) + (size_t)wave * KBX * 64 + lane;
+        {
+            float v[KBT][8];
+#pragma unroll
+            for (int kb = 0; kb < KBT; ++kb)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[kb][e] = W2[(16 * kb + 8 * lh + e) * Ci + ecol];
+#pragma unroll
+            for (int kb = 0; kb < KBT; ++kb) {
+                SplitFrag lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(v[kb][2 * e], v[kb][2 * e + 1], wh[kb].u[e], wm[kb].u[e], lo.u[e]);
+                if (kb < KBX) wl_lds[kb * 64] = lo.q; else wl[kb < KBX ? 0 : kb - KBX] = lo;
+            }
+        }
+        Affine a(aff_p, Ci);
+        const float emu = a.mean[ecol], esc = a.scale[ecol], ebe = a.beta[ecol], eis = a.invstd[ecol];
+        const float eh = W2[(Co + Ci) * Ci + ecol];
+        double st0 = 0.0, st1 = 0.0, st2 = 0.0;
+        int64_t chunk = blockIdx.x;
+        int buf = 0;
+        __syncthreads();                                            // the tables are in place
+        RABS(wave, 1)
+        RSTAMP_DECL
+        while (chunk < chunks) {
+            __syncthreads();                                        // this chunk is staged in `buf`
+            RSTAMP(2)
+            const unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * PANEL;
+            f32x16 acc, acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#ifndef PN2_X_CF_NODXM
+#pragma unroll
+            for (int kb = 0; kb < KBT; ++kb) {
+                const unsigned char *img = kb < KBX ? ia : ib;
+                const unsigned o = tr_img_off(l31, 2 * (kb < KBX ? kb : kb - KBX) + lh);
+                SplitFrag ah, am, al, wlo;
+                ah.q = *reinterpret_cast<const uint4 *>(img + o);
+                am.q = *reinterpret_cast<const uint4 *>(img + o + PANEL);
+                al.q = *reinterpret_cast<const uint4 *>(img + o + 2 * PANEL);
+                if (kb < KBX) wlo.q = wl_lds[kb * 64]; else wlo = wl[kb < KBX ? 0 : kb - KBX];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, wh[kb].v, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wlo.v, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wm[kb].v, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, wh[kb].v, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wm[kb].v, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, wh[kb].v, acc2, 0, 0, 0);
+            }
+#endif
+#ifdef PN2_STAMP
+            { float a0_ = acc[0] + acc2[0]; asm volatile("" : "+v"(a0_)); }
+#endif
+            RSTAMP(3)
+#ifdef PN2_X_CF_NOEPI
+            if (acc[0] == 1.2345e-33f) dX[0] = acc2[1];
+            chunk += G; buf ^= 1;
+            continue;
+#endif
+            const float *yq = Yps + buf * (BP * LDP) + (4 * lh) * LDP + ecol;
+            float yv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yv[r] = yq[((r & 3) + 8 * (r >> 2)) * LDP];
+            float *xb = dX + ((size_t)chunk * BP + 4 * lh) * (unsigned)ldxo;
+            unsigned offx = (unsigned)ecol;
+            asm volatile("" : "+v"(offx));
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float y = yv[r];
+                const float x = bn_act(y, emu, esc, ebe);
+                float dz = (acc[r] + acc2[r]) + eh;
+                dz = x > 0.f ? dz : 0.f;
+                s0 += dz;
+                s1 = __builtin_fmaf(dz, (y - emu) * eis, s1);
+                s2 += fmaxf(x, 0.f);
+                PN2_STREAM_STORE(dz, xb + offx);
+                offx += ((r & 3) == 3 ? 5u : 1u) * (unsigned)ldxo;
+            }
+            st0 += (double)s0; st1 += (double)s1; st2 += (double)s2;
+            RSTAMP(4)
+            chunk += G;
+            buf ^= 1;
+        }
+        RSTAMP_FLUSH(wave)
+        RABS(wave, 2)
+        st0 += __shfl_xor(st0, 32, 64);
+        st1 += __shfl_xor(st1, 32, 64);
+        st2 += __shfl_xor(st2, 32, 64);
+        if (lh == 0) {
+            if (red_p != nullptr) {
+                double *rep = red_p + (size_t)(blockIdx.x % PN2_STAT_REPLICAS) * 2 * Ci;
+                atomicAdd(rep + ecol, st0);
+                atomicAdd(rep + Ci + ecol, st1);
+            }
+            slab[(size_t)blockIdx.x * (Ci * LDT) + (size_t)ecol * LDT + Co + Ci] = (float)st2;
+        }
+    } else {
+        // the six products of a block, smallest terms first: (A piece, B piece) = (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        auto mm2 = [&](f32x16 &c0, const SplitFrag (&a0)[3], const SplitFrag (&b0)[3], f32x16 &c1, const SplitFrag (&a1)[3], const SplitFrag (&b1)[3]) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {                           // two tiles, alternating: back-to-back MFMAs on one accumulator wait for each other
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[q]].v, b0[PB[q]].v, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[q]].v, b1[PB[q]].v, c1, 0, 0, 0);
+            }
+        };
+        auto mm1 = [&](f32x16 &c0, const SplitFrag (&a0)[3], const SplitFrag (&b0)[3]) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[q]].v, b0[PB[q]].v, c0, 0, 0, 0);
+        };
+        auto frag3 = [&](const unsigned char *img, int blk, int pb, SplitFrag (&f)[3]) {
+            f[0] = frag_t(img, blk, pb); f[1] = frag_t(img + PANEL, blk, pb); f[2] = frag_t(img + 2 * PANEL, blk, pb);
+        };
+        float *sl = slab + (size_t)blockIdx.x * (Ci * LDT);
+        if (is_gram) {
+            // ------------------------------------------------------------------------------------------------ Gram wave
+            f32x16 accg[NGT];                                       // tile (i <= j) at index j (j + 1) / 2 + i
+#pragma unroll
+            for (int j = 0; j < NGT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accg[j][r] = 0.f;
+            int64_t chunk = blockIdx.x;
+            int buf = 0;
+            __syncthreads();                                        // the tables are in place
+            RABS(wave, 1)
+            RSTAMP_DECL
+            while (chunk < chunks) {
+                __syncthreads();
+                RSTAMP(2)
+#ifndef PN2_X_CF_NOT
+                const unsigned char *ib = lds_b + buf * BUF + 3 * PANEL;
+#pragma unroll
+                for (int pb = 0; pb < BP / 16; ++pb) {
+                    SplitFrag fx[CI_T][3];
+#pragma unroll
+                    for (int i = 0; i < CI_T; ++i) frag3(ib, i, pb, fx[i]);
+                    if constexpr (CI_T == 1) {
+                        mm1(accg[0], fx[0], fx[0]);
+                    } else if constexpr (CI_T == 2) {
+                        mm2(accg[0], fx[0], fx[0], accg[1], fx[0], fx[1]);
+                        mm1(accg[2], fx[1], fx[1]);
+                    } else {
+                        static_assert(CI_T <= 3, "Gram tiles");
+                        mm2(accg[0], fx[0], fx[0], accg[1], fx[0], fx[1]);
+                        mm2(accg[2], fx[1], fx[1], accg[3], fx[0], fx[2]);
+                        mm2(accg[4], fx[1], fx[2], accg[5], fx[2], fx[2]);
+                    }
+                }
+#endif
+                RSTAMP(3)
+                chunk += G;
+                buf ^= 1;
+            }
+            RSTAMP_FLUSH(wave)
+            RABS(wave, 2)
+#pragma unroll
+            for (int j = 0; j < CI_T; ++j)
+#pragma unroll
+                for (int i = 0; i <= j; ++i) {
+                    const f32x16 &acc = accg[j * (j + 1) / 2 + i];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sl[(i * 32 + acc_row(r, lh)) * LDT + Co + j * 32 + l31] = acc[r];
+                    if (i != j) {                                   // above the diagonal: its mirror image too
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sl[(j * 32 + l31) * LDT + Co + i * 32 + acc_row(r, lh)] = acc[r];
+                    }
+                }
+        } else {
+            // ------------------------------------------------------------------------------------------------ staging waves (one D column of T each)
+            f32x16 accw[CI_T];
+#pragma unroll
+            for (int j = 0; j < CI_T; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+            const int nb = wave - CI_T - 1 < CO_T ? wave - CI_T - 1 : -1;             // (uniform) this wave's column of D, -1: staging only
+            int64_t chunk = blockIdx.x;
+            fetch(chunk);
+            __syncthreads();                                        // the tables are in place
+            stage(chunk, 0);
+            fetch(chunk + G);
+            raw_landed();
+            int buf = 0;
+            RABS(wave, 1)
+            RSTAMP_DECL
+            while (chunk < chunks) {
+                __syncthreads();                                    // this chunk is staged in `buf`; every wave is done with buf ^ 1
+                RSTAMP(2)
+#ifndef PN2_X_CF_NOSTAGE
+                stage(chunk + G, buf ^ 1);
+#endif
+                RSTAMP(0)
+#ifndef PN2_X_CF_NOFETCH
+                fetch(chunk + 2 * (int64_t)G);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                RSTAMP(1)
+#ifndef PN2_X_CF_NOT
+                if (nb >= 0) {
+                    const unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * PANEL;
+#pragma unroll
+                    for (int pb = 0; pb < BP / 16; ++pb) {
+                        SplitFrag fb[3], fa0[3], fa1[3];
+                        frag3(ia, nb, pb, fb);
+                        frag3(ib, 0, pb, fa0);
+                        if constexpr (CI_T >= 2) {
+                            frag3(ib, 1, pb, fa1);
+                            mm2(accw[0], fa0, fb, accw[CI_T >= 2 ? 1 : 0], fa1, fb);
+                            if constexpr (CI_T == 3) {
+                                frag3(ib, 2, pb, fa0);
+                                mm1(accw[CI_T == 3 ? 2 : 0], fa0, fb);
+                            }
+                        } else {
+                            mm1(accw[0], fa0, fb);
+                        }
+                    }
+                }
+#endif
+                RSTAMP(3)
+                chunk += G;
+                buf ^= 1;
+            }
+            RSTAMP_FLUSH(wave)
+            RABS(wave, 2)
+            if (nb >= 0) {
+#pragma unroll
+                for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sl[(i * 32 + acc_row(r, lh)) * LDT + nb * 32 + l31] = accw[i][r];
+            }
+        }
+    }
+    RABS(wave, 3)
+}
+
+// W2 = [diag(c0) W ; W^T diag(q1) W] and h = (q1 (b - mean) + q0)^T W from the layer's coefficient block (filled here from the
+// reductions when the caller hands them over: every block recomputes it, block 0 writes dgamma / dbeta), in fp64.
+__global__ __launch_bounds__(128) void cf_prep_kernel(LazyCoef lc, const float *coef, int ldc, const float *__restrict__ W, int ldw,
+                                                      const float *__restrict__ bias, int Co, int Ci, float *__restrict__ W2) {
+    __shared__ double fac[256];                                     // (Co <= 256)
+    lazy_coef_prologue(lc);
+    const float *c0 = coef, *q1 = coef + ldc, *q0 = coef + 2 * ldc, *mean = coef + 3 * ldc;
+    const int r = blockIdx.x;
+    if (r < Co) {
+        for (int i = threadIdx.x; i < Ci; i += 128) W2[r * Ci + i] = c0[r] * W[(int64_t)r * ldw + i];
+        return;
+    }
+    // row Co + j of W2: M[j, i] = sum_c (W[c, j] q1[c]) W[c, i];  the last row: h[i] = sum_c (q1 (b - mean) + q0)[c] W[c, i]
+    const int j = r - Co;
+    for (int c = threadIdx.x; c < Co; c += 128)
+        fac[c] = j == Ci ? ((double)q1[c] * ((double)bias[c] - (double)mean[c]) + (double)q0[c]) : (double)W[(int64_t)c * ldw + j] * (double)q1[c];
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ci; i += 128) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;            // (Co % 4 == 0: the shapes this path takes)
+#pragma unroll 4
+        for (int c = 0; c < Co; c += 4) {
+            s0 += fac[c] * (double)W[(int64_t)c * ldw + i];
+            s1 += fac[c + 1] * (double)W[(int64_t)(c + 1) * ldw + i];
+            s2 += fac[c + 2] * (double)W[(int64_t)(c + 2) * ldw + i];
+            s3 += fac[c + 3] * (double)W[(int64_t)(c + 3) * ldw + i];
+        }
+        W2[r * Ci + i] = (float)((s0 + s1) + (s2 + s3));
+    }
+}
+
+// dW[c, i] += c0 (D^T X)[c, i] + q1 (sum_j W[c, j] Gram[j, i] + (b - mean) sx[i]) + q0 sx[i]; block i sums row i of every workgroup's
+// slab in a fixed order (fp64) first.  dW is accumulated into (the gradient bucket's contract), this launch is its only writer.
+__global__ __launch_bounds__(256) void cf_finish_kernel(const float *__restrict__ slab, int nslab, int Co, int Ci, const float *coef, int ldc,
+                                                        const float *__restrict__ W, int ldw, const float *__restrict__ bias,
+                                                        float *__restrict__ dW, int lddw) {
+    extern __shared__ double cf_row[];                              // [4][LDT] partial sums, then the row in cf_row[0 .. LDT)
+    const int i = blockIdx.x, LDT = Co + Ci + 4, NQ = LDT / 4;      // (LDT <= 256: one float4 column per thread of a 64-thread group)
+    const int q = threadIdx.x & 63, sg = threadIdx.x >> 6;          // column quad, slab group (slabs sg, sg + 4, ...)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (q < NQ) {
+        const float *p = slab + (size_t)i * LDT + 4 * q;
+        const size_t ss = (size_t)Ci * LDT;
+        int w = sg;
+        for (; w + 28 < nslab; w += 32) {                           // eight requests in flight per thread, summed in slab order
+            float4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ld4(p + (size_t)(w + 4 * e) * ss);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0 += (double)v[e].x; a1 += (double)v[e].y; a2 += (double)v[e].z; a3 += (double)v[e].w; }
+        }
+        for (; w < nslab; w += 4) {
+            const float4 v = ld4(p + (size_t)w * ss);
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+        double *d = cf_row + sg * LDT + 4 * q;
+        d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < LDT; n += 256) cf_row[n] = (cf_row[n] + cf_row[LDT + n]) + (cf_row[2 * LDT + n] + cf_row[3 * LDT + n]);
+    __syncthreads();
+    const float *c0 = coef, *q1 = coef + ldc, *q0 = coef + 2 * ldc, *mean = coef + 3 * ldc;
+    const double sx = cf_row[Co + Ci];
+    for (int c = threadIdx.x; c < Co; c += 256) {
+        double dot = 0.0;
+        for (int j = 0; j < Ci; ++j) dot += (double)W[(int64_t)c * ldw + j] * cf_row[Co + j];
+        const double g = (double)c0[c] * cf_row[c] + (double)q1[c] * (dot + ((double)bias[c] - (double)mean[c]) * sx) + (double)q0[c] * sx;
+        dW[(int64_t)c * lddw + i] += (float)g;
+    }
+}
+
+template <int CO_T, int CI_T>
+int launch_split_bwd_cf(const float *dZp, const int32_t *arg, int ldo, int kshift, const float *coef, LazyCoef lc, const float *W, int ldw,
+                        const float *bias, const float *Yp, int ldp, const float *aff_p, int64_t P, float *dX, int ldxo, double *red_p,
+                        float *dW, int lddw, float *scratch, hipStream_t s) {
+    constexpr int Co = 32 * CO_T, Ci = 32 * CI_T, LDT = Co + Ci + 4;
+    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 3 * Ci) + (size_t)CI_T * (Co / 16) * 1024;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = split_bwd_cf_kernel<CO_T, CI_T>;
+    static Pn2PerDevice raised;
+    if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
+    float *W2 = scratch, *slab = scratch + (((Co + Ci + 1) * Ci + 63) & ~63);
+    const int64_t chunks = P / 32, cap = pn2_num_cus() < 256 ? pn2_num_cus() : 256;
+    const int grid = (int)(chunks < cap ? chunks : cap);
+    hipLaunchKernelGGL(cf_prep_kernel, dim3(Co + Ci + 1), dim3(128), 0, s, lc, coef, (Co + 3) & ~3, W, ldw, bias, Co, Ci, W2);
+    PN2_NOTE_KERNEL(kern);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, dZp, arg, ldo, kshift, W2, Yp, ldp, aff_p, chunks, dX, ldxo, red_p, slab);
+    hipLaunchKernelGGL(cf_finish_kernel, dim3(Ci), dim3(256), sizeof(double) * 4 * LDT, s, slab, grid, Co, Ci, coef, (Co + 3) & ~3, W, ldw, bias,
+                       dW, lddw);
     return pn2_launch_status();
 }
 
@@ -1187,6 +1643,7 @@ int launch_fwd_res(const float *X, int ldx, const float *aff, const float *W, in
     const int64_t slabs = P / 32;                                  // whole slabs; the caller handles P % 32
     int64_t grid = pn2_cdiv(slabs / (POOL ? pool.U : 1), nw);
     if (grid > pn2_num_cus()) grid = pn2_num_cus();
+    PN2_NOTE_KERNEL(fwd_res_kernel<K_T, N_T, ACT, POOL>);
     hipLaunchKernelGGL((fwd_res_kernel<K_T, N_T, ACT, POOL>), dim3((unsigned)grid), dim3(64 * nw), lds, s, X, ldx, aff, W, ldw, bias, Y, ldy,
                        slabs, stats, pool);
     return pn2_launch_status();
@@ -1304,7 +1761,9 @@ __global__ __launch_bounds__(256) void bn_pool_select_kernel(const float2 *__res
 extern "C" int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_affine, const float *W, int ldw, const float *bias, float *Y,
                                     int ldy, int64_t P, int K, int N, double *stats, int Kpool, const float *gamma, float *pool_ws,
                                     const pn2_bn_lazy *in_lazy, pn2_stream_t stream) {
-    PN2_CHECK_ARG(X && in_affine && W && bias && Y && stats && gamma && pool_ws && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && Kpool > 0);
+    // Y == NULL: the pre-BN output is not written at all (statistics and extrema only) -- taken by the bf16-pipe forms of the
+    // register-stationary forward alone (PN2_EUNSUPPORTED otherwise); the layer's backward then runs on its input (pn2_conv1x1_bwd_cf)
+    PN2_CHECK_ARG(X && in_affine && W && bias && stats && gamma && pool_ws && P > 0 && P < (1LL << 31) && K > 0 && N > 0 && Kpool > 0);
     PN2_CHECK_ARG(lazy_bn_ok(in_lazy, in_affine, K));
     PN2_CHECK_ARG(ldx % 4 == 0 && ldx >= K && ldw >= K && ldy % 4 == 0 && ldy >= N);
     PN2_CHECK_ARG((reinterpret_cast<uintptr_t>(pool_ws) & 15) == 0);
@@ -1314,6 +1773,7 @@ extern "C" int pn2_conv1x1_fwd_pool(const float *X, int ldx, const float *in_aff
                                     Kpool, gamma, pool_ws);
         if (rc != PN2_EUNSUPPORTED) return rc;
     }
+    if (Y == nullptr) return PN2_EUNSUPPORTED;
     if (!pn2_res_supported(P, N, K) || P % 32 != 0 || P % Kpool != 0 || !(Kpool == 16 || Kpool % 32 == 0)) return PN2_EUNSUPPORTED;
     ResPool pool;
     pool.rec = reinterpret_cast<float2 *>(pool_ws);
@@ -1377,4 +1837,43 @@ extern "C" int pn2_conv1x1_bwd(const float *dZ, int ldz, const float *dZp, int l
     if (rc != PN2_OK) return rc;
     return pn2_conv1x1_wgrad(dZt, ldz, dZpt, ldo, argt, Kpool, Y + P_full * ldy, ldy, coef, prev_Y + P_full * ld_prev, ld_prev, prev_affine,
                              dW, lddw, nullptr, tail, C_out, C_in, nullptr, stream);
+}
+
+// ----------------------------------------------------------------------------------------------- pooled last layer from its input: entry points
+static bool cf_shape(int C_out, int C_in) { return C_out == 128 && (C_in == 96 || C_in == 64); }
+
+extern "C" int pn2_conv1x1_bwd_cf_supported(int64_t P, int C_out, int C_in, int Kpool) {
+    if (!(pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_RES) && pn2_opt(PN2_OPT_POOL_CF))) return 0;
+    if (!pn2_res_supported(P, C_out, C_in) || !cf_shape(C_out, C_in)) return 0;
+    // 128 x 64: the forward does not gain from the missing store (its kernel is bound by its epilogue: 103 -> 100 us at 524 288 rows)
+    // and this backward costs 30 us more than the Y-reading one: off unless POOL_CF >= 2
+    if (C_in == 64 && pn2_opt(PN2_OPT_POOL_CF) < 2) return 0;
+    if (Kpool < 32 || (Kpool & (Kpool - 1)) != 0 || P % Kpool != 0) return 0;
+    if (P * (int64_t)std::max(C_out, C_in) >= (1LL << 32)) return 0;           // 32-bit element offsets inside the kernel
+    return 1;
+}
+
+extern "C" int64_t pn2_conv1x1_bwd_cf_scratch_bytes(int C_out, int C_in) {
+    if (!cf_shape(C_out, C_in)) return 0;
+    const int64_t w2 = (((int64_t)(C_out + C_in + 1) * C_in + 63) & ~63LL);
+    return 4 * (w2 + 256LL * C_in * (C_out + C_in + 4));
+}
+
+extern "C" int pn2_conv1x1_bwd_cf(const float *dZp, int ldo, const int32_t *arg, int Kpool, const float *coef, const float *W, int ldw,
+                                  const float *bias, const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
+                                  double *prev_red, float *dW, int lddw, int64_t P, int C_out, int C_in, const pn2_bn_coef_lazy *coef_lazy,
+                                  float *scratch, pn2_stream_t stream) {
+    PN2_CHECK_ARG(dZp && arg && coef && W && bias && prev_Y && prev_affine && dXout && dW && scratch && P > 0 && P < (1LL << 31));
+    PN2_CHECK_ARG(lazy_coef_ok(coef_lazy, coef, C_out));
+    PN2_CHECK_ARG(ldw >= C_in && lddw >= C_in && ld_prev % 4 == 0 && ld_prev >= C_in && ldxo >= C_in && ldo % 4 == 0 && ldo >= C_out);
+    PN2_CHECK_ARG((reinterpret_cast<uintptr_t>(scratch) & 255) == 0 && (reinterpret_cast<uintptr_t>(prev_Y) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(dZp) & 15) == 0 && (reinterpret_cast<uintptr_t>(arg) & 15) == 0);
+    if (!pn2_conv1x1_bwd_cf_supported(P, C_out, C_in, Kpool)) return PN2_EUNSUPPORTED;
+    const int64_t ld_max = std::max(std::max((int64_t)ld_prev, (int64_t)ldxo), (int64_t)ldo);
+    if (P * ld_max >= (1LL << 32)) return PN2_EUNSUPPORTED;
+    const int kshift = pow2_shift(Kpool);
+    const LazyCoef lc = make_lazy_coef(coef_lazy);
+    hipStream_t s = pn2_s(stream);
+    if (C_in == 96) return launch_split_bwd_cf<4, 3>(dZp, arg, ldo, kshift, coef, lc, W, ldw, bias, prev_Y, ld_prev, prev_affine, P, dXout, ldxo, prev_red, dW, lddw, scratch, s);
+    return launch_split_bwd_cf<4, 2>(dZp, arg, ldo, kshift, coef, lc, W, ldw, bias, prev_Y, ld_prev, prev_affine, P, dXout, ldxo, prev_red, dW, lddw, scratch, s);
 }

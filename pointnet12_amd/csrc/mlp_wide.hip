@@ -462,6 +462,7 @@ int launch_regw(const RegwArgs &g, hipStream_t s) {
     static Pn2PerDevice raised;
     if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
     const int64_t cap = pn2_num_cus();
+    PN2_NOTE_KERNEL(kern);
     hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles < cap ? g.tiles : cap)), dim3(64 * NCB * RS), lds, s, g);
     return pn2_launch_status();
 }
@@ -833,6 +834,7 @@ int launch_ring_fwd_nx(const RegwArgs &g, hipStream_t s) {
     static Pn2PerDevice raised;
     if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
     const int64_t cap = pn2_num_cus();
+    PN2_NOTE_KERNEL(kern);
     hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles < cap ? g.tiles : cap)), dim3(64 * NCB * RS), lds, s, g);
     return pn2_launch_status();
 }
@@ -1259,8 +1261,11 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
         raw_landed();
         // ---- epilogue straight from the accumulators (the layout of v_mfma_f32_32x32x2_f32: column on the lane); instantiated
         // twice where N is ragged: the full column blocks take the copy without column predicates
-        auto epilogue = [&](auto all_tag) {
+        auto epilogue = [&](auto all_tag, auto store_tag) {
             constexpr bool ALLC = decltype(all_tag)::value;
+            // STORE = false (pooled last layer only, g.Out == nullptr): Y never leaves the chip -- the statistics and the pooling
+            // extrema come from the accumulators, and the layer's backward runs on its INPUT (split_bwd_res_kernel, CF)
+            constexpr bool STORE = decltype(store_tag)::value;
             const unsigned row0 = (unsigned)tile * BM + rs * TM * 32 + 4 * lh;
             unsigned lo = (unsigned)n;
             asm volatile("" : "+v"(lo));
@@ -1282,7 +1287,7 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
                     for (int r = 0; r < 16; ++r) {
                         static_assert(KS == 1 || EPI != EPI_FWD, "the K split serves the data gradient only");
                         const float y = acc[i][r] + e0;
-                        if (ALLC || n < N4) PN2_STREAM_STORE(y, yb + off);      // pad columns receive exact zeros (w = bias = 0)
+                        if (STORE && (ALLC || n < N4)) PN2_STREAM_STORE(y, yb + off);      // pad columns receive exact zeros (w = bias = 0)
                         s0 += y;
                         s1 = __builtin_fmaf(y, y, s1);
                         if (FPOOL > 0) {
@@ -1340,7 +1345,13 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
             }
             st0 += (double)s0; st1 += (double)s1;
         };
-        if (NX || all_cols) epilogue(pn2_true{}); else epilogue(pn2_false{});
+        if constexpr (EPI == EPI_FWD && FPOOL > 0) {
+            if (g.Out == nullptr) { if (NX || all_cols) epilogue(pn2_true{}, pn2_false{}); else epilogue(pn2_false{}, pn2_false{}); }
+            else if (NX || all_cols) epilogue(pn2_true{}, pn2_true{});
+            else epilogue(pn2_false{}, pn2_true{});
+        } else {
+            if (NX || all_cols) epilogue(pn2_true{}, pn2_true{}); else epilogue(pn2_false{}, pn2_true{});
+        }
         WSTAMP(4)
         ++seq;
         tile = tile_next;
@@ -1376,7 +1387,11 @@ int launch_split(const RegwArgs &g, hipStream_t s) {
     static Pn2PerDevice raised;
     if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
     constexpr int SUB = (EPI == EPI_FWD && PKP > BM) ? PKP / BM : 1;
-    const int64_t cap = pn2_num_cus() / NG, units = g.tiles / SUB;
+    // four-wave workgroups fit a CU twice (launch bounds, LDS): option SPLIT_WG2 lets the grid say so (two co-resident workgroups:
+    // one's staging / epilogue under the other's MFMAs)
+    const int64_t per_cu = (NCB * RS * KS <= 4 && pn2_opt(PN2_OPT_SPLIT_WG2)) ? 2 : 1;
+    const int64_t cap = per_cu * pn2_num_cus() / NG, units = g.tiles / SUB;
+    PN2_NOTE_KERNEL(kern);
     hipLaunchKernelGGL(kern, dim3((unsigned)(units < cap ? units : cap), NG), dim3(64 * NCB * RS * KS), lds, s, g);
     return pn2_launch_status();
 }
@@ -1420,7 +1435,7 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
     if (pn2_opt(PN2_OPT_SPLIT) && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (ldw & 3) == 0) {
         const bool pool_ok = Kpool == 0 || (in_affine && pool_gamma && pool_ws && pn2_opt(PN2_OPT_WIDE_POOL) && P % 128 == 0);
 #define SPLIT_FWD(KK, NN, NCB, RS, TM, PKP)                                                                              \
-        if (K == KK && N == NN && Kpool == PKP && pool_ok) {                                                             \
+        if (K == KK && N == NN && Kpool == PKP && pool_ok && (Y != nullptr || PKP > 0)) {                                \
             constexpr int BM = 32 * TM * RS;                                                                             \
             g.tiles = P / BM;                                                                                            \
             if (PKP > 0) g.tiles = (P / (PKP > BM ? PKP : BM)) * ((PKP > BM ? PKP : BM) / BM);                           \
@@ -1450,6 +1465,7 @@ int pn2_wide_fwd(const float *X, int ldx, const float *in_affine, const float *W
 #undef SPLIT_FWD
         *rows_done = 0;
     }
+    if (Y == nullptr) return PN2_EUNSUPPORTED;                      // (only the pooled bf16-pipe forms above run without an output)
     if (Kpool > 0) {
         // the last layer of a pooled MLP: whole tiles only (a pooled launch has no streamed tail), needs an input affine block
         const int pool_on = pn2_opt(PN2_OPT_WIDE_POOL);
@@ -2056,6 +2072,7 @@ int launch_split_tn(WgradArgs g, hipStream_t s) {
     if (PKP > 0 && rows % PKP != 0 && PKP % rows != 0) rows = pn2_cdiv(rows, PKP) * PKP;   // chunks never straddle a group: BP | PKP
     g.rows_per_wg = rows;
     wgs = pn2_cdiv(g.P, rows);
+    PN2_NOTE_KERNEL(kern);
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * NW), lds, s, g);
     if (g.ws != nullptr) {                                          // (second phase as launch_wgrad_full's)
         const int rows_pad = MB * 32, ldn = NB * 32;
@@ -2083,6 +2100,7 @@ int launch_wgrad_full(WgradArgs g, hipStream_t s) {
     if (PKP > 0 && rows % PKP != 0 && PKP % rows != 0) rows = pn2_cdiv(rows, PKP) * PKP;   // chunks never straddle a group: BP | PKP
     g.rows_per_wg = rows;
     wgs = pn2_cdiv(g.P, rows);
+    PN2_NOTE_KERNEL(kern);
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * NW), lds, s, g);
     if (g.ws != nullptr) {
         const int rows_pad = MB * 32, ldn = NB * 32;

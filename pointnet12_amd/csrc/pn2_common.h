@@ -38,6 +38,7 @@ static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
     X(FPS_ROWS_MIN_PPT, 24) /* FPS rows kernel: points per thread from which it replaces the wave-level pruned kernel */ \
     X(FPS_ROWMAP, 2) /* FPS rows kernel: row ownership (0 contiguous run per wave, 1 round robin, 2 groups of four rows round robin) */ \
     X(FPS_SINGLE_MAX, 24576) /* largest cloud of the single-workgroup FPS kernel (clamped to 16384 .. 28672) */ \
+    X(FPS_PIECE, 0) /* 2048 < N <= 4096: the sampling chain as launches of this many iterations each (0: one launch); state through the workspace */ \
     X(FPS_COOP, 1) /* cooperative multi-workgroup FPS above FPS_SINGLE_MAX */ \
     X(FPS_PRUNE, 1) /* spatially pruned FPS kernels (8192 < N) */ \
     X(BQ_ORDER, 1) /* ball query: centres taken in Morton order (pn2_ball_query_ws) */ \
@@ -65,6 +66,8 @@ static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
     X(SPLIT_K256, 1) /* ... the pooled data gradients with C_out = 256 (contraction split over wave pairs) */ \
     X(SPLIT_NARROW, 1) /* ... also on the narrow sa1 forward layers the weight-resident kernels served */ \
     X(SPLIT_RES, 1) /* ... and the fused data + weight gradient of the narrow long layers (split_bwd_res_kernel) */ \
+    X(SPLIT_WG2, 0) /* ... its four-wave forms (sa1 of MSG) as two workgroups per CU */ \
+    X(POOL_CF, 1) /* ... the pooled last layers of sa1 (128 x 96, 128 x 64) WITHOUT their pre-BN output: forward stores nothing, backward from the input (split_bwd_cf_kernel) */ \
     X(SPLIT_RES_MIN_TILES_128, 1024) /* ... its 128 x 128 pair from this many 64-row tiles on (below: the streamed pair kernel) */ \
     X(SPLIT_MIN_ROWS_128, 98304) /* ... 128 -> 128 forward / data gradient from this many rows on (below: the streamed fp32 kernels) */ \
     X(RING, 0) /* forward: the LDS-DMA ring form of the register-stationary kernel (measured equal: DESIGN.md section 3) */ \
@@ -84,6 +87,13 @@ enum Pn2Option {
 };
 extern int pn2_option_table[PN2_OPT_COUNT];                          // api.hip
 static inline int pn2_opt(int id) { return __atomic_load_n(&pn2_option_table[id], __ATOMIC_RELAXED); }
+
+// ----------------------------------------------------------------------------- diagnostics
+// pn2_last_kernel() (include/pn2.h): the kernel (template instantiation) the calling thread's most recent GEMM launcher enqueued, as
+// the profiler prints it.  The launchers store the kernel's host-side function pointer (one thread-local store); nothing inside the
+// library reads it: bench.py prices each launch of its instrumented pass against the peak of the pipe that kernel runs on.
+extern thread_local const void *pn2_last_kernel_fn;                  // api.hip
+#define PN2_NOTE_KERNEL(...) (pn2_last_kernel_fn = reinterpret_cast<const void *>(__VA_ARGS__))
 
 // Current device, clamped to the per-device tables below (a process driving more than PN2_MAX_DEVICES GPUs shares the
 // last slot, which only costs it a redundant attribute call or a CU count of the wrong device for grid sizing).

@@ -1,4 +1,5 @@
-"""CPU, world_size 2, gloo: the flat gradient bucket + all-reduce reproduce the global-mean gradient."""
+"""CPU, gloo, world_size 2 / 4 / 8: the flat gradient bucket + all-reduce reproduce the global-mean gradient."""
+import pytest
 import os
 import socket
 
@@ -33,8 +34,8 @@ def _worker(rank, world, port, out):
             p.data.add_(1.0)
     parallel.broadcast_module(model)
     bucket = parallel.FlatGradBucket(model)
-    x = torch.randn(4, 5, 16, generator=torch.Generator().manual_seed(100))
-    lo, hi = parallel.shard_range(4, rank, world)
+    x = torch.randn(8, 5, 16, generator=torch.Generator().manual_seed(100))
+    lo, hi = parallel.shard_range(8, rank, world)
     assert bucket.use_comm_stream() is bucket and bucket.comm is None     # host tensors: there is no stream to move to
     for it in range(2):                # second pass checks zero() really clears the aliased grads
         bucket.wait_reduced()          # (the call sites of the GPU step; no-ops here)
@@ -49,19 +50,20 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_bucket_matches_per_replica_mean():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gloo_ranks_bucket_matches_per_replica_mean(world):
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
         flats = [out[r] for r in range(world)]
-    assert torch.equal(flats[0], flats[1])
+    assert all(torch.equal(flats[0], f) for f in flats[1:])
     # single process, batch split into per-replica BN groups (the DataParallel semantics)
-    x = torch.randn(4, 5, 16, generator=torch.Generator().manual_seed(100))
+    x = torch.randn(8, 5, 16, generator=torch.Generator().manual_seed(100))
+    per = 8 // world
     ref = None
     for r in range(world):
         model = _make_model()
-        model(x[2 * r:2 * r + 2]).square().mean().backward()
+        model(x[per * r:per * r + per]).square().mean().backward()
         g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
         ref = g if ref is None else ref + g
     ref /= world
@@ -169,24 +171,25 @@ def _oracle_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_run_of_the_oracle_network_equals_two_bn_groups():
-    """Two gloo ranks, each running the CPU restatement of SSG-SemSeg on its own two clouds (per-replica BatchNorm, as
-    the reference's nn.DataParallel, semseg.py:91) and averaging the flat bucket, against ONE process evaluating the
-    two shards as two BatchNorm groups and averaging the gradients: <= 1e-6 relative."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_run_of_the_oracle_network_equals_per_rank_bn_groups(world):
+    """World gloo ranks, each running the CPU restatement of SSG-SemSeg on its own clouds (4 / world of them; per-replica BatchNorm,
+    as the reference's nn.DataParallel, semseg.py:91) and averaging the flat bucket, against ONE process evaluating the
+    shards as separate BatchNorm groups and averaging the gradients: <= 1e-6 relative."""
     from oracle import torch_ref as T
-    world = 2
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_oracle_worker, args=(world, _free_port(), out), nprocs=world, join=True)
         res = [out[r] for r in range(world)]
-    assert torch.equal(res[0][0], res[1][0])                     # every rank holds the same averaged gradient
+    assert all(torch.equal(res[0][0], res[r][0]) for r in range(1, world))        # every rank holds the same averaged gradient
     torch.set_num_threads(2)
     pts, labels = _oracle_batch()
+    per = pts.shape[0] // world
     ref = None
     for r in range(world):
         net = _oracle_net()
         torch.manual_seed(100 + r)
-        T.seg_loss(net(pts[2 * r:2 * r + 2]), labels[2 * r:2 * r + 2]).backward()
+        T.seg_loss(net(pts[per * r:per * r + per]), labels[per * r:per * r + per]).backward()
         g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
         ref = g if ref is None else ref + g
         if r == 0:

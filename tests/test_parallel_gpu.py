@@ -201,3 +201,33 @@ def test_bench_self_launch_one_rank_through_torchrun(dev):
     assert len(line) == 1
     doc = json.loads(line[0])
     assert doc["n_gpus"] == 1 and doc["value"] > 1e6 and doc["config"]["parallelism"] == "dp1"
+
+
+def test_bench_two_ranks_on_one_device_or_records_the_refusal(dev):
+    """the N > 1 path of bench.py (RCCL communicator over two ranks, disjoint-shard check, comm-stream
+    verification, RCCL log parsing, all-reduce after every step, MAX over ranks) with a REAL peer -- two ranks on the one GPU of
+    this box (`--same-device`).  RCCL may refuse two ranks on one device ("Duplicate GPU detected"): then the refusal is what is
+    recorded (gpurun_out/rccl_same_device.txt) and the launch must have failed cleanly -- non-zero exit of the parent, no JSON
+    line, no hang (the parent starts its ranks as child processes and never re-execs)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--steps", "3", "--warmup", "2",
+                        "--workload", "ssg", "--batch", "4", "--no-cpu-baseline", "--no-roofline", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_same_device.txt"), "w") as f:
+        if p.returncode == 0:
+            assert len(lines) == 1, p.stdout[-2000:]
+            doc = json.loads(lines[0])
+            assert doc["n_gpus"] == 2 and doc["config"]["parallelism"] == "dp2" and doc["config"]["global_batch"] == 8
+            assert doc["rccl"]["first_cloud_per_rank"] == [0, 4] and doc["rccl"]["ranks"] == 2
+            assert doc["allreduce_ms"] > 0.0 and doc["rank_ms_per_step_max"] >= doc["rank_ms_per_step_min"] > 0.0
+            f.write("two ranks on one device: RCCL accepted\n" + json.dumps({k: doc[k] for k in ("ms_per_step", "allreduce_ms", "rccl", "config")}, indent=1) + "\n")
+        else:
+            refused = [ln for ln in p.stderr.splitlines() if "Duplicate GPU" in ln or "invalid usage" in ln.lower() or "ncclInvalidUsage" in ln]
+            f.write("two ranks on one device: launch failed with exit code %d\n" % p.returncode + "\n".join(refused[:6]) + "\n---- stderr tail\n" + p.stderr[-3000:])
+            assert not lines, "a failed launch must not print a result line"
+            assert refused, p.stderr[-3000:]            # the only accepted failure is RCCL's refusal of a duplicate device

@@ -197,11 +197,22 @@ def _hip_decisions(h_out, B):
             C, ld = chans[l + 1], (chans[l + 1] + 3) & ~3
             a = affs[l]
             mean, scale, beta = a[:C], a[ld:ld + C], a[2 * ld:2 * ld + C]
-            z = (Ys[l][:, :C] - mean).double() * scale.double() + beta.double()
-            m = z > 0
+            if Ys[l] is None:
+                # round 6: a pooled last layer that ran WITHOUT its pre-BN output (pn2_conv1x1_bwd_cf).  Its only ReLU decisions that
+                # reach the output or a gradient sit at the recorded arg-max rows, and there the decision is "pooled output > 0"
+                # (out = max(bn(y*), 0)): the mask holds exactly those; the other rows of a group never pass the forced gather
+                assert pool and l == L - 1
+                G = P // K
+                hit = out.view(G, -1)[:, :C] > 0
+                m = torch.zeros(G, K, C, dtype=torch.bool, device=out.device)
+                m.scatter_(1, arg.view(G, -1)[:, :C].long().unsqueeze(1), hit.unsqueeze(1))
+                m = m.view(P, C)
+            else:
+                z = (Ys[l][:, :C] - mean).double() * scale.double() + beta.double()
+                m = z > 0
             m = m.view(B, S, K, C).permute(0, 3, 2, 1) if pool else m.view(B, S, C).permute(0, 2, 1)
             masks.append(m.contiguous().cpu())
-            del z
+            z = None
         C = chans[-1]
         if pool:
             am = arg.view(B, S, -1)[:, :, :C].permute(0, 2, 1).contiguous().cpu().long()
@@ -209,7 +220,7 @@ def _hip_decisions(h_out, B):
         else:
             am = None
             carry.append(None)
-        stacks.append({"masks": masks, "argmax": am})
+        stacks.append({"masks": masks, "argmax": am, "last_mask_at_argmax_only": bool(pool and Ys[L - 1] is None)})
     return stacks, carry
 
 
@@ -219,7 +230,13 @@ def _count_decisions(hip, carry, ref):
         return None
     relu = amx = total = 0
     for h, c, r in zip(hip, carry, ref):
-        for mh, mr in zip(h["masks"], r["masks"]):
+        for l, (mh, mr) in enumerate(zip(h["masks"], r["masks"])):
+            if h.get("last_mask_at_argmax_only") and l == len(h["masks"]) - 1:
+                # (the output-free pooled last layer: its ReLU decisions exist at the recorded rows only -- compared there)
+                idx = h["argmax"].unsqueeze(2)                      # masks [B, C, K, S], arg-max [B, C, S]
+                relu += int((mh.gather(2, idx) != mr.gather(2, idx)).sum())
+                total += idx.numel()
+                continue
             relu += int((mh != mr).sum())
             total += mh.numel()
         if h["argmax"] is not None and r["argmax"] is not None:

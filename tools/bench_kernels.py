@@ -108,6 +108,26 @@ def main():
                 report("fwdpool%d" % Kp, (P, K, N), timeit(fnp, args.reps), 2.0 * P * K * N, 4.0 * (P * K + P * N + N * K))
             del X, Y
 
+    if args.which in ("bwdcf", "all"):
+        for P, Cl, Cp, Kp in BWD:
+            if not Kp or not lib.pn2_conv1x1_bwd_cf_supported(P, Cl, Cp, Kp):
+                continue
+            Yp, coef, affp, Wt, bias = rnd(P, r4(Cp)), affine(Cl), affine(Cp), rnd(Cl, Cp), rnd(Cl)
+            G = P // Kp
+            dOut = rnd(G, r4(Cl))
+            arg = torch.randint(0, Kp, (G, r4(Cl)), device=dev, dtype=torch.int32, generator=g)
+            dX = torch.empty(P, r4(Cp), device=dev)
+            red = torch.zeros(8 * 2 * Cp, device=dev, dtype=torch.float64)
+            dW = torch.zeros(Cl, Cp, device=dev)
+            scratch = torch.empty(int(lib.pn2_conv1x1_bwd_cf_scratch_bytes(Cl, Cp)), device=dev, dtype=torch.uint8)
+
+            def fn():
+                rc = lib.pn2_conv1x1_bwd_cf(p(dOut), r4(Cl), p(arg), Kp, p(coef), p(Wt), Cp, p(bias), p(Yp), r4(Cp), p(affp), p(dX), r4(Cp), p(red),
+                                            p(dW), Cp, P, Cl, Cp, None, p(scratch), st)
+                assert rc == 0
+            report("bwdcf", (P, Cl, Cp, Kp), timeit(fn, args.reps), 4.0 * P * Cl * Cp, 4.0 * (2 * P * Cp + 2 * Cl * Cp))
+            del Yp, dX
+
     for which in ("dgrad", "wgrad", "bwd", "pair"):
         if args.which not in (which, "all"):
             continue

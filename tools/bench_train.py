@@ -53,7 +53,7 @@ def main():
             for _ in range(20):
                 loader.prepare_batch(store, list(range(B)), N, train=True, rng=gen)
             torch.cuda.synchronize()
-        ker = float(np.median([a.elapsed_time(b) for _, _, a, b in calls])) * 1e3
+        ker = float(np.median([a.elapsed_time(b) for _, _, a, b, _k in calls])) * 1e3
         # algorithmic bytes per output point: choice 8 + raw row 16 + noise row 16 + label 4 + out 16 + label out 8
         print(json.dumps({"kernel": "pn2_prepare_clouds", "B": B, "M": M, "N": N, "kernel_us": round(ker, 2),
                           "GB/s": round(68.0 * B * N / ker / 1e3, 1), "prepare_batch_device_rng_us": round(whole, 1)}))

@@ -32,17 +32,31 @@ def family(name):
     return fam
 
 
-def load(path, counter):
+def load(path, counter, key=family):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            a = agg[family(r["Kernel_Name"])]
+            a = agg[key(r["Kernel_Name"])]
             a[0] += float(r["Counter_Value"])
             a[1] += 1
     return agg
 
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                     # noqa: E402  (csrc_digest: stamps the file; kernel_key: the per-kernel names bench.py prices)
+
 fetch, write, steps = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE"), int(sys.argv[3])
+# per kernel (template instantiation), per LAUNCH: what bench.py's roofline.kernels[].pmc_bytes quotes
+kf, kw = load(sys.argv[1], "FETCH_SIZE", bench.kernel_key), load(sys.argv[2], "WRITE_SIZE", bench.kernel_key)
+per_kernel = {}
+for k in sorted(set(kf) | set(kw)):
+    f, nf = kf.get(k, [0.0, 0])
+    w, nw = kw.get(k, [0.0, 0])
+    n = max(nf, nw)
+    if n and (2.0 * f + w) * 1024 / n > 1e6 and "at::" not in k:
+        per_kernel[k] = {"launches_per_step": n / steps, "hbm_bytes_per_launch": (2.0 * f + w) * 1024 / n,
+                         "hbm_read_bytes_per_launch": 2.0 * f * 1024 / n, "hbm_write_bytes_per_launch": w * 1024 / n}
 out = {}
 for fam in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(fam, [0.0, 0])
@@ -51,10 +65,8 @@ for fam in sorted(set(fetch) | set(write)):
     if rd + wr > 50e6:
         out[fam] = {"launches_per_step": nf / steps, "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
                     "hbm_bytes_per_step": rd + wr}
-import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench                                     # noqa: E402  (csrc_digest: stamps the file with the kernel sources it measured)
 total = sum(v["hbm_bytes_per_step"] for v in out.values())
 print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 (gfx950)",
                   "steps_in_run": steps, "csrc_sha256": bench.csrc_digest(), "hbm_bytes_per_step_listed_families": total,
-                  "families": out}, indent=1))
+                  "hbm_bytes_per_step_all_kernels": sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in per_kernel.values()),
+                  "families": out, "kernels": per_kernel}, indent=1))
