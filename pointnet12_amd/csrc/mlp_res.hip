@@ -543,8 +543,15 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     static_assert(!POOLED || NT % QD == 0, "pooled: one channel quad per thread");
     unsigned char *lds_b = reinterpret_cast<unsigned char *>(res_lds);
     float *Yps = res_lds + (2 * BUF) / 4;                           // [2][BP][LDP]: the raw Y_prev chunk
-    float *ctab = Yps + 2 * BP * LDP;                               // c0, q1, q0, mean of this layer: 4 * Co
-    float *xtab = ctab + 4 * Co;                                    // mean, scale, beta of the previous BatchNorm: 3 * Ci
+    // SIGN ALTERNATION (round 6).  v_mfma_f32_32x32x16_bf16 does not round its accumulation to nearest: against fp64 every product sum
+    // comes out LOW by ~1.4e-8 of its magnitude whatever its sign (tools/exp/split_bias_probe.py: mean error -1.4e-8 |dX| for dX > 0 and
+    // for dX < 0 alike; the fp32 MFMA: 1e-10).  Invisible per element, but the BatchNorm-backward sums add dX over 10^5 - 10^7 rows of
+    // mixed sign, where a one-sided error grows like P against a sum that grows like sqrt(P): 1.4e-6 of the sum at 2^17 rows, 5e-6 at
+    // 2^22.  So every ODD chunk is computed NEGATED -- dY and X are staged with the opposite sign (negated coefficient tables, a median
+    // in place of the maximum: no extra instruction; dW = (-dY)^T (-X) is unchanged), the dX tile gets its sign back in the epilogue --
+    // and the one-sided error alternates in sign from chunk to chunk: it cancels in every sum over rows.
+    float *ctab = Yps + 2 * BP * LDP;                               // [2][4 * Co]: c0, q1, q0, mean of this layer; then -c0, -q1, -q0, mean
+    float *xtab = ctab + 8 * Co;                                    // [2][3 * Ci]: mean, scale, beta of the previous BatchNorm; then mean, -scale, -beta
     // WL_LDS (C_out = 128 with C_in < 128): a dX wave's `lo` fragments -- the operand of one MFMA in six -- live in LDS, 8 KiB per
     // wave, written and read by that wave alone: 32 registers for the second accumulator (split_nt_kernel does the same at K = 196)
     constexpr bool WL_LDS = CO_T == 4 && CI_T < 4;
@@ -553,9 +560,9 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
 
     RABS(wave, 0)
     lazy_coef_prologue(dy.lc);
-    for (int i = t; i < 4 * Co; i += NT) ctab[i] = dy.coef[i];
+    for (int i = t; i < 4 * Co; i += NT) { const float v = dy.coef[i]; ctab[i] = v; ctab[4 * Co + i] = i < 3 * Co ? -v : v; }
     if (MASKED)
-        for (int i = t; i < 3 * Ci; i += NT) xtab[i] = aff_p[i];
+        for (int i = t; i < 3 * Ci; i += NT) { const float v = aff_p[i]; xtab[i] = v; xtab[3 * Ci + i] = i < Ci ? v : -v; }
 
     // ---- roles (the two kinds of wave run separate instantiations of the chunk loop: a dX wave's 96 fragment registers and a dW
     // wave's 64 accumulator registers then share the register file instead of adding up)
@@ -606,11 +613,15 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
         float *yp = Yps + buf * (BP * LDP);
         const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;
         const int kbase = POOLED ? (int)(m0 & ((1u << dy.kshift) - 1u)) : 0;
+        const int par = (int)(chunk & 1);                           // (uniform) odd chunks are staged negated
+        const float *ct = ctab + par * (4 * Co), *xt = xtab + par * (3 * Ci);
+        const float lim = par ? -INFINITY : INFINITY;               // med3(t, 0, +inf) = max(t, 0);  med3(-t, 0, -inf) = min(-t, 0) = -max(t, 0)
+        const unsigned sm = (unsigned)par << 31;
 #pragma unroll
         for (int i = 0; i < IT_D; ++i) {
             int row, q;
             d_item(i, row, q);
-            const DyParams dp = dy_params_tab(ctab, Co, 4 * q, true);
+            const DyParams dp = dy_params_tab(ct, Co, 4 * q, true);
             float4 dz = raw.z[POOLED ? 0 : i];
             if (POOLED) {
                 const int4 a = raw.a[0];
@@ -626,10 +637,13 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
             float4 x = raw.p[i];
             *reinterpret_cast<float4 *>(&yp[row * LDP + 4 * q]) = x;
             if (MASKED) {
-                const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]), sc = *reinterpret_cast<const float4 *>(&xtab[Ci + 4 * q]);
-                const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * Ci + 4 * q]);
-                x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f); x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
-                x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f); x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+                const float4 mu = *reinterpret_cast<const float4 *>(&xt[4 * q]), sc = *reinterpret_cast<const float4 *>(&xt[Ci + 4 * q]);
+                const float4 be = *reinterpret_cast<const float4 *>(&xt[2 * Ci + 4 * q]);
+                x.x = __builtin_amdgcn_fmed3f(bn_act(x.x, mu.x, sc.x, be.x), 0.f, lim); x.y = __builtin_amdgcn_fmed3f(bn_act(x.y, mu.y, sc.y, be.y), 0.f, lim);
+                x.z = __builtin_amdgcn_fmed3f(bn_act(x.z, mu.z, sc.z, be.z), 0.f, lim); x.w = __builtin_amdgcn_fmed3f(bn_act(x.w, mu.w, sc.w, be.w), 0.f, lim);
+            } else {
+                x.x = __uint_as_float(__float_as_uint(x.x) ^ sm); x.y = __uint_as_float(__float_as_uint(x.y) ^ sm);
+                x.z = __uint_as_float(__float_as_uint(x.z) ^ sm); x.w = __uint_as_float(__float_as_uint(x.w) ^ sm);
             }
             store_split(ib, row, q, x);
         }
@@ -667,7 +681,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     auto run = [&](auto dx_tag) {
         constexpr bool DXW = decltype(dx_tag)::value;               // this wave owns a dX tile (else: dW tiles)
         SplitFrag wh[DXW ? KBX : 1], wm[DXW ? KBX : 1], wl[DXW && !WL_LDS ? KBX : 1];       // W[co][ecol], co = 16 kb + 8 lh + 0 .. 7
-        uint4 *wl_lds = reinterpret_cast<uint4 *>(xtab + 3 * Ci + (Ci % 4 ? 4 - Ci % 4 : 0)) + (size_t)(DXW ? wave : 0) * KBX * 64 + lane;
+        uint4 *wl_lds = reinterpret_cast<uint4 *>(xtab + 6 * Ci) + (size_t)(DXW ? wave : 0) * KBX * 64 + lane;
         float emu = 0.f, esc = 0.f, ebe = 0.f, eis = 0.f;
         // dW tile (wave - CI_T) + j NDW: rows 32 mb .., columns 32 nb ..
         f32x16 accw[DXW ? 1 : TW];
@@ -798,9 +812,10 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
                 unsigned offx = (unsigned)ecol;
                 asm volatile("" : "+v"(offx));
                 float s0 = 0.f, s1 = 0.f;
+                const unsigned sgn = (unsigned)(chunk & 1) << 31;           // an odd chunk was multiplied negated: its sign back
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float dz = DX2 ? acc[r] + acc2[r] : acc[r];
+                    float dz = __uint_as_float(__float_as_uint(DX2 ? acc[r] + acc2[r] : acc[r]) ^ sgn);
                     if (MASKED) {
                         const float y = yv[r];
                         dz = bn_act(y, emu, esc, ebe) > 0.f ? dz : 0.f;
@@ -859,7 +874,7 @@ template <int CO_T, int CI_T, bool POOLED, bool MASKED>
 int launch_split_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
                          double *red_p, float *dW, int lddw, hipStream_t s) {
     constexpr int Co = 32 * CO_T, Ci = 32 * CI_T;
-    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 4 * Co + 3 * Ci) +
+    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 8 * Co + 6 * Ci) +
                            (CO_T == 4 && CI_T < 4 ? (size_t)CI_T * (Co / 16) * 1024 : 0);      // (the kernel's WL_LDS region)
     static_assert(lds <= 160 * 1024, "LDS");
     if ((reinterpret_cast<uintptr_t>(dy.Y) & 15) != 0 || (reinterpret_cast<uintptr_t>(Yp) & 15) != 0) return PN2_EUNSUPPORTED;
@@ -906,11 +921,12 @@ __global__ __launch_bounds__(512, 1) void split_bwd_cf_kernel(const float *dZp, 
     static_assert(NTS % QD == 0, "one channel quad of D per staging thread");
     unsigned char *lds_b = reinterpret_cast<unsigned char *>(res_lds);
     float *Yps = res_lds + (2 * BUF) / 4;                           // [2][BP][LDP]: the raw Y_prev chunk
-    float *xtab = Yps + 2 * BP * LDP;                               // mean, scale, beta of the previous BatchNorm: 3 * Ci
+    float *xtab = Yps + 2 * BP * LDP;                               // [2][3 * Ci]: mean, scale, beta of the previous BatchNorm; then mean, -scale, -beta
+                                                                    // (odd chunks are computed negated: split_bwd_res_kernel, SIGN ALTERNATION)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
     const int G = gridDim.x;
     RABS(wave, 0)
-    for (int i = t; i < 3 * Ci; i += 512) xtab[i] = aff_p[i];
+    for (int i = t; i < 3 * Ci; i += 512) { const float v = aff_p[i]; xtab[i] = v; xtab[3 * Ci + i] = i < Ci ? v : -v; }
 
     const bool has_dx = wave < CI_T, is_gram = wave == CI_T;
     const int ecol = (has_dx ? wave : 0) * 32 + l31;
@@ -944,10 +960,15 @@ __global__ __launch_bounds__(512, 1) void split_bwd_cf_kernel(const float *dZp, 
         float *yp = Yps + buf * (BP * LDP);
         const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;
         const int kbase = (int)(m0 & ((1u << kshift) - 1u));
+        const int par = (int)(chunk & 1);                           // (uniform) odd chunks are staged negated
+        const float *xt = xtab + par * (3 * Ci);
+        const float lim = par ? -INFINITY : INFINITY;
         {   // D: the group's dZp quad, split ONCE; a row takes the pieces of the channels whose maximum sits in it, zeros elsewhere
             unsigned h0, m0_, l0, h1, m1, l1;
             split2(raw.z.x, raw.z.y, h0, m0_, l0);
             split2(raw.z.z, raw.z.w, h1, m1, l1);
+            const unsigned sm2 = par ? 0x80008000u : 0u;            // (the pieces of -x are the pieces of x negated)
+            h0 ^= sm2; m0_ ^= sm2; l0 ^= sm2; h1 ^= sm2; m1 ^= sm2; l1 ^= sm2;
             const int q = ts % QD, r0 = ts / QD;
             const int4 a = raw.a;
 #pragma unroll
@@ -968,10 +989,10 @@ __global__ __launch_bounds__(512, 1) void split_bwd_cf_kernel(const float *dZp, 
             p_item(i, row, q);
             float4 x = raw.p[i];
             *reinterpret_cast<float4 *>(&yp[row * LDP + 4 * q]) = x;
-            const float4 mu = *reinterpret_cast<const float4 *>(&xtab[4 * q]), sc = *reinterpret_cast<const float4 *>(&xtab[Ci + 4 * q]);
-            const float4 be = *reinterpret_cast<const float4 *>(&xtab[2 * Ci + 4 * q]);
-            x.x = fmaxf(bn_act(x.x, mu.x, sc.x, be.x), 0.f); x.y = fmaxf(bn_act(x.y, mu.y, sc.y, be.y), 0.f);
-            x.z = fmaxf(bn_act(x.z, mu.z, sc.z, be.z), 0.f); x.w = fmaxf(bn_act(x.w, mu.w, sc.w, be.w), 0.f);
+            const float4 mu = *reinterpret_cast<const float4 *>(&xt[4 * q]), sc = *reinterpret_cast<const float4 *>(&xt[Ci + 4 * q]);
+            const float4 be = *reinterpret_cast<const float4 *>(&xt[2 * Ci + 4 * q]);
+            x.x = __builtin_amdgcn_fmed3f(bn_act(x.x, mu.x, sc.x, be.x), 0.f, lim); x.y = __builtin_amdgcn_fmed3f(bn_act(x.y, mu.y, sc.y, be.y), 0.f, lim);
+            x.z = __builtin_amdgcn_fmed3f(bn_act(x.z, mu.z, sc.z, be.z), 0.f, lim); x.w = __builtin_amdgcn_fmed3f(bn_act(x.w, mu.w, sc.w, be.w), 0.f, lim);
             store_split(ib, row, q, x);
         }
     };
@@ -1002,7 +1023,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_cf_kernel(const float *dZp, 
         // W2[k][ecol], k = 16 kb + 8 lh + 0 .. 7: hi / mid in registers; lo of the D W' blocks in LDS (8 KiB per wave, written and
         // read by this wave alone), lo of the X M blocks in registers
         SplitFrag wh[KBT], wm[KBT], wl[KBM];
-        uint4 *wl_lds = reinterpret_cast<uint4 *>(xtab + 3 * Ci + (Ci % 4 ? 4 - Ci % 4 : 0)) + (size_t)wave * KBX * 64 + lane;
+        uint4 *wl_lds = reinterpret_cast<uint4 *>(xtab + 6 * Ci) + (size_t)wave * KBX * 64 + lane;
         {
             float v[KBT][8];
 #pragma unroll
@@ -1068,11 +1089,12 @@ __global__ __launch_bounds__(512, 1) void split_bwd_cf_kernel(const float *dZp, 
             unsigned offx = (unsigned)ecol;
             asm volatile("" : "+v"(offx));
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            const unsigned sgn = (unsigned)(chunk & 1) << 31;       // an odd chunk was multiplied negated: its sign back (before h joins)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float y = yv[r];
                 const float x = bn_act(y, emu, esc, ebe);
-                float dz = (acc[r] + acc2[r]) + eh;
+                float dz = __uint_as_float(__float_as_uint(acc[r] + acc2[r]) ^ sgn) + eh;
                 dz = x > 0.f ? dz : 0.f;
                 s0 += dz;
                 s1 = __builtin_fmaf(dz, (y - emu) * eis, s1);
@@ -1311,7 +1333,7 @@ int launch_split_bwd_cf(const float *dZp, const int32_t *arg, int ldo, int kshif
                         const float *bias, const float *Yp, int ldp, const float *aff_p, int64_t P, float *dX, int ldxo, double *red_p,
                         float *dW, int lddw, float *scratch, hipStream_t s) {
     constexpr int Co = 32 * CO_T, Ci = 32 * CI_T, LDT = Co + Ci + 4;
-    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 3 * Ci) + (size_t)CI_T * (Co / 16) * 1024;
+    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 6 * Ci) + (size_t)CI_T * (Co / 16) * 1024;
     static_assert(lds <= 160 * 1024, "LDS");
     auto kern = split_bwd_cf_kernel<CO_T, CI_T>;
     static Pn2PerDevice raised;

@@ -888,8 +888,13 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
     static_assert(FPOOL == 0 || (RS == 1 && (BM % FPOOL == 0 || FPOOL % BM == 0) && FPOOL % 32 == 0), "forward pooling geometry");
     static_assert(!POOLED || (PKP > 0 && (PKP % BM == 0 || BM % PKP == 0)), "pooled dY: groups and tiles nest");
     unsigned char *lds_b = reinterpret_cast<unsigned char *>(wide_lds);
-    float *tab = wide_lds + (2 * 3 * IMG) / 4;                      // NTAB rows of KPAD floats
-    float *xch = tab + NTAB * KPAD;                                 // KS == 2: one row block of accumulators per wave (16 x 64 floats)
+    float *tab = wide_lds + (2 * 3 * IMG) / 4;                      // NTAB rows of KPAD floats (data gradients: twice -- see SIGNED)
+    // SIGNED (data gradients; round 6): odd TILES are computed negated -- the coefficient rows c0, q1, q0 of the second table copy carry
+    // the opposite sign, the epilogue gives the tile its sign back -- so that the one-sided error of the bf16 MFMA's accumulation
+    // (mlp_res.hip, SIGN ALTERNATION) alternates from tile to tile and cancels in the BatchNorm-backward sums over the rows
+    constexpr bool SIGNED = DY && EPI == EPI_MASK;
+    constexpr int TABF = NTAB * KPAD * (SIGNED ? 2 : 1);
+    float *xch = tab + TABF;                                        // KS == 2: one row block of accumulators per wave (16 x 64 floats)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, lh = lane >> 5;
     const int cb = wave % NCB + (int)blockIdx.y * NCB, rs = (wave / NCB) % RS, ks = wave / (NCB * RS);
     // WL_LDS (13 k blocks: 156 fragment registers next to accumulators, operands and the staging is over a wave's 256): the `lo`
@@ -923,7 +928,9 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
 
     for (int i = t; i < NTAB * KPAD; i += NT) {
         const int r = i / KPAD, k = i - r * KPAD;
-        tab[i] = k < K4 ? g.tab[r * K4 + k] : 0.f;
+        const float v = k < K4 ? g.tab[r * K4 + k] : 0.f;
+        tab[i] = v;
+        if (SIGNED) tab[NTAB * KPAD + i] = r < 3 ? -v : v;          // (-c0, -q1, -q0, mean)
     }
 
     const int N4 = (N + 3) & ~3;
@@ -979,14 +986,15 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
     };
     // the table entries of a chunk: a thread's items all lie in the same four columns (NT is a multiple of 16)
     struct Tabs { float4 a, b, c, d; };
-    auto stage_tabs = [&](int c) {
+    auto stage_tabs = [&](int c, int64_t tile_ = 0) {
         Tabs tb{};
         const int k = c * KC + 4 * (t & 15);
         const int kt = k < KPAD ? k : 0;                            // (pad quads of the last chunk: any entry, zeroed when staged)
         if (MODE != MODE_PLAIN) {
-            tb.a = *reinterpret_cast<const float4 *>(&tab[kt]); tb.b = *reinterpret_cast<const float4 *>(&tab[KPAD + kt]);
-            tb.c = *reinterpret_cast<const float4 *>(&tab[2 * KPAD + kt]);
-            if (DY) tb.d = *reinterpret_cast<const float4 *>(&tab[3 * KPAD + kt]);
+            const float *tp = tab + (SIGNED ? (int)(tile_ & 1) * (NTAB * KPAD) : 0);     // (uniform) odd tiles: the negated coefficients
+            tb.a = *reinterpret_cast<const float4 *>(&tp[kt]); tb.b = *reinterpret_cast<const float4 *>(&tp[KPAD + kt]);
+            tb.c = *reinterpret_cast<const float4 *>(&tp[2 * KPAD + kt]);
+            if (DY) tb.d = *reinterpret_cast<const float4 *>(&tp[3 * KPAD + kt]);
         }
         return tb;
     };
@@ -1113,7 +1121,7 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
         for (int e = (K4 % 16) / 2; e < 4; ++e) { wh[KBW - 1].u[e] = 0u; wm[KBW - 1].u[e] = 0u; if (!WL_LDS) wl[KBW - 1].u[e] = 0u; }
     }
     __syncthreads();                                                // the table is in place, the W tiles are read
-    stage(tile, 0, 0, stage_tabs(0));
+    stage(tile, 0, 0, stage_tabs(0, tile));
     if (NCH > 1) fetch(tile, 1); else fetch(tile_of(1), 0);
     auto raw_landed = [&]() {                                       // a use of every raw register: hipcc waits for the requests HERE
 #pragma unroll
@@ -1173,7 +1181,7 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
             // next chunk (BatchNorm / dY transform, split, LDS stores: vector work) and then multiplies, the second multiplies first
             // -- one's staging runs beside the other's MFMAs instead of both queueing for the matrix pipe and then both idling it
             // (in-kernel stamps of the in-step version: MFMA phases 36 - 53 % of the loop, staging 16 - 27 %, barrier waits 34 %).
-            const Tabs tb = stage_tabs(c1);                         // (first in program order: its LDS reads lead the chunk)
+            const Tabs tb = stage_tabs(c1, t1 < tiles ? t1 : tiles - 1);     // (first in program order: its LDS reads lead the chunk)
             // (measured slower woven, in the step: KS == 2 -- two k blocks of twelve MFMAs per chunk and wave -- 291 -> 323 us; the
             // four-wave workgroups, two to a CU: 96 -> 128 pooled 304 -> 328, 64 -> 128 pooled 184 -> 193)
             constexpr bool WOVEN = PN2_SPLIT_ORDER >= 2 && KS == 1 && NW >= 6;
@@ -1331,10 +1339,11 @@ __global__ __launch_bounds__(64 * NCB * RS * KS, (NCB * RS * KS <= 4 ? 2 : 1)) v
                         else pv[r] = (ALLC || n < N4) ? pb[offp] : 0.f;
                         offp += ((r & 3) == 3 ? 5u : 1u) * (unsigned)g.ldp;
                     }
+                    const unsigned sgn = SIGNED ? (unsigned)(tile & 1) << 31 : 0u;       // an odd tile was multiplied negated: its sign back
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float y = pv[r];
-                        const float a = KS == 1 ? acc[i][r] : (ks == 0 ? acc[0][r] : acc[1][r]);
+                        const float a = __uint_as_float(__float_as_uint(KS == 1 ? acc[i][r] : (ks == 0 ? acc[0][r] : acc[1][r])) ^ sgn);
                         const float dz = bn_act(y, e0, e1, e2) > 0.f ? a : 0.f;   // pad columns: scale = beta = 0 -> 0
                         if (ALLC || n < N4) PN2_STREAM_STORE(dz, xb + offx);
                         s0 += dz;
@@ -1380,7 +1389,8 @@ int launch_split(const RegwArgs &g, hipStream_t s) {
     constexpr int KC = 64, BM = 32 * TM * RS, KPAD = 16 * ((K4 + 15) / 16);
     constexpr int NTAB = MODE == MODE_PLAIN ? 0 : (MODE == MODE_BNRELU ? 3 : 4);
     constexpr int KBW = ((K4 + 15) / 16) / KS;
-    constexpr size_t lds = 2 * 3 * (size_t)(BM * KC * 2) + sizeof(float) * (NTAB * KPAD + (KS == 2 ? NCB * RS * KS * 16 * 64 : 0)) +
+    constexpr bool SIGNED = (MODE == MODE_DYDENSE || MODE == MODE_DYPOOLED) && EPI == EPI_MASK;     // (two coefficient tables)
+    constexpr size_t lds = 2 * 3 * (size_t)(BM * KC * 2) + sizeof(float) * (NTAB * KPAD * (SIGNED ? 2 : 1) + (KS == 2 ? NCB * RS * KS * 16 * 64 : 0)) +
                            (KBW >= 13 ? (size_t)NCB * KBW * 1024 : 0);               // (the kernel's WL_LDS region)
     static_assert(lds <= 160 * 1024, "LDS");
     auto kern = split_nt_kernel<K4, NCB, RS, TM, MODE, EPI, BNN, PKP, NN % 32 == 0 && NN == 32 * NCB * NG, KS>;
