@@ -124,7 +124,7 @@ void pn2_clear_last_kernel(void);
  *     fp32 pipe gives a finite product), and pieces below 2^-126 are flushed (the lo piece of |x| < 2^-110 is lost: relative
  *     error up to 2^-16 on such operands).  Activations, weights and gradients of a BatchNorm network sit 30 binades inside both.
  *     0 = v_mfma_f32_32x32x2_f32 everywhere (an exact fp32 fma chain per output element).
- *   POOL_CF: 1 = a pooled last layer of 128 x 96 (2: also 128 x 64) never writes its pre-BN output; its backward is evaluated from the
+ *   POOL_CF: 2 (default) = a pooled last layer of 128 x 96 or 128 x 64 (1: 128 x 96 only; 0: off) never writes its pre-BN output; its backward is evaluated from the
  *     layer's input (pn2_conv1x1_bwd_cf: the same function, another rounding order; fp64-checked to 3e-6).
  * A caller that needs one arithmetic across library versions sets these explicitly. */
 int pn2_set_option(const char *name, int value);

@@ -1867,8 +1867,8 @@ static bool cf_shape(int C_out, int C_in) { return C_out == 128 && (C_in == 96 |
 extern "C" int pn2_conv1x1_bwd_cf_supported(int64_t P, int C_out, int C_in, int Kpool) {
     if (!(pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_RES) && pn2_opt(PN2_OPT_POOL_CF))) return 0;
     if (!pn2_res_supported(P, C_out, C_in) || !cf_shape(C_out, C_in)) return 0;
-    // 128 x 64: the forward does not gain from the missing store (its kernel is bound by its epilogue: 103 -> 100 us at 524 288 rows)
-    // and this backward costs 30 us more than the Y-reading one: off unless POOL_CF >= 2
+    // 128 x 64 (POOL_CF >= 2, the default): alone the forward gains little from the missing store and this backward ties the Y-reading
+    // one (159 vs 158 us at 524 288 rows, + 18 us of prep / finish); in the step the forward runs 125 -> 99 us and cfg5 MSG gains 0.3 ms
     if (C_in == 64 && pn2_opt(PN2_OPT_POOL_CF) < 2) return 0;
     if (Kpool < 32 || (Kpool & (Kpool - 1)) != 0 || P % Kpool != 0) return 0;
     if (P * (int64_t)std::max(C_out, C_in) >= (1LL << 32)) return 0;           // 32-bit element offsets inside the kernel

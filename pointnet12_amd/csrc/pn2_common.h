@@ -66,8 +66,8 @@ static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
     X(SPLIT_K256, 1) /* ... the pooled data gradients with C_out = 256 (contraction split over wave pairs) */ \
     X(SPLIT_NARROW, 1) /* ... also on the narrow sa1 forward layers the weight-resident kernels served */ \
     X(SPLIT_RES, 1) /* ... and the fused data + weight gradient of the narrow long layers (split_bwd_res_kernel) */ \
-    X(SPLIT_WG2, 0) /* ... its four-wave forms (sa1 of MSG) as two workgroups per CU */ \
-    X(POOL_CF, 1) /* ... the pooled last layers of sa1 (128 x 96, 128 x 64) WITHOUT their pre-BN output: forward stores nothing, backward from the input (split_bwd_cf_kernel) */ \
+    X(SPLIT_WG2, 1) /* ... its four-wave forms (sa1 of MSG) as two workgroups per CU (alone: 96 -> 128 pooled 244 -> 209 us; cfg5 MSG 41.4 -> 41.0 ms) */ \
+    X(POOL_CF, 2) /* the pooled last layers of sa1 WITHOUT their pre-BN output: forward stores nothing, backward from the layer's input (split_bwd_cf_kernel); 1: 128 x 96 only, 2: also 128 x 64 */ \
     X(SPLIT_RES_MIN_TILES_128, 1024) /* ... its 128 x 128 pair from this many 64-row tiles on (below: the streamed pair kernel) */ \
     X(SPLIT_MIN_ROWS_128, 98304) /* ... 128 -> 128 forward / data gradient from this many rows on (below: the streamed fp32 kernels) */ \
     X(RING, 0) /* forward: the LDS-DMA ring form of the register-stationary kernel (measured equal: DESIGN.md section 3) */ \

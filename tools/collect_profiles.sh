@@ -58,8 +58,8 @@ stats cfg5_msg $CFG5_MSG --steps 5 --warmup 2
 # 4. A/B lines of the round's switches (same box, back to back, twice)
 : > $O/ab_switches.txt
 for rep in 1 2; do
-  for v in "PN2_SPLIT=0" "PN2_SPLIT=1" "PN2_SPLIT_RES=0" "PN2_SPLIT_RES=1" "PN2_SPLIT_RES=2" "PN2_SPLIT_NARROW=0" "PN2_SPLIT_WGRAD=0" "PN2_SPLIT_K256=0" \
-           "PN2_BENCH_FORK=top" "PN2_BENCH_FORK=sa2" "PN2_BENCH_FORK=loss" "PN2_RING=1" "PN2_LAZY_BN=0" "PN2_WIDE_POOL=0" "PN2_BWD_PAIR=0"; do
+  for v in "PN2_SPLIT=1" "PN2_POOL_CF=0" "PN2_POOL_CF=1" "PN2_POOL_CF=2" "PN2_SPLIT_WG2=0" "PN2_SPLIT_WG2=1" "PN2_FPS_PIECE=128" "PN2_SPLIT=0" "PN2_SPLIT_RES=0" \
+           "PN2_SPLIT_NARROW=0" "PN2_SPLIT_WGRAD=0" "PN2_SPLIT_K256=0" "PN2_LAZY_BN=0" "PN2_WIDE_POOL=0" "PN2_BWD_PAIR=0"; do
     for w in msg ssg; do
       env $v python3 bench.py --workload $w --no-cpu-baseline --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], d['ms_per_step'])" $v $w >> $O/ab_switches.txt
     done
@@ -76,6 +76,12 @@ if [ -f pointnet12_amd/libpn2_hip_stamp.so ]; then
   PN2_SPLIT_RES=2 PN2_LIB_PATH=pointnet12_amd/libpn2_hip_stamp.so python3 tools/stamp_res.py > $O/stamp_split_bwd_res.txt 2>&1
 fi
 
+# SQ / GRBM counters of the fused backward kernels alone (clock held, matrix-pipe busy share, VALU : MFMA, LDS): tools/pmc_kernels.sh
+( bash tools/pmc_kernels.sh bwd 1048576,524288 $O/sq_bwd > /dev/null 2>&1; echo "=== bwd"; cat $O/sq_bwd/summary.txt
+  bash tools/pmc_kernels.sh bwdcf 1048576,524288 $O/sq_bwdcf > /dev/null 2>&1; echo "=== bwdcf"; cat $O/sq_bwdcf/summary.txt ) > $O/sq_counters_split.txt 2>&1
+rm -rf $O/sq_bwd $O/sq_bwdcf
+python3 tools/exp/split_bias_probe.py > $O/split_bias_probe.txt 2>&1
+python3 tools/exp/nostore_probe.py > $O/nostore_probe.txt 2>&1
 tools/exp/mfma_peak > $O/mfma_peak.txt 2>&1
 [ -x tools/exp/mfma_shape ] && tools/exp/mfma_shape > $O/mfma_shape.txt 2>&1
 if [ -z "$QUICK" ]; then
@@ -84,6 +90,7 @@ if [ -z "$QUICK" ]; then
   python3 tools/bench_fps.py > $O/fps_probe.txt 2> $O/fps.err
   python3 tools/bench_ball.py > $O/ball_query_cfg5.txt 2> $O/ball.err
   python3 -m pytest tests -m gpu -q > $O/tests_gpu_full.txt 2>&1; (grep "^E  " $O/tests_gpu_full.txt | head -20; tail -5 $O/tests_gpu_full.txt) > $O/tests_gpu.txt
+  cp gpurun_out/rccl_same_device.txt $O/rccl_same_device.txt 2>/dev/null
   cp gpurun_out/parity_stages.json $O/parity_stages.json 2>/dev/null
   cp gpurun_out/parity_fullsize.json $O/parity_fullsize.json 2>/dev/null
 fi
