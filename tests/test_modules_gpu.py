@@ -326,19 +326,48 @@ def test_prefetched_geometry_graph_matches_eager(dev):
             loss.backward()
             return loss
         torch.manual_seed(31)
+        geos = []
+
+        def eager_geometry():
+            # the geometry an eager step is about to compute (same generator state: restored afterwards), as a recorded tape
+            state = torch.get_rng_state()
+            tape = U.GeometryTape()
+            U.set_geometry_tape(tape)
+            try:
+                with torch.no_grad():
+                    net.features(pts)
+            finally:
+                U.set_geometry_tape(None)
+            torch.set_rng_state(state)
+            return [t.detach().cpu().clone() for t in G_._flatten(tape.items)]
         if mode == "eager":
             for _ in range(2):
                 compute()
-            step = compute
+
+            def step():
+                geos.append(eager_geometry())
+                return compute()
         else:
             # "prefetch-forked": the geometry branch of the captured step starts at fork_point(), between forward and backward,
             # instead of at its top -- when it runs changes, what it computes (draws, tapes) does not
             step = GraphedStep(compute, dev, warmup=2, geometry_fn=lambda: net.features(pts), fork_in_step=mode == "prefetch-forked")
         losses = []
-        for _ in range(4):
+        for r in range(4):
             losses.append(float(step()))
-        seqs.append((losses, bucket.flat.clone()))
-    (la, ga), (lb, gb), (lc, gc) = seqs
+            if mode != "eager":
+                # the tape replay r ran on (graph r % 2 reads the tape the other graph's side branch wrote one replay earlier)
+                geos.append([t.detach().cpu().clone() for t in G_._flatten(step._tapes[r % 2].items)])
+        seqs.append((losses, bucket.flat.clone(), geos))
+    (la, ga, ta), (lb, gb, tb), (lc, gc, tc) = seqs
+    # the geometry is index-exact -- the recorded tensors (FPS indices, centres, ball-query indices, 3-NN indices and
+    # weights) of every step must be bit-identical between the eager run and both captured schedules; a tape or stream-ordering
+    # race cannot hide under the loss tolerance below
+    for name, other in (("prefetch", tb), ("prefetch-forked", tc)):
+        assert len(other) == len(ta) == 4
+        for r, (x, y) in enumerate(zip(ta, other)):
+            assert len(x) == len(y), (name, r, len(x), len(y))
+            for i, (u, v) in enumerate(zip(x, y)):
+                assert u.shape == v.shape and torch.equal(u, v), "%s: recorded geometry %d of step %d differs from the eager step's" % (name, i, r)
     # (a wrong start draw or a stale tape samples other points and moves the loss by 1e-2 and more; the three schedules differ in
     # the ORDER of the statistics atomics, which now and then flips a pooled arg-max and moves the loss of these small clouds in
     # the fifth digit -- one full-suite run in five of round 5 tripped a 2e-5 bound here and passed when repeated)

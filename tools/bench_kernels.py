@@ -47,8 +47,18 @@ def timeit(fn, reps):
 
 
 def report(tag, shape, secs, flops, nbytes):
+    """One line per shape, priced as bench.py prices a kernel: algorithmic bytes against HBM 8 TB/s, algorithmic fp32 flops against
+    the matrix peak of the pipe the kernel that just ran uses (pn2_last_kernel(): f32 157.3 TF, bf16x3 split 416.7 TF); the larger
+    fraction is the bound -- never above 1."""
+    import bench
+    kern = _lib.load().pn2_last_kernel()
+    key = bench.kernel_key(kern.decode()) if kern else ""
+    pipe = bench.kernel_pipe(key) if key else "f32"
+    bound, ach, peak, unit, frac, hf, mf = bench.price(flops, nbytes, secs, pipe)
+    assert frac <= 1.0, (tag, shape, frac)
     tf, gbs = flops / secs / 1e12, nbytes / secs / 1e9
-    print("%-6s %-28s %8.1f us %7.2f TF %8.1f GB/s  frac %.3f" % (tag, shape, secs * 1e6, tf, gbs, max(tf / 157.3, gbs / 8000)))
+    print("%-6s %-28s %8.1f us %7.2f TF %8.1f GB/s  %-4s frac %.3f  (hbm %.3f, %s mfma %.3f)  %s" %
+          (tag, shape, secs * 1e6, tf, gbs, bound, frac, hf, pipe, mf, key[:70]))
 
 
 def main():
