@@ -176,7 +176,7 @@ def main():
                 def fn():
                     rc = lib.pn2_conv1x1_bwd_pair(*dz, p(Y), r4(Cl), p(coef), p(Wt), Cp, p(Yp), r4(Cp), p(affp), p(dX), r4(Cp), p(red),
                                                   p(Yp), r4(Cp), p(affp), p(dW), Cp, P, Cl, Cp, None, st)
-                    assert rc == 0
+                    assert rc in (0, 1)                 # (1: run as dgrad + wgrad launches -- the kernel named is then the second one)
                 report("pair", (P, Cl, Cp, Kp), timeit(fn, args.reps), 4.0 * P * Cl * Cp, 4.0 * (dy_bytes + 2 * P * Cp))
             elif which == "bwd":
                 dX = torch.empty(P, r4(Cp), device=dev)
