@@ -69,7 +69,12 @@ def algorithmic_work(name, a):
         return 2.0 * P * M * N, 4.0 * (P * M * (2 if dense else 1) + P * N + M * N)
     if name == "pn2_conv1x1_wgrad_cf":       # dZ ldz coef X ldx W ldw bias mom dW lddw P M N: closed-form BatchNorm terms, Y not read
         P, M, N = a[11], a[12], a[13]          # (booked with the bytes THIS formulation needs, not the general one's P*M more)
+        if a[0] is None:                     # (dZ^T x came from the next layer's fused backward: this pass reads the input rows only)
+            return 2.0 * P * N * N, 4.0 * (P * N + M * N)
         return 2.0 * P * M * N, 4.0 * (P * M + P * N + M * N)
+    if name == "pn2_conv1x1_bwd_first":      # fused backward that also forms the first layer's dZ^T x: dZ, Y, prev_Y, X0 read; NO dX written
+        P, Co, Ci, N0 = a[17], a[18], a[19], a[15]
+        return 4.0 * P * Co * Ci + 2.0 * P * Ci * N0, 4.0 * (2 * P * Co + P * Ci + P * a[14] + 2 * Co * Ci)
     if name == "pn2_conv1x1_bwd_pair":       # dgrad + wgrad of one layer behind ONE grid: each body reads its own operands
         P, Co, Ci = a[22], a[23], a[24]
         dense, masked = a[0] is not None, a[11] is not None

@@ -374,6 +374,8 @@ int pn2_conv1x1_wgrad_ws(const float *dZ, int ldz, const float *dZp, int ldo, co
  * workgroups) and the closed-form part is added once, by the workgroup that finishes last.  `coef` as for pn2_conv1x1_wgrad
  * (rows c0, q1, q0, mean of pitch round4(M); realised from `coef_lazy` when given); W [M, N] (pitch ldw) and bias [M] are the
  * layer's parameters; `scratch`: pn2_conv1x1_wgrad_cf_scratch_bytes() bytes, 16-byte aligned, ZEROED by the caller (left dirty).
+ * dZ == NULL (ABI 11): sum_p dZ[p,c] x[p,j] is already in `scratch` -- pn2_conv1x1_bwd_first of the NEXT layer added it there --
+ * and this call takes the input's moments and finishes.
  * PN2_EUNSUPPORTED for other shapes: use pn2_conv1x1_wgrad. */
 int64_t pn2_conv1x1_wgrad_cf_scratch_bytes(void);
 int pn2_conv1x1_wgrad_cf(const float *dZ, int ldz, const float *coef, const float *X, int ldx, const float *W, int ldw,
@@ -411,6 +413,21 @@ int pn2_conv1x1_bwd_cf(const float *dZp, int ldo, const int32_t *arg, int Kpool,
                        const float *bias, const float *prev_Y, int ld_prev, const float *prev_affine, float *dXout, int ldxo,
                        double *prev_red, float *dW, int lddw, int64_t P, int C_out, int C_in,
                        const pn2_bn_coef_lazy *coef_lazy, float *scratch, pn2_stream_t stream);
+
+/* pn2_conv1x1_bwd of a layer whose INPUT is the output of a FIRST layer with a narrow input X0 (N0 <= 12 columns: the grouped
+ * 3 + D rows of sa1; model/pointnet_util.py:127-131 feeding :195-197 / :252-255) when nobody needs a gradient with respect to X0
+ * (ABI 11).  The masked dX of this call IS that first layer's dZ; its backward (pn2_conv1x1_wgrad_cf: BatchNorm terms in closed
+ * form) needs only sum_p dZ[p, c] X0[p, j] from it, which this call forms from its dX tiles and adds into THAT call's scratch
+ * (cf_scratch: pn2_conv1x1_wgrad_cf_scratch_bytes() bytes, zeroed by the caller, then handed to pn2_conv1x1_wgrad_cf with
+ * dZ == NULL) -- dX itself is never written.  dense dZ, prev_affine / prev_red required (training-mode BatchNorm), X0 16-byte
+ * aligned with pitch ld0 >= 12, ld0 % 4 == 0 (pad columns zero).  prev_red receives the first layer's two reductions as in
+ * pn2_conv1x1_bwd.  _supported(): 1 for 96 x 64 and 64 x 64 with P % 64 == 0 from pn2_res_supported()'s row count on (options
+ * SPLIT, SPLIT_RES, FUSE_FIRST on); PN2_EUNSUPPORTED otherwise (call pn2_conv1x1_bwd). */
+int pn2_conv1x1_bwd_first_supported(int64_t P, int C_out, int C_in, int N0);
+int pn2_conv1x1_bwd_first(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *W, int ldw,
+                          const float *prev_Y, int ld_prev, const float *prev_affine, double *prev_red, float *dW, int lddw,
+                          const float *X0, int ld0, int N0, void *cf_scratch, int64_t P, int C_out, int C_in,
+                          const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream);
 
 /* Fused backward of one layer for the narrow, long layers (csrc/mlp_res.hip): dgrad AND wgrad in ONE pass over dZ / Y /
  * prev_Y -- autograd of model/pointnet_util.py:197,254,312 for conv + BatchNorm + ReLU.  dY is formed once per row

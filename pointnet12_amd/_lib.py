@@ -67,6 +67,8 @@ SIGNATURES = {
     "pn2_conv1x1_bwd_cf_supported": (_i, [_i64, _i, _i, _i]),
     "pn2_conv1x1_bwd_cf_scratch_bytes": (_i64, [_i, _i]),
     "pn2_conv1x1_bwd_cf": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "pn2_conv1x1_bwd_first_supported": (_i, [_i64, _i, _i, _i]),
+    "pn2_conv1x1_bwd_first": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _i, _vp, _vp]),
     "pn2_fused_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "pn2_invert_index": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pn2_three_interp_bwd_seg": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -142,7 +144,7 @@ class _Timed:
         fn = getattr(_raw, name)
         if not name.startswith("pn2_") or name in ("pn2_version", "pn2_error_string", "pn2_set_option", "pn2_get_option", "pn2_option_name", "pn2_fps_workspace_bytes",
                                                    "pn2_nll_loss_workspace_bytes", "pn2_res_supported", "pn2_bwd_res_supported", "pn2_conv1x1_wgrad_workspace_bytes",
-                                                   "pn2_conv1x1_wgrad_cf_scratch_bytes", "pn2_conv1x1_bwd_cf_supported", "pn2_conv1x1_bwd_cf_scratch_bytes", "pn2_last_kernel", "pn2_clear_last_kernel",
+                                                   "pn2_conv1x1_wgrad_cf_scratch_bytes", "pn2_conv1x1_bwd_cf_supported", "pn2_conv1x1_bwd_first_supported", "pn2_conv1x1_bwd_cf_scratch_bytes", "pn2_last_kernel", "pn2_clear_last_kernel",
                                                    "pn2_ball_query_workspace_bytes"):
             return fn
 

@@ -1663,7 +1663,7 @@ namespace {
 // closed-form part needs the COMPLETE moments: the workgroup that draws the last ticket adds it, once, in fp64.
 typedef float cf_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CF_REPL = 8;                                        // scratch replicas: 1 / 8 of the workgroups add into each
+constexpr int CF_REPL = PN2_CF_REPL;                              // scratch replicas: 1 / 8 of the workgroups add into each
 
 template <int NB, int U>                                          // 16-channel blocks: M = 16 NB; 4-row groups in flight per wave
 __global__ __launch_bounds__(256) void wgrad_first_cf_kernel(const float *__restrict__ dZ, int ldz, const float *coef /* written by the prologue */, int ldc,
@@ -1675,6 +1675,9 @@ __global__ __launch_bounds__(256) void wgrad_first_cf_kernel(const float *__rest
     __shared__ float fold[4][NB][256];                            // [wave][block][lane * 4 + r]
     __shared__ double sfold[4][256];
     lazy_coef_prologue(lc);                                       // consumer-side BatchNorm backward (bn_tail.h)
+    // dZ == NULL (round 6): `part` already holds sum_p dZ[p, c] x[p, j] -- the NEXT layer's fused backward added it straight from
+    // its dX tiles (split_bwd_res_kernel, FUSE0: dZ never reached memory) -- and this launch only takes the input's moments
+    const bool have_dz = dZ != nullptr;                           // (uniform)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, k = lane >> 4, n = lane & 15;
     const float *zp = reinterpret_cast<const float *>(pn2_zero_page);
     const bool xin = n < N;
@@ -1717,7 +1720,7 @@ __global__ __launch_bounds__(256) void wgrad_first_cf_kernel(const float *__rest
             const float *zb = dZ + (size_t)(g0 * 4) * (unsigned)ldz, *xb = X + (size_t)(g0 * 4) * (unsigned)ldx;     // uniform
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                load_a(zb + (size_t)(4 * u) * (unsigned)ldz + lo_z, a[u]);
+                if (have_dz) load_a(zb + (size_t)(4 * u) * (unsigned)ldz + lo_z, a[u]);
                 const float xv = xb[(size_t)(4 * u) * (unsigned)ldx + lo_x];
                 x[u] = xin ? xv : fill;
             }
@@ -1726,15 +1729,17 @@ __global__ __launch_bounds__(256) void wgrad_first_cf_kernel(const float *__rest
             for (int u = 0; u < U; ++u) {
                 const int64_t p = (g0 + u) * 4 + k;
                 const bool v = p < P;
-                load_a(v ? dZ + p * ldz + NB * n : zp, a[u]);     // (a dead row reads the zero page)
+                if (have_dz) load_a(v ? dZ + p * ldz + NB * n : zp, a[u]);     // (a dead row reads the zero page)
                 const float xv = (v ? X + p * ldx + nc : zp)[0];
                 x[u] = v ? (xin ? xv : fill) : 0.f;
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (have_dz) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][b], x[u], acc[b], 0, 0, 0);
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][b], x[u], acc[b], 0, 0, 0);
+            }
             sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u], x[u], sacc, 0, 0, 0);
         }
         rows64 += 4 * U;
@@ -1756,7 +1761,7 @@ __global__ __launch_bounds__(256) void wgrad_first_cf_kernel(const float *__rest
     for (int r = 0; r < 4; ++r) sfold[wave][lane * 4 + r] = sd[r];
     __syncthreads();
     const int rep = blockIdx.x % CF_REPL;
-    for (int e = t; e < NB * 256; e += 256) {
+    for (int e = t; e < NB * 256 && have_dz; e += 256) {
         const int b = e >> 8, q = e & 255, l2 = q >> 2, r = q & 3, i = 4 * (l2 >> 4) + r, j = l2 & 15;
         if (j >= N) continue;
         atomicAdd(part + (rep * M + NB * i + b) * 16 + j, fold[0][b][q] + fold[1][b][q] + fold[2][b][q] + fold[3][b][q]);
@@ -1979,9 +1984,9 @@ int64_t pn2_conv1x1_wgrad_cf_scratch_bytes(void) { return CF_REPL * (128 * 16 * 
 int pn2_conv1x1_wgrad_cf(const float *dZ, int ldz, const float *coef, const float *X, int ldx, const float *W, int ldw, const float *bias,
                          void *scratch, float *dW, int lddw, int64_t P, int M, int N, const pn2_bn_coef_lazy *coef_lazy,
                          pn2_stream_t stream) {
-    PN2_CHECK_ARG(dZ && coef && X && W && bias && scratch && dW && P > 0 && P < (1LL << 31) && M > 0 && N > 0 && lazy_coef_ok(coef_lazy, coef, M));
+    PN2_CHECK_ARG(coef && X && W && bias && scratch && dW && P > 0 && P < (1LL << 31) && M > 0 && N > 0 && lazy_coef_ok(coef_lazy, coef, M));
     if (M % 16 != 0 || M > 128 || N > 15) return PN2_EUNSUPPORTED;
-    PN2_CHECK_ARG(ldz >= M && ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0 && ldx >= N && lddw >= N && ldw >= N &&
+    PN2_CHECK_ARG((dZ == nullptr || (ldz >= M && ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0)) && ldx >= N && lddw >= N && ldw >= N &&
                   (reinterpret_cast<uintptr_t>(scratch) & 15) == 0);
     const LazyCoef lc = make_lazy_coef(coef_lazy);
     double *mom = reinterpret_cast<double *>(scratch);                              // [CF_REPL][16][16]

@@ -532,9 +532,15 @@ int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, 
 //     dX tile is C_out / 32 units, a dW tile one) and does not need to be: the heaviest SIMD of 128 x 96 has 7 of the chunk's
 //     24 units, 2 700 matrix-pipe cycles per chunk = 165 us per launch, under the memory time.
 //   * the raw Y_prev chunk is kept in LDS as well (fp32): the mask and the sums of the dX epilogue need the pre-BatchNorm value.
-template <int CO_T, int CI_T, bool POOLED, bool MASKED>
+// FUSE0 (round 6): this layer's INPUT is the output of a FIRST layer whose own input is the 48-byte grouped row X0 (sa1 of the
+// segmentation nets: 12 -> 64 -> ...), and nobody needs a gradient with respect to X0.  The masked dX tile of this kernel IS that first
+// layer's dZ; the only thing its backward still wants from it (pn2_conv1x1_wgrad_cf: BatchNorm terms in closed form) is
+// sum_p dZ[p, c] x0[p, j] -- 12 products per element, formed here straight from the dX registers against the chunk's X0 rows in LDS and
+// added into that kernel's scratch.  dX is then NEVER written (nor read back): 0.8 GB and two launches' work per MSG-SemSeg step.
+template <int CO_T, int CI_T, bool POOLED, bool MASKED, bool FUSE0 = false>
 __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw,
-                                                               int64_t chunks, float *dX, int ldxo, double *red_p, float *dW, int lddw) {
+                                                               int64_t chunks, float *dX, int ldxo, double *red_p, float *dW, int lddw,
+                                                               const float *X0 = nullptr, int ld0 = 0, float *part0 = nullptr) {
     constexpr int Co = 32 * CO_T, Ci = 32 * CI_T, BP = 32, NT = 512, QD = Co / 4, QP = Ci / 4, LDP = Ci + 4;
     constexpr int PANEL = BP * 256, BUF = 6 * PANEL;                // one 128-channel panel per piece: dY hi / mid / lo, X hi / mid / lo
     constexpr int KBX = Co / 16;                                    // contraction blocks of a dX tile
@@ -552,6 +558,8 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     // and the one-sided error alternates in sign from chunk to chunk: it cancels in every sum over rows.
     float *ctab = Yps + 2 * BP * LDP;                               // [2][4 * Co]: c0, q1, q0, mean of this layer; then -c0, -q1, -q0, mean
     float *xtab = ctab + 8 * Co;                                    // [2][3 * Ci]: mean, scale, beta of the previous BatchNorm; then mean, -scale, -beta
+    float *x0s = xtab + 6 * Ci;                                     // FUSE0: [2][BP][12], the chunk's rows of the first layer's input
+    static_assert(!FUSE0 || (MASKED && !POOLED && !(CO_T == 4 && CI_T < 4)), "FUSE0: a hidden layer behind a first layer");
     // WL_LDS (C_out = 128 with C_in < 128): a dX wave's `lo` fragments -- the operand of one MFMA in six -- live in LDS, 8 KiB per
     // wave, written and read by that wave alone: 32 registers for the second accumulator (split_nt_kernel does the same at K = 196)
     constexpr bool WL_LDS = CO_T == 4 && CI_T < 4;
@@ -569,10 +577,10 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     const bool has_dx = wave < CI_T;
     const int ecol = (has_dx ? wave : 0) * 32 + l31;                // the dX tile's column of this lane
     // ---- staging: dY item i of thread t = quad q of row `row` (idx = t + 512 i; a thread without an i-th item repeats its last)
-    struct Raw { float4 y[IT_D]; float4 z[POOLED ? 1 : IT_D]; int4 a[1]; float4 p[IT_P]; };
+    struct Raw { float4 y[IT_D]; float4 z[POOLED ? 1 : IT_D]; int4 a[1]; float4 p[IT_P]; float4 x0; };
     // D2: two register sets, chunk j's requests live in set j & 1 and go out two chunks ahead of their use.  (C_out = 128: one set
     // -- a dX wave holds 96 fragment registers there, and its chunk is longer than a memory latency anyway.)
-    constexpr bool D2 = CO_T < 4;
+    constexpr bool D2 = CO_T < 4 && !(FUSE0 && CO_T == 3);          // (96 x 64 with FUSE0: twelve more live registers per dX lane -- one set)
     constexpr bool DX2 = CO_T * CI_T < 16;                          // two alternating dX accumulators (128 x 128: no registers for them, no LDS for WL_LDS)
     Raw raw0, raw1;
     auto d_item = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QD) ? min(t + NT * i, BP * QD - 1) : t + NT * i; row = idx / QD; q = idx - row * QD; };
@@ -597,6 +605,10 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
             int row, q;
             p_item(i, row, q);
             raw.p[i] = ld4(Yp + ((m0 + (unsigned)row) * (unsigned)ldp + 4u * (unsigned)q));
+        }
+        if (FUSE0) {                                                // threads 0 .. 95: quad t % 3 of row t / 3 (the others repeat the last)
+            const unsigned i0 = (unsigned)(t < 3 * BP ? t : 3 * BP - 1);
+            raw.x0 = ld4(X0 + ((m0 + i0 / 3u) * (unsigned)ld0 + 4u * (i0 % 3u)));
         }
     };
     auto store_split = [&](unsigned char *img, int row, int q, const float4 v) {
@@ -647,6 +659,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
             }
             store_split(ib, row, q, x);
         }
+        if (FUSE0 && t < 3 * BP) *reinterpret_cast<float4 *>(&x0s[buf * (BP * 12) + 4 * t]) = raw.x0;      // [row][12]: 4 t = 12 (t / 3) + 4 (t % 3)
     };
     auto raw_landed = [&](Raw &raw) {                                       // (see split_nt_kernel: hipcc then waits for the requests, not for the stores)
 #pragma unroll
@@ -660,6 +673,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
         }
 #pragma unroll
         for (int i = 0; i < IT_P; ++i) asm volatile("" : "+v"(raw.p[i].x), "+v"(raw.p[i].y), "+v"(raw.p[i].z), "+v"(raw.p[i].w));
+        if (FUSE0) asm volatile("" : "+v"(raw.x0.x), "+v"(raw.x0.y), "+v"(raw.x0.z), "+v"(raw.x0.w));
     };
     // transposed fragment (split_tn_kernel's): channels 32 cblk + l31, rows 16 pb + 8 lh + 0 .. 7 of the chunk, of one piece image
     const int g16 = lane >> 4, j16 = lane & 15, tq = j16 >> 2, tp = j16 & 3;
@@ -686,6 +700,9 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
         // dW tile (wave - CI_T) + j NDW: rows 32 mb .., columns 32 nb ..
         f32x16 accw[DXW ? 1 : TW];
         double st0 = 0.0, st1 = 0.0;
+        float g0[DXW && FUSE0 ? 12 : 1];                            // FUSE0: sum_p dZ[p, ecol] x0[p, j] of this lane's rows
+#pragma unroll
+        for (int j = 0; j < (DXW && FUSE0 ? 12 : 1); ++j) g0[j] = 0.f;
         if (DXW) {
             float v[KBX][8];
 #pragma unroll
@@ -812,6 +829,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
                 unsigned offx = (unsigned)ecol;
                 asm volatile("" : "+v"(offx));
                 float s0 = 0.f, s1 = 0.f;
+                const float *x0q = x0s + buf * (BP * 12) + (4 * lh) * 12;     // FUSE0: rows 4 lh + (r & 3) + 8 (r >> 2) of the chunk
                 const unsigned sgn = (unsigned)(chunk & 1) << 31;           // an odd chunk was multiplied negated: its sign back
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -822,13 +840,25 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
                         s0 += dz;
                         s1 = __builtin_fmaf(dz, (y - emu) * eis, s1);
                     }
+                    if (FUSE0) {
+                        // (the same address in every lane of a half-wave: broadcast reads)
+                        const float4 *xr = reinterpret_cast<const float4 *>(x0q + ((r & 3) + 8 * (r >> 2)) * 12);
+                        const float4 a0 = xr[0], a1 = xr[1], a2 = xr[2];
+                        g0[0] = __builtin_fmaf(dz, a0.x, g0[0]); g0[FUSE0 ? 1 : 0] = __builtin_fmaf(dz, a0.y, g0[FUSE0 ? 1 : 0]);
+                        g0[FUSE0 ? 2 : 0] = __builtin_fmaf(dz, a0.z, g0[FUSE0 ? 2 : 0]); g0[FUSE0 ? 3 : 0] = __builtin_fmaf(dz, a0.w, g0[FUSE0 ? 3 : 0]);
+                        g0[FUSE0 ? 4 : 0] = __builtin_fmaf(dz, a1.x, g0[FUSE0 ? 4 : 0]); g0[FUSE0 ? 5 : 0] = __builtin_fmaf(dz, a1.y, g0[FUSE0 ? 5 : 0]);
+                        g0[FUSE0 ? 6 : 0] = __builtin_fmaf(dz, a1.z, g0[FUSE0 ? 6 : 0]); g0[FUSE0 ? 7 : 0] = __builtin_fmaf(dz, a1.w, g0[FUSE0 ? 7 : 0]);
+                        g0[FUSE0 ? 8 : 0] = __builtin_fmaf(dz, a2.x, g0[FUSE0 ? 8 : 0]); g0[FUSE0 ? 9 : 0] = __builtin_fmaf(dz, a2.y, g0[FUSE0 ? 9 : 0]);
+                        g0[FUSE0 ? 10 : 0] = __builtin_fmaf(dz, a2.z, g0[FUSE0 ? 10 : 0]); g0[FUSE0 ? 11 : 0] = __builtin_fmaf(dz, a2.w, g0[FUSE0 ? 11 : 0]);
+                    } else {
 #if defined(PN2_EXP_NOSTORE)
-                    if (dz == 1.2345e-33f) xb[offx] = dz;
+                        if (dz == 1.2345e-33f) xb[offx] = dz;
 #elif defined(PN2_EXP_PLAINSTORE)
-                    xb[offx] = dz;
+                        xb[offx] = dz;
 #else
-                    PN2_STREAM_STORE(dz, xb + offx);
+                        PN2_STREAM_STORE(dz, xb + offx);
 #endif
+                    }
                     offx += ((r & 3) == 3 ? 5u : 1u) * (unsigned)ldxo;       // rows (r & 3) + 8 (r >> 2): +1 +1 +1 +5
                 }
                 if (MASKED) { st0 += (double)s0; st1 += (double)s1; }
@@ -865,26 +895,35 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
                 atomicAdd(rep + Ci + ecol, st1);
             }
         }
+        if (DXW && FUSE0) {                                         // into pn2_conv1x1_wgrad_cf's scratch: part[replica][channel][16]
+#pragma unroll
+            for (int j = 0; j < (DXW && FUSE0 ? 12 : 1); ++j) g0[j] += __shfl_xor(g0[j], 32, 64);
+            if (lh == 0) {
+                float *pr = part0 + ((size_t)(blockIdx.x % PN2_CF_REPL) * Ci + ecol) * 16;
+#pragma unroll
+                for (int j = 0; j < (DXW && FUSE0 ? 12 : 1); ++j) atomicAdd(pr + j, g0[j]);
+            }
+        }
     };
     if (has_dx) run(pn2_true{}); else run(pn2_false{});             // (grid <= chunks: every workgroup has a first chunk)
     RABS(wave, 3)
 }
 
-template <int CO_T, int CI_T, bool POOLED, bool MASKED>
+template <int CO_T, int CI_T, bool POOLED, bool MASKED, bool FUSE0 = false>
 int launch_split_bwd_res(ResDy dy, const float *Yp, int ldp, const float *aff_p, const float *W, int ldw, int64_t tiles, float *dX, int ldxo,
-                         double *red_p, float *dW, int lddw, hipStream_t s) {
+                         double *red_p, float *dW, int lddw, hipStream_t s, const float *X0 = nullptr, int ld0 = 0, float *part0 = nullptr) {
     constexpr int Co = 32 * CO_T, Ci = 32 * CI_T;
-    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 8 * Co + 6 * Ci) +
+    constexpr size_t lds = 2 * 6 * (size_t)(32 * 256) + sizeof(float) * (2 * 32 * (Ci + 4) + 8 * Co + 6 * Ci + (FUSE0 ? 2 * 32 * 12 : 0)) +
                            (CO_T == 4 && CI_T < 4 ? (size_t)CI_T * (Co / 16) * 1024 : 0);      // (the kernel's WL_LDS region)
     static_assert(lds <= 160 * 1024, "LDS");
     if ((reinterpret_cast<uintptr_t>(dy.Y) & 15) != 0 || (reinterpret_cast<uintptr_t>(Yp) & 15) != 0) return PN2_EUNSUPPORTED;
-    auto kern = split_bwd_res_kernel<CO_T, CI_T, POOLED, MASKED>;
+    auto kern = split_bwd_res_kernel<CO_T, CI_T, POOLED, MASKED, FUSE0>;
     static Pn2PerDevice raised;
     if (pn2_raise_dynamic_lds(reinterpret_cast<const void *>(kern), raised) != PN2_OK) return PN2_ELAUNCH;
     const int64_t chunks = tiles * (RES_BM / 32), cap = pn2_num_cus();
     PN2_NOTE_KERNEL(kern);
     hipLaunchKernelGGL(kern, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(512), lds, s, dy, Yp, ldp, aff_p, W, ldw, chunks, dX, ldxo,
-                       red_p, dW, lddw);
+                       red_p, dW, lddw, X0, ld0, part0);
     return pn2_launch_status();
 }
 
@@ -1898,4 +1937,31 @@ extern "C" int pn2_conv1x1_bwd_cf(const float *dZp, int ldo, const int32_t *arg,
     hipStream_t s = pn2_s(stream);
     if (C_in == 96) return launch_split_bwd_cf<4, 3>(dZp, arg, ldo, kshift, coef, lc, W, ldw, bias, prev_Y, ld_prev, prev_affine, P, dXout, ldxo, prev_red, dW, lddw, scratch, s);
     return launch_split_bwd_cf<4, 2>(dZp, arg, ldo, kshift, coef, lc, W, ldw, bias, prev_Y, ld_prev, prev_affine, P, dXout, ldxo, prev_red, dW, lddw, scratch, s);
+}
+
+// ----------------------------------------------------------------------------------------------- fused backward with the first layer's dZ^T x
+extern "C" int pn2_conv1x1_bwd_first_supported(int64_t P, int C_out, int C_in, int N0) {
+    if (!(pn2_opt(PN2_OPT_SPLIT) && pn2_opt(PN2_OPT_SPLIT_RES) && pn2_opt(PN2_OPT_FUSE_FIRST))) return 0;
+    if (!pn2_res_supported(P, C_out, C_in) || P % 64 != 0 || N0 < 1 || N0 > 12) return 0;
+    if (P * (int64_t)std::max(C_out, C_in) >= (1LL << 32)) return 0;
+    return (C_out == 96 && C_in == 64) || (C_out == 64 && C_in == 64);
+}
+
+extern "C" int pn2_conv1x1_bwd_first(const float *dZ, int ldz, const float *Y, int ldy, const float *coef, const float *W, int ldw,
+                                     const float *prev_Y, int ld_prev, const float *prev_affine, double *prev_red, float *dW, int lddw,
+                                     const float *X0, int ld0, int N0, void *cf_scratch, int64_t P, int C_out, int C_in,
+                                     const pn2_bn_coef_lazy *coef_lazy, pn2_stream_t stream) {
+    PN2_CHECK_ARG(dZ && Y && coef && W && prev_Y && prev_affine && prev_red && dW && X0 && cf_scratch && P > 0 && P < (1LL << 31));
+    PN2_CHECK_ARG(lazy_coef_ok(coef_lazy, coef, C_out));
+    PN2_CHECK_ARG(ldz == ldy && ldw >= C_in && lddw >= C_in && ldy % 4 == 0 && ldy >= C_out && ld_prev % 4 == 0 && ld_prev >= C_in);
+    PN2_CHECK_ARG(ld0 % 4 == 0 && ld0 >= 12 && (reinterpret_cast<uintptr_t>(X0) & 15) == 0 && (reinterpret_cast<uintptr_t>(cf_scratch) & 15) == 0);
+    if (!pn2_conv1x1_bwd_first_supported(P, C_out, C_in, N0)) return PN2_EUNSUPPORTED;
+    if (P * (int64_t)std::max((int64_t)ldy, std::max((int64_t)ld_prev, (int64_t)ld0)) >= (1LL << 32)) return PN2_EUNSUPPORTED;
+    // pn2_conv1x1_wgrad_cf's scratch: moments [PN2_CF_REPL][16][16] doubles, then part [PN2_CF_REPL][128][16] floats (here: [..][C_in][16])
+    float *part0 = reinterpret_cast<float *>(reinterpret_cast<double *>(cf_scratch) + PN2_CF_REPL * 256);
+    ResDy dy{dZ, nullptr, nullptr, 0, 0, Y, ldy, coef, make_lazy_coef(coef_lazy)};
+    const int64_t tiles = P / RES_BM;
+    hipStream_t s = pn2_s(stream);
+    if (C_out == 96) return launch_split_bwd_res<3, 2, false, true, true>(dy, prev_Y, ld_prev, prev_affine, W, ldw, tiles, nullptr, 0, prev_red, dW, lddw, s, X0, ld0, part0);
+    return launch_split_bwd_res<2, 2, false, true, true>(dy, prev_Y, ld_prev, prev_affine, W, ldw, tiles, nullptr, 0, prev_red, dW, lddw, s, X0, ld0, part0);
 }

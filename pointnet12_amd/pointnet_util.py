@@ -837,6 +837,14 @@ class _SharedMLP(torch.autograd.Function):
                                            _p(dZ), dZ.shape[1], _p(red_L), coef_tail(L - 1), st), "pn2_relu_bwd_reduce")
         grads = [None] * (7 * L)
         d_rows = None
+        # sa1-style stacks (a first layer on the 48-byte grouped rows, nobody needs d rows): the second layer's fused backward forms
+        # the first layer's sum dZ^T x from its dX tiles (pn2_conv1x1_bwd_first) -- dZ1 is never written -- and the first layer's
+        # weight gradient finishes from the input's moments (pn2_conv1x1_wgrad_cf with dZ == NULL)
+        fuse_first = bool(L >= 3 and ctx.gather is not None and not ctx.needs_input_grad[0] and training and WGRAD_CF and LAZY_BN and
+                          not FUSED_BN_TAILS and chans[0] <= 12 and chans[1] % 16 == 0 and chans[1] <= 128 and rows.shape[1] % 4 == 0 and
+                          rows.shape[1] >= 12 and Ys[1] is not None and
+                          lib.pn2_conv1x1_bwd_first_supported(P, chans[2], chans[1], chans[0]))
+        first_scratch = None
         side, side_used = None, False
         if 0 < P <= WGRAD_SIDE_MAX_ROWS:
             main_stream = torch.cuda.current_stream(dev)
@@ -873,6 +881,24 @@ class _SharedMLP(torch.autograd.Function):
             if not training and direct:
                 raise NotImplementedError("direct gradient accumulation with eval-mode BatchNorm: use autograd mode")
             need_dx = l > 0 or ctx.needs_input_grad[0]
+            if l == 1 and fuse_first and dZ is not None:
+                first_scratch = _zeros_small(int(lib.pn2_conv1x1_wgrad_cf_scratch_bytes()), dev)
+                rc = lib.pn2_conv1x1_bwd_first(_p(dZ), dZ.shape[1], _p(y), ldy, _p(coef), _p(_contig_weight(Ws[l])), ci, _p(x), ldx, _p(x_aff),
+                                               _p(red[offs[0]:offs[1]]), _p(dW), ci, _p(rows), rows.shape[1], chans[0], _p(first_scratch),
+                                               P, co, ci, coef_lazy, st)
+                if rc != _lib.PN2_EUNSUPPORTED:
+                    _check(rc, "pn2_conv1x1_bwd_first")
+                    if not direct:
+                        grads[7 * l] = dW.view_as(Ws[l])
+                    dZ = None                                       # (the first layer's dZ exists only as the sums above)
+                    continue
+                first_scratch = None
+            if l == 0 and first_scratch is not None:
+                _check(lib.pn2_conv1x1_wgrad_cf(None, 0, _p(coef), _p(x), ldx, _p(_contig_weight(Ws[l])), ci, _p(flat[7 * l + 1]),
+                                                _p(first_scratch), _p(dW), ci, P, co, ci, coef_lazy, st), "pn2_conv1x1_wgrad_cf")
+                if not direct:
+                    grads[7 * l] = dW.view_as(Ws[l])
+                continue
             if y is None:
                 # pooled last layer without its output: dX and dW from (dZp, arg) and the layer's input alone
                 scratch = torch.empty(int(lib.pn2_conv1x1_bwd_cf_scratch_bytes(co, ci)), device=dev, dtype=torch.uint8)

@@ -729,3 +729,87 @@ def test_batchnorm_backward_sums_of_the_split_kernels_do_not_drift_with_the_row_
     e0, e1, ew = _rel(redsum[0], ref["r0"]), _rel(redsum[1], ref["r1"]), _rel(dW, ref["dW"])
     print("2^%d rows: sum dX %.2e  sum dX xhat %.2e  dW %.2e" % (log2P, e0, e1, ew))
     assert e0 <= 1e-6 and e1 <= 1e-6 and ew <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,co,ci", [(65536, 96, 64), (65536, 64, 64), (131072 + 64, 96, 64)])
+def test_fused_backward_with_the_first_layers_sums_vs_fp64(dev, P, co, ci):
+    """Round 6: pn2_conv1x1_bwd_first -- the second layer's fused backward forms sum_p dZ1[p, c] x0[p, j] from its dX tiles (dZ1 is
+    never written) and pn2_conv1x1_wgrad_cf (dZ == NULL) finishes the FIRST layer's weight gradient from the input's moments -- against
+    fp64 on fixed operands: this layer's dW and reductions as in the plain fused backward, the first layer's dW as
+    c0 dZ1^T x0 + q1 (W0 S + (b0 - mean0) s^T) + q0 s^T with S, s the input's moments."""
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    old_opt = _lib.options()["PN2_FUSE_FIRST"]
+    _lib.set_option("PN2_FUSE_FIRST", 1)               # (off by default: measured slower than the two separate launches)
+    try:
+        _bwd_first_case(dev, lib, st, P, co, ci)
+    finally:
+        _lib.set_option("PN2_FUSE_FIRST", old_opt)
+
+
+def _bwd_first_case(dev, lib, st, P, co, ci):
+    assert lib.pn2_conv1x1_bwd_first_supported(P, co, ci, 12) == 1
+    c, ref = _fixed_layer_case(dev, P, co, ci, 0, 3 * P + co)
+    g = torch.Generator(device=dev).manual_seed(P + 7)
+    rnd = lambda *s_: torch.randn(*s_, device=dev, generator=g)
+    X0 = rnd(P, 12)
+    W0, b0 = rnd(ci, 12) * 0.3, rnd(ci) * 0.1
+    coef0 = torch.zeros(4 * ci, device=dev)
+    coef0[:ci] = rnd(ci) * 0.5 + 1.0
+    coef0[ci:2 * ci] = rnd(ci) * 1e-3
+    coef0[2 * ci:3 * ci] = rnd(ci) * 1e-3
+    coef0[3 * ci:] = rnd(ci) * 0.3
+    red = torch.zeros(8 * 2 * ci, device=dev, dtype=torch.float64)
+    dW = torch.zeros(co, ci, device=dev)
+    scratch = torch.zeros(int(lib.pn2_conv1x1_wgrad_cf_scratch_bytes()), device=dev, dtype=torch.uint8)
+    rc = lib.pn2_conv1x1_bwd_first(*c["dz_args"][:2], c["Y"].data_ptr(), c["ldc"], c["coef"].data_ptr(), c["W"].data_ptr(), ci, c["Yp"].data_ptr(),
+                                   c["ldp"], c["affp"].data_ptr(), red.data_ptr(), dW.data_ptr(), ci, X0.data_ptr(), 12, 12, scratch.data_ptr(),
+                                   P, co, ci, None, st)
+    assert rc == 0
+    dW0 = torch.zeros(ci, 12, device=dev)
+    rc = lib.pn2_conv1x1_wgrad_cf(None, 0, coef0.data_ptr(), X0.data_ptr(), 12, W0.data_ptr(), 12, b0.data_ptr(), scratch.data_ptr(), dW0.data_ptr(), 12,
+                                  P, ci, 12, None, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    redsum = red.view(8, 2, ci).sum(0)
+    x0 = X0.double()
+    c0, q1, q0, mu = (coef0[i * ci:(i + 1) * ci].double() for i in range(4))
+    S, sv = x0.t() @ x0, x0.sum(0)
+    dW0_ref = c0[:, None] * (ref["dX"].t() @ x0) + q1[:, None] * (W0.double() @ S + (b0.double() - mu)[:, None] * sv[None, :]) + q0[:, None] * sv[None, :]
+    errs = (_rel(dW, ref["dW"]), _rel(redsum[0], ref["r0"]), _rel(redsum[1], ref["r1"]), _rel(dW0, dW0_ref))
+    print("bwd_first (%d, %d x %d): dW %.2e  red %.2e %.2e  first layer's dW %.2e" % ((P, co, ci) + errs))
+    assert max(errs) <= 3e-6, errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,pool,chans", [(262144, 128, [9, 64, 96, 128]), (131072, 64, [12, 64, 64, 128])])
+def test_shared_mlp_with_the_fused_first_layer_option(dev, P, pool, chans):
+    """The whole stack through the Python glue with PN2_FUSE_FIRST=1 (pn2_conv1x1_bwd_first + pn2_conv1x1_wgrad_cf without dZ), held
+    to fp64 like every other stack.  (The grouped-row first layer is reached through grouped_mlp in the modules; shared_mlp on
+    plain rows takes the same backward branch only with a gather context, so this drives sa1 of a small MSG module instead.)"""
+    from pointnet12_amd import pointnet_util as U2
+    old_opt = _lib.options()["PN2_FUSE_FIRST"]
+    res = {}
+    B, N, S, K = 4, 4096, P // pool // 4, pool
+    gen = torch.Generator().manual_seed(P)
+    xyz = torch.rand(B, 3, N, generator=gen) * 2 - 1
+    feat = torch.randn(B, chans[0] - 3, N, generator=gen)
+    try:
+        for opt in (0, 1):
+            _lib.set_option("PN2_FUSE_FIRST", opt)
+            torch.manual_seed(7)
+            sa = U2.PointNetSetAbstraction(S, 0.4, K, chans[0], chans[1:], False).to(dev).train()
+            torch.manual_seed(11)
+            with _lib.call_profile() as calls:
+                new_xyz, out = sa(xyz.to(dev), feat.to(dev))
+                gw = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+                (out * gw).sum().backward()
+                torch.cuda.synchronize()
+                names = [c_[0] for c_ in calls]
+            assert ("pn2_conv1x1_bwd_first" in names) == bool(opt), names        # (the option really switches the path)
+            res[opt] = [out.detach().clone()] + [p.grad.clone() for p in sa.parameters()]
+    finally:
+        _lib.set_option("PN2_FUSE_FIRST", old_opt)
+    for a, b in zip(res[0], res[1]):
+        scale = max(float(a.abs().max()), 1e-12)
+        assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
