@@ -518,6 +518,9 @@ int launch_bwd_res_impl(ResDy dy, const float *Yp, int ldp, const float *aff_p, 
     return pn2_launch_status();
 }
 
+#ifndef PN2_SPLIT_RES_DXFREE
+#define PN2_SPLIT_RES_DXFREE 1
+#endif
 // ----------------------------------------------------------------------------------------------- fused backward, bf16 pipe (round 5)
 // bwd_res_kernel's job -- dX = dY W masked by the previous ReLU with its BatchNorm-backward sums, dW += dY^T act(Y_prev), ONE pass
 // over dZ / Y / Y_prev -- with the fp32 products formed from exact three-way bf16 splits (split_bf16.h; mlp_wide.hip's
@@ -545,8 +548,17 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     constexpr int PANEL = BP * 256, BUF = 6 * PANEL;                // one 128-channel panel per piece: dY hi / mid / lo, X hi / mid / lo
     constexpr int KBX = Co / 16;                                    // contraction blocks of a dX tile
     constexpr int NDW = 8 - CI_T, NTILE = CO_T * CI_T, TW = (NTILE + NDW - 1) / NDW;     // dW tiles: waves CI_T .. 7, TW each at most
-    constexpr int IT_D = (BP * QD + NT - 1) / NT, IT_P = (BP * QP + NT - 1) / NT;
-    static_assert(!POOLED || NT % QD == 0, "pooled: one channel quad per thread");
+    // DXFREE (round 6): where only one or two waves own dX tiles and the others hold one weight-gradient tile each (96 x 64, 64 x 64,
+    // 32 x 32), the dX waves were the long pole -- their share of the staging, then 6 C_out / 16 MFMAs, then the mask epilogue, while
+    // the other waves spent 40 - 57 % of the loop at the barrier (in-kernel stamps, profiles/r05c_stamp_split_bwd_res.txt).  There the
+    // dX waves do NO staging: the six or seven other waves stage the whole chunk (the structure split_bwd_cf_kernel was built with).
+    // In the serial step (real activations): 96 x 64 at 1 M rows 269.6 -> 242.9 us, 64 x 64 109.9 -> 113.2; MSG step 4.986 -> 4.959 ms
+    // over three alternating runs.  (Alone on random operands the same kernels measure 301 -> 317 and 111 -> 117: the microbench's
+    // dense random data keeps the staging waves' split arithmetic and the chip's clock elsewhere than the step's ReLU-sparse rows do.)
+    constexpr bool DXFREE = CI_T <= 2 && CO_T <= 3 && PN2_SPLIT_RES_DXFREE;
+    constexpr int NTS = DXFREE ? NT - 64 * CI_T : NT;               // staging threads
+    constexpr int IT_D = (BP * QD + NTS - 1) / NTS, IT_P = (BP * QP + NTS - 1) / NTS;
+    static_assert(!POOLED || NTS % QD == 0, "pooled: one channel quad per thread");
     unsigned char *lds_b = reinterpret_cast<unsigned char *>(res_lds);
     float *Yps = res_lds + (2 * BUF) / 4;                           // [2][BP][LDP]: the raw Y_prev chunk
     // SIGN ALTERNATION (round 6).  v_mfma_f32_32x32x16_bf16 does not round its accumulation to nearest: against fp64 every product sum
@@ -575,6 +587,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     // ---- roles (the two kinds of wave run separate instantiations of the chunk loop: a dX wave's 96 fragment registers and a dW
     // wave's 64 accumulator registers then share the register file instead of adding up)
     const bool has_dx = wave < CI_T;
+    const int ts = DXFREE ? (has_dx ? 0 : t - 64 * CI_T) : t;       // staging thread index
     const int ecol = (has_dx ? wave : 0) * 32 + l31;                // the dX tile's column of this lane
     // ---- staging: dY item i of thread t = quad q of row `row` (idx = t + 512 i; a thread without an i-th item repeats its last)
     struct Raw { float4 y[IT_D]; float4 z[POOLED ? 1 : IT_D]; int4 a[1]; float4 p[IT_P]; float4 x0; };
@@ -583,8 +596,8 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
     constexpr bool D2 = CO_T < 4 && !(FUSE0 && CO_T == 3);          // (96 x 64 with FUSE0: twelve more live registers per dX lane -- one set)
     constexpr bool DX2 = CO_T * CI_T < 16;                          // two alternating dX accumulators (128 x 128: no registers for them, no LDS for WL_LDS)
     Raw raw0, raw1;
-    auto d_item = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QD) ? min(t + NT * i, BP * QD - 1) : t + NT * i; row = idx / QD; q = idx - row * QD; };
-    auto p_item = [&](int i, int &row, int &q) { const int idx = (NT * (i + 1) > BP * QP) ? min(t + NT * i, BP * QP - 1) : t + NT * i; row = idx / QP; q = idx - row * QP; };
+    auto d_item = [&](int i, int &row, int &q) { const int idx = (NTS * (i + 1) > BP * QD) ? min(ts + NTS * i, BP * QD - 1) : ts + NTS * i; row = idx / QD; q = idx - row * QD; };
+    auto p_item = [&](int i, int &row, int &q) { const int idx = (NTS * (i + 1) > BP * QP) ? min(ts + NTS * i, BP * QP - 1) : ts + NTS * i; row = idx / QP; q = idx - row * QP; };
     auto fetch = [&](Raw &raw, int64_t chunk) {
         const unsigned m0 = (unsigned)(chunk < chunks ? chunk : chunks - 1) * BP;      // past the end: re-read the last chunk (never used)
 #pragma unroll
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
             if (!POOLED) raw.z[POOLED ? 0 : i] = ld4(dy.dZ + o);
         }
         if (POOLED) {                                               // the chunk lies inside ONE group (Kp a multiple of 32)
-            const unsigned o = (m0 >> dy.kshift) * (unsigned)dy.ldo + 4u * (unsigned)(t % QD);
+            const unsigned o = (m0 >> dy.kshift) * (unsigned)dy.ldo + 4u * (unsigned)(ts % QD);
             raw.z[0] = ld4(dy.dZp + o);
             raw.a[0] = ld4i(dy.arg + o);
         }
@@ -607,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
             raw.p[i] = ld4(Yp + ((m0 + (unsigned)row) * (unsigned)ldp + 4u * (unsigned)q));
         }
         if (FUSE0) {                                                // threads 0 .. 95: quad t % 3 of row t / 3 (the others repeat the last)
-            const unsigned i0 = (unsigned)(t < 3 * BP ? t : 3 * BP - 1);
+            const unsigned i0 = (unsigned)(ts < 3 * BP ? ts : 3 * BP - 1);
             raw.x0 = ld4(X0 + ((m0 + i0 / 3u) * (unsigned)ld0 + 4u * (i0 % 3u)));
         }
     };
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
             }
             store_split(ib, row, q, x);
         }
-        if (FUSE0 && t < 3 * BP) *reinterpret_cast<float4 *>(&x0s[buf * (BP * 12) + 4 * t]) = raw.x0;      // [row][12]: 4 t = 12 (t / 3) + 4 (t % 3)
+        if (FUSE0 && ts < 3 * BP) *reinterpret_cast<float4 *>(&x0s[buf * (BP * 12) + 4 * ts]) = raw.x0;    // [row][12]: 4 t = 12 (t / 3) + 4 (t % 3)
     };
     auto raw_landed = [&](Raw &raw) {                                       // (see split_nt_kernel: hipcc then waits for the requests, not for the stores)
 #pragma unroll
@@ -726,17 +739,20 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
                 for (int r = 0; r < 16; ++r) accw[DXW ? 0 : j][r] = 0.f;
         }
         int64_t chunk = blockIdx.x;
-        fetch(raw0, chunk);
+        constexpr bool STAGES = !(DXW && DXFREE);                   // (this instantiation's waves take part in the staging)
+        if (STAGES) fetch(raw0, chunk);
         __syncthreads();                                            // the tables are in place
-        stage(raw0, chunk, 0);
-        if (D2) {
-            fetch(raw1, chunk + G);
-            fetch(raw0, chunk + 2 * (int64_t)G);
-            raw_landed(raw1);
-        } else {
-            fetch(raw0, chunk + G);
+        if (STAGES) {
+            stage(raw0, chunk, 0);
+            if (D2) {
+                fetch(raw1, chunk + G);
+                fetch(raw0, chunk + 2 * (int64_t)G);
+                raw_landed(raw1);
+            } else {
+                fetch(raw0, chunk + G);
+            }
+            raw_landed(raw0);
         }
-        raw_landed(raw0);
         int buf = 0;
         RABS(wave, 1)
         RSTAMP_DECL
@@ -746,9 +762,9 @@ __global__ __launch_bounds__(512, 1) void split_bwd_res_kernel(ResDy dy, const f
         auto iter = [&](Raw &raw) {
             __syncthreads();                                        // this chunk is staged in `buf`; every wave is done with buf ^ 1
             RSTAMP(2)
-            stage(raw, chunk + G, buf ^ 1);
+            if (STAGES) stage(raw, chunk + G, buf ^ 1);
             RSTAMP(0)
-            fetch(raw, chunk + (D2 ? 3 : 2) * (int64_t)G);
+            if (STAGES) fetch(raw, chunk + (D2 ? 3 : 2) * (int64_t)G);
             __builtin_amdgcn_sched_barrier(0);                      // (hipcc sinks the requests below the MFMAs otherwise: ISA of the first version)
             RSTAMP(1)
             const unsigned char *ia = lds_b + buf * BUF, *ib = ia + 3 * PANEL;
