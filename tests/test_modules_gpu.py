@@ -302,8 +302,9 @@ def test_direct_grad_accumulation_matches_autograd(dev):
     assert abs(float(a.norm()) - float(b.norm())) <= 5e-3 * float(a.norm())
 
 
-def test_prefetched_geometry_graph_matches_eager(dev):
-    """Graph with the next batch's geometry on a side stream: same loss sequence as plain eager steps (same draws)."""
+def _eager_and_captured_sequences(dev):
+    """(losses, bucket, recorded geometry per step) of four steps run eagerly, as a captured step with the next batch's geometry on a side
+    stream, and with that branch forked between forward and backward -- same draws."""
     from pointnet12_amd import parallel
     from pointnet12_amd.graph import GraphedStep
     g = golden("g6_nets.npz")
@@ -358,7 +359,12 @@ def test_prefetched_geometry_graph_matches_eager(dev):
                 # the tape replay r ran on (graph r % 2 reads the tape the other graph's side branch wrote one replay earlier)
                 geos.append([t.detach().cpu().clone() for t in G_._flatten(step._tapes[r % 2].items)])
         seqs.append((losses, bucket.flat.clone(), geos))
-    (la, ga, ta), (lb, gb, tb), (lc, gc, tc) = seqs
+    return seqs
+
+
+def test_prefetched_geometry_graph_matches_eager(dev):
+    """Graph with the next batch's geometry on a side stream: same loss sequence as plain eager steps (same draws)."""
+    (la, ga, ta), (lb, gb, tb), (lc, gc, tc) = _eager_and_captured_sequences(dev)
     # ADVICE r5: the geometry is index-exact -- the recorded tensors (FPS indices, centres, ball-query indices, 3-NN indices and
     # weights) of every step must be bit-identical between the eager run and both captured schedules; a tape or stream-ordering
     # race cannot hide under the loss tolerance below
@@ -375,12 +381,18 @@ def test_prefetched_geometry_graph_matches_eager(dev):
                     assert torch.equal(torch.sort(u.flatten())[0], torch.sort(v.flatten())[0]), (name, r, i)
                     continue
                 assert torch.equal(u, v), "%s: recorded geometry %d of step %d differs from the eager step's" % (name, i, r)
-    # (a wrong start draw or a stale tape samples other points and moves the loss by 1e-2 and more; the three schedules differ in
-    # the ORDER of the statistics atomics, which now and then flips a pooled arg-max and moves the loss of these small clouds in
-    # the fifth digit -- one full-suite run in five of round 5 tripped a 2e-5 bound here and passed when repeated)
-    assert np.allclose(la, lb, rtol=0, atol=2e-4), (la, lb)
+    # The forward has no order-dependent arithmetic left except the fp64 statistics atomics (1e-16 of a sum): measured, the three
+    # loss sequences are BIT-IDENTICAL (tools/exp/graph_eager_loss_delta.py: 32 of 32 comparisons, round 6).  Back to 2e-5 (round 5
+    # had widened it to 2e-4 after one trip in five full-suite runs that nothing reproduced); a difference beyond it must
+    # reproduce in a second evaluation -- a wrong start draw or a stale tape moves the loss by 1e-2 every time, a last-bit flip
+    # of a statistic does not come twice.
+    def close(x, y):
+        return np.allclose(x, y, rtol=0, atol=2e-5)
+    if not (close(la, lb) and close(la, lc)):
+        (la, ga, _), (lb, gb, _), (lc, gc, _) = _eager_and_captured_sequences(dev)
+    assert close(la, lb), (la, lb)
     assert abs(float(ga.norm()) - float(gb.norm())) <= 5e-3 * float(ga.norm())
-    assert np.allclose(la, lc, rtol=0, atol=2e-4), (la, lc)
+    assert close(la, lc), (la, lc)
     assert abs(float(ga.norm()) - float(gc.norm())) <= 5e-3 * float(ga.norm())
 
 
