@@ -88,6 +88,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         float cx, cy, cz;
         if (XYZ_LDS) {
             float4 c = cloud[far];
+            PN2_LDS_SETTLE3(c.x, c.y, c.z);                        // (the packed distance arithmetic below reads it first: pn2_common.h)
             cx = c.x; cy = c.y; cz = c.z;
         } else {
             int f = __builtin_amdgcn_readfirstlane(far);
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
         if (t == 0) o[it] = far;
         float cx, cy, cz;
         if (XYZ_LDS) {
-            const float4 c = cloud[far];
+            float4 c = cloud[far];
+            PN2_LDS_SETTLE3(c.x, c.y, c.z);
             cx = c.x; cy = c.y; cz = c.z;
         } else {
             const int f = __builtin_amdgcn_readfirstlane(far);
@@ -498,7 +500,8 @@ __global__ __launch_bounds__(THREADS) void fps_rows_kernel(const float *__restri
         if (t == 0) o[it] = far;
         float cx, cy, cz;
         if (XYZ_LDS) {
-            const float4 c = cloud[far];
+            float4 c = cloud[far];
+            PN2_LDS_SETTLE3(c.x, c.y, c.z);
             cx = c.x; cy = c.y; cz = c.z;
         } else {
             const int f = __builtin_amdgcn_readfirstlane(far);
@@ -739,7 +742,8 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
                 bcast[it & 1] = make_float4(wx, wy, wz, __uint_as_float(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull)));
         }
         __syncthreads();
-        const float4 c = bcast[it & 1];
+        float4 c = bcast[it & 1];
+        PN2_LDS_SETTLE4(c.x, c.y, c.z, c.w);
         cx = c.x; cy = c.y; cz = c.z;
         far = (int)__float_as_uint(c.w);
     }

@@ -148,6 +148,19 @@ static inline int pn2_raise_dynamic_lds_once(const void *kernel) {
     return PN2_OK;
 }
 
+// PN2_LDS_SETTLE (round 6; HISTORY.md "pn2_fps beside the pooled bf16-split forward"): wait for an LDS read and idle four states
+// before anything touches its registers.  pn2_fps read the winner's coordinates with one broadcast ds_read_b96 and fed them
+// straight into packed-fp32 arithmetic (v_pk_add_f32 with op_sel); co-resident on a CU with the pooled split_nt forward (another
+// workgroup's bf16 MFMAs on the same SIMDs -- the captured training step's geometry branch) one 32-bit vector WRITE of lanes 48..63
+// near that read was lost now and then (a running minimum kept its old value), and 4 .. 100 % of the launches returned a different
+// sample list; alone: never.  tools/exp/pk_probe.hip reproduces it outside the library (packed and scalar distances of the same
+// registers differ in lanes 48..63: 12 000 .. 150 000 events in 960 workgroup runs beside that kernel, 0 alone), and every form that
+// keeps the packed arithmetic away from the read's return -- this macro, three ds_read_b32, the centre through SGPRs, scalar
+// arithmetic -- measured 0.  The mechanism is NOT established (hand-written sequences around a wide read did not reproduce it:
+// tools/exp/lds_reader_probe.hip); tests/test_geometry_gpu.py keeps the measurement in the suite.
+#define PN2_LDS_SETTLE3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c))
+#define PN2_LDS_SETTLE4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
 // 64-bit max across a wave with xor-shuffles; every lane ends with the result.
 __device__ __forceinline__ unsigned long long pn2_wave_max_u64(unsigned long long v) {
 #pragma unroll

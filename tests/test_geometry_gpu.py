@@ -299,3 +299,58 @@ def test_fps_spatially_pruned_kernel_vs_oracle(dev, N, S, kind):
     ref = G.farthest_point_sample(xyz, S, start)
     mine = U.farthest_point_sample(cu(xyz, dev), S, cu(start, dev)).cpu().numpy()
     assert (mine == ref).all(), (np.argwhere(mine != ref)[:3], kind)
+
+
+@pytest.mark.parametrize("B,N,S", [(16, 4096, 512), (2, 1024, 512), (8, 2048, 256)])
+def test_fps_beside_the_pooled_split_forward_is_index_exact(dev, B, N, S):
+    """Round 6 (HISTORY.md: "pn2_fps beside the pooled bf16-split forward"): the captured training step runs the next batch's sampling on
+    a side stream while the main stream runs the MLPs.  Co-resident with the pooled split_nt forward, pn2_fps used to return a different
+    sample list in 4 .. 100 % of the launches (one 32-bit write of lanes 48..63 lost near the winner's LDS read; PN2_LDS_SETTLE in
+    pn2_common.h).  Here: the same launch on a side stream beside that kernel, 40 times, against the oracle's list -- bit for bit."""
+    from pointnet12_amd import _lib
+    from pointnet12_amd._lib import ptr as p
+
+    lib = _lib.load()
+    pts, _ = syn.kitti_batch(0, B, N)
+    xyz_np = np.ascontiguousarray(pts[:, :3, :].transpose(0, 2, 1))
+    xyz = cu(xyz_np, dev)
+    P = 1 << 18
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(P, 96, device=dev, generator=g)
+    W = torch.randn(128, 96, device=dev, generator=g)
+    bias = torch.randn(128, device=dev, generator=g)
+    Y = torch.empty(P, 128, device=dev)
+    aff = torch.zeros(4 * 96, device=dev)
+    aff[96:192] = 1
+    aff[288:] = 1
+    stats = torch.zeros(8 * 2 * 128, device=dev, dtype=torch.float64)
+    ws = torch.zeros(2 * (P // 128) * 128, device=dev)
+    main_s = torch.cuda.current_stream().cuda_stream
+
+    def pooled_forward():
+        rc = lib.pn2_conv1x1_fwd_pool(p(X), 96, p(aff), p(W), 96, p(bias), p(Y), 128, P, 96, 128, p(stats), 128, p(bias), p(ws), None, main_s)
+        assert rc == 0
+        assert b"split_nt_kernel" in (lib.pn2_last_kernel() or b""), "this test is about the bf16-split pooled forward"
+
+    side = torch.cuda.Stream(device=dev)
+    rng = np.random.default_rng(1)
+    differ = 0
+    for wg2 in (1, 0):                              # two workgroups per CU (the default) and one (pn2_fps finds room on every CU)
+        _lib.set_option("PN2_SPLIT_WG2", wg2)
+        try:
+            for _ in range(20):
+                start_np = rng.integers(0, N, B)
+                ref = G.farthest_point_sample(xyz_np, S, start_np)
+                start = cu(start_np, dev)
+                torch.cuda.synchronize()
+                side.wait_stream(torch.cuda.current_stream())
+                pooled_forward()
+                with torch.cuda.stream(side):
+                    mine = U.farthest_point_sample(xyz, S, start)
+                pooled_forward()
+                pooled_forward()
+                torch.cuda.synchronize()
+                differ += int(not (mine.cpu().numpy() == ref).all())
+        finally:
+            _lib.set_option("PN2_SPLIT_WG2", 1)
+    assert differ == 0, "%d of 40 pn2_fps launches beside the pooled split forward differ from the oracle" % differ

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Round 6: tools/exp/lds_reader_probe.hip beside the pooled bf16-split forward: which first reader of a fresh wide LDS read sees stale lanes."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from pointnet12_amd import _lib
+from pointnet12_amd import synthetic as syn
+from pointnet12_amd._lib import ptr as p
+
+
+def main(trials=60):
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    probe = ctypes.CDLL(os.path.join(ROOT, "tools", "exp", "liblds_reader_probe.so"))
+    probe.reader_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    big_np, _ = syn.kitti_batch(0, 16, 4096)
+    xyz = torch.from_numpy(np.ascontiguousarray(big_np[:, :3, :].transpose(0, 2, 1))).to(dev)
+    B, N = 16, 4096
+    P = 1 << 19
+    g = torch.Generator(device=dev).manual_seed(0)
+    X96 = torch.randn(P, 96, device=dev, generator=g)
+    W128 = torch.randn(128, 96, device=dev, generator=g)
+    b128 = torch.randn(128, device=dev, generator=g)
+    Y128 = torch.empty(P, 128, device=dev)
+    aff96 = torch.zeros(4 * 96, device=dev); aff96[96:192] = 1; aff96[288:] = 1
+    st128 = torch.zeros(8 * 2 * 128, device=dev, dtype=torch.float64)
+    ws = torch.zeros(2 * (P // 128) * 128, device=dev)
+    main_s = torch.cuda.current_stream().cuda_stream
+    _lib.set_option("PN2_SPLIT_WG2", 0)
+
+    def k_pool():
+        assert lib.pn2_conv1x1_fwd_pool(p(X96), 96, p(aff96), p(W128), 96, p(b128), p(Y128), 128, P, 96, 128, p(st128), 128, p(b128), p(ws), None, main_s) == 0
+
+    def k_none():
+        pass
+
+    kinds = {0: "b128, v_pk_add_f32 of the low pair", 1: "b128, two v_add_f32", 2: "b128, v_pk_mul_f32 of the high pair", 3: "b128, v_fma_f64 of the low pair",
+             4: "b128, one idle state, v_pk_add_f32", 5: "b64, v_pk_add_f32", 6: "b128, v_mfma_f32_32x32x2_f32", 7: "b128, v_mfma_f32_32x32x16_bf16",
+             8: "b128, pk add op_sel/neg (failing form)", 9: "b96, pk add op_sel/neg", 10: "b128, 4 VALU before wait, pk op_sel/neg",
+             11: "b128, 4 VALU before wait, plain pk add", 12: "b96 onto its address reg, 4 VALU, pk",
+             13: "b128, 16 VALU, wait, v_add_f32", 14: "b128, 16 VALU, wait, pk add", 15: "b128, 24 VALU, wait, v_add_f32",
+             16: "b128, 16 VALU, wait, 1 idle, v_add_f32", 17: "b128, 16 VALU, wait, 4 idle, v_add_f32", 18: "2 x b32, 16 VALU, wait, v_add_f32",
+             19: "b128, 8 VALU, wait, v_add_f32", 20: "b128, 12 VALU, wait, v_add_f32", 21: "b64, 16 VALU, wait, v_add_f32",
+             22: "b96, wait, packed + 32-bit mix", 23: "b96, wait, 4 idle, packed + 32-bit mix", 24: "b96, wait, 32-bit only",
+             25: "b96, wait, 16 idle, packed + 32-bit mix", 26: "b96 onto its address, wait, mix",
+             27: "32 VALU writes under a b128 read", 28: "32 VALU writes under a b32 read", 29: "32 VALU writes, no LDS read", 30: "b128, wait, 32 VALU writes"}
+    if len(sys.argv) > 1:
+        kinds = {k: v for k, v in kinds.items() if k in [int(a) for a in sys.argv[1:]]}
+    side = torch.cuda.Stream(device=dev)
+    for kind, label in kinds.items():
+        for name, kern in (("beside the pooled split forward", k_pool),):
+            out = torch.zeros(8 + 4 * 32, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            for tr in range(trials):
+                side.wait_stream(torch.cuda.current_stream())
+                kern()
+                with torch.cuda.stream(side):
+                    assert probe.reader_probe(xyz.data_ptr(), B, N, 2048, kind, out.data_ptr(), side.cuda_stream) == 0
+                kern(); kern()
+                torch.cuda.synchronize()
+            o = out.cpu().numpy().view(np.uint32)
+            lanes = sorted({int(o[9 + 4 * k]) % 64 for k in range(min(32, int(o[2])))})
+            print("%-42s %-32s: %d workgroup runs; first reader != late reader %d times in %d threads%s" % (
+                label + ",", name, o[3], o[0], o[2], ("; lanes seen " + str(lanes)) if lanes else ""))
+
+
+if __name__ == "__main__":
+    main()
