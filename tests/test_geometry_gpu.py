@@ -354,3 +354,53 @@ def test_fps_beside_the_pooled_split_forward_is_index_exact(dev, B, N, S):
         finally:
             _lib.set_option("PN2_SPLIT_WG2", 1)
     assert differ == 0, "%d of 40 pn2_fps launches beside the pooled split forward differ from the oracle" % differ
+
+
+def test_ball_query_and_three_nn_beside_the_pooled_split_forward_are_index_exact(dev):
+    """The rest of the captured step's geometry branch under the same co-residency as the test above (both kernels read LDS and compute
+    with packed fp32 operations): 20 launches each on a side stream beside the pooled split_nt forward equal the launch alone."""
+    from pointnet12_amd import _lib
+    from pointnet12_amd._lib import ptr as p
+
+    lib = _lib.load()
+    B, N, S = 16, 4096, 1024
+    pts, _ = syn.kitti_batch(0, B, N)
+    xyz = cu(np.ascontiguousarray(pts[:, :3, :].transpose(0, 2, 1)), dev)
+    new_xyz = xyz[:, :S].contiguous()
+    P = 1 << 18
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(P, 96, device=dev, generator=g)
+    W = torch.randn(128, 96, device=dev, generator=g)
+    bias = torch.randn(128, device=dev, generator=g)
+    Y = torch.empty(P, 128, device=dev)
+    aff = torch.zeros(4 * 96, device=dev)
+    aff[96:192] = 1
+    aff[288:] = 1
+    stats = torch.zeros(8 * 2 * 128, device=dev, dtype=torch.float64)
+    ws = torch.zeros(2 * (P // 128) * 128, device=dev)
+    main_s = torch.cuda.current_stream().cuda_stream
+
+    def pooled_forward():
+        assert lib.pn2_conv1x1_fwd_pool(p(X), 96, p(aff), p(W), 96, p(bias), p(Y), 128, P, 96, 128, p(stats), 128, p(bias), p(ws), None, main_s) == 0
+
+    ref_bq = U.query_ball_point(0.2, 32, xyz, new_xyz)
+    ref_i, ref_d = U.three_nn(xyz, new_xyz)[:2]
+    side = torch.cuda.Stream(device=dev)
+    differ = 0
+    for wg2 in (1, 0):
+        _lib.set_option("PN2_SPLIT_WG2", wg2)
+        try:
+            for _ in range(10):
+                torch.cuda.synchronize()
+                side.wait_stream(torch.cuda.current_stream())
+                pooled_forward()
+                with torch.cuda.stream(side):
+                    bq = U.query_ball_point(0.2, 32, xyz, new_xyz)
+                    i, d = U.three_nn(xyz, new_xyz)[:2]
+                pooled_forward()
+                pooled_forward()
+                torch.cuda.synchronize()
+                differ += int(not (torch.equal(bq, ref_bq) and torch.equal(i, ref_i) and torch.equal(d, ref_d)))
+        finally:
+            _lib.set_option("PN2_SPLIT_WG2", 1)
+    assert differ == 0, "%d of 20 launches beside the pooled split forward differ from the launch alone" % differ
