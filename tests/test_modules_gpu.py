@@ -847,3 +847,40 @@ def test_gather_conv_first_layer_equals_group_then_gemm(dev, K, co, D, xyz_first
     assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5 * float(res[False][0].abs().max())
     for a, b in zip([res[True][1]] + res[True][2], [res[False][1]] + res[False][2]):
         assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6)
+
+
+def test_forward_is_bit_reproducible_and_the_backward_noise_is_bounded(dev):
+    """What is reproducible run to run, measured (HISTORY.md round 6, tools/exp/determinism_probe.py): the FORWARD of a training step --
+    every module's output, the log-probabilities, the loss -- is bit-identical (the statistics are fp64 atomics whose rounding never
+    reached an fp32 bit in any run); the BACKWARD is not (fp32 atomics: the weight-gradient flush, the 3-NN interpolation's and the
+    grouping's scatter-adds), and differs by <= 3.2e-6 of a gradient's largest element.  There is no deterministic mode (VERDICT r5
+    #6: about 80 atomic sites in ten files); this test holds the forward to the bit and the backward to 1e-5."""
+    from pointnet12_amd import pointnet2 as M
+    from pointnet12_amd import synthetic as syn
+    from pointnet12_amd.loss import nll_loss
+    torch.manual_seed(0)
+    net = M.PointNet2SemSegMsg(13, 6).to(dev).train()
+    pts_np, lab_np = syn.kitti_batch(0, 4, 4096)
+    pts, labels = torch.from_numpy(pts_np).to(dev), torch.from_numpy(lab_np).to(dev)
+    acts = {}
+    for name, mod in net.named_children():
+        mod.register_forward_hook(lambda m, i, o, name=name: acts.setdefault(name, []).append((o[1] if isinstance(o, tuple) else o).detach().clone()))
+    runs = []
+    for r in range(3):
+        torch.manual_seed(123)                      # the FPS start draws and the dropout mask
+        net.zero_grad(set_to_none=True)
+        lp = net(pts)
+        loss = nll_loss(lp.reshape(-1, lp.shape[-1]), labels.reshape(-1))
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), lp.detach().clone(), [p.grad.detach().clone() for p in net.parameters()]))
+    for name, lst in acts.items():
+        assert all(torch.equal(lst[0], t) for t in lst[1:]), "forward output of %s differs between two runs" % name
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    names = [n for n, _ in net.named_parameters()]
+    for r in runs[1:]:
+        for n, a, b in zip(names, runs[0][2], r[2]):
+            scale = float(a.abs().max())
+            if scale < 1e-7:                        # (a gradient that is zero in exact arithmetic: conv biases before a BatchNorm, ...)
+                continue
+            assert float((a - b).abs().max()) <= 1e-5 * scale, n
