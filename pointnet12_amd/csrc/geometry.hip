@@ -88,7 +88,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         float cx, cy, cz;
         if (XYZ_LDS) {
             float4 c = cloud[far];
-            PN2_LDS_SETTLE3(c.x, c.y, c.z);                        // (the packed distance arithmetic below reads it first: pn2_common.h)
+            PN2_OPAQUE3(c.x, c.y, c.z);                            // (no high-half selects in the packed arithmetic below: pn2_common.h)
             cx = c.x; cy = c.y; cz = c.z;
         } else {
             int f = __builtin_amdgcn_readfirstlane(far);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(const float *__rest
         float cx, cy, cz;
         if (XYZ_LDS) {
             float4 c = cloud[far];
-            PN2_LDS_SETTLE3(c.x, c.y, c.z);
+            PN2_OPAQUE3(c.x, c.y, c.z);
             cx = c.x; cy = c.y; cz = c.z;
         } else {
             const int f = __builtin_amdgcn_readfirstlane(far);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(THREADS) void fps_rows_kernel(const float *__restri
         float cx, cy, cz;
         if (XYZ_LDS) {
             float4 c = cloud[far];
-            PN2_LDS_SETTLE3(c.x, c.y, c.z);
+            PN2_OPAQUE3(c.x, c.y, c.z);
             cx = c.x; cy = c.y; cz = c.z;
         } else {
             const int f = __builtin_amdgcn_readfirstlane(far);
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(const float *__restrict_
         }
         __syncthreads();
         float4 c = bcast[it & 1];
-        PN2_LDS_SETTLE4(c.x, c.y, c.z, c.w);
+        PN2_OPAQUE4(c.x, c.y, c.z, c.w);
         cx = c.x; cy = c.y; cz = c.z;
         far = (int)__float_as_uint(c.w);
     }

@@ -148,18 +148,20 @@ static inline int pn2_raise_dynamic_lds_once(const void *kernel) {
     return PN2_OK;
 }
 
-// PN2_LDS_SETTLE (round 6; HISTORY.md "pn2_fps beside the pooled bf16-split forward"): wait for an LDS read and idle four states
-// before anything touches its registers.  pn2_fps read the winner's coordinates with one broadcast ds_read_b96 and fed them
-// straight into packed-fp32 arithmetic (v_pk_add_f32 with op_sel); co-resident on a CU with the pooled split_nt forward (another
-// workgroup's bf16 MFMAs on the same SIMDs -- the captured training step's geometry branch) one 32-bit vector WRITE of lanes 48..63
-// near that read was lost now and then (a running minimum kept its old value), and 4 .. 100 % of the launches returned a different
-// sample list; alone: never.  tools/exp/pk_probe.hip reproduces it outside the library (packed and scalar distances of the same
-// registers differ in lanes 48..63: 12 000 .. 150 000 events in 960 workgroup runs beside that kernel, 0 alone), and every form that
-// keeps the packed arithmetic away from the read's return -- this macro, three ds_read_b32, the centre through SGPRs, scalar
-// arithmetic -- measured 0.  The mechanism is NOT established (hand-written sequences around a wide read did not reproduce it:
-// tools/exp/lds_reader_probe.hip); tests/test_geometry_gpu.py keeps the measurement in the suite.
-#define PN2_LDS_SETTLE3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c))
-#define PN2_LDS_SETTLE4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+// PN2_OPAQUE (round 6; HISTORY.md "pn2_fps beside the pooled bf16-split forward"; tools/exp/lds_reader_probe.hip kinds 48 .. 62):
+// ON THIS HARDWARE a packed-fp32 operation (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) whose SECOND source is a VGPR pair read
+// through its HIGH half for the low result (op_sel:[0,1], with or without op_sel_hi / neg modifiers) does not write the LOW half of its
+// result in lanes 48 .. 63 (the register keeps its previous content; the high half is right) while another wave of the same SIMD executes bf16 MFMAs (v_mfma_f32_32x32x16_bf16, v_mfma_f32_16x16x32_bf16): 1.7 M wrong
+// results in 960 workgroup runs beside the pooled bf16-split forward, 19 M beside a bare 16x16x32 spinner, 0 alone, 0 beside fp32
+// MFMAs or vector-only work; the same select on src0, on src2 of an fma, on an SGPR pair, and the LOW-half broadcast
+// (op_sel_hi:[1,0]) measured 0.  hipcc emits the form when it broadcasts the second register of a tuple -- e.g. {cy, cy} from the
+// ds_read_b96 that fetched (cx, cy, cz), which is what pn2_fps did: co-resident with the pooled forward of the captured step, 4 .. 100 %
+// of its launches returned a different sample list.  Passing the scalars through an empty asm statement makes them plain 32-bit
+// values again (no tuple to select a half of): the compiler then broadcasts with the LOW half, a v_mov where needed.
+// tools/check_isa.py `pkhi` (tests/test_isa_cpu.py) fails the build if the form appears anywhere in the library.
+#define PN2_OPAQUE1(a) asm volatile("" : "+v"(a))
+#define PN2_OPAQUE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#define PN2_OPAQUE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 
 // 64-bit max across a wave with xor-shuffles; every lane ends with the result.
 __device__ __forceinline__ unsigned long long pn2_wave_max_u64(unsigned long long v) {

@@ -234,8 +234,10 @@ __global__ __launch_bounds__(256) void three_interp_bwd_seg_kernel(const float *
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     cur = tg[u];
                 }
-                acc.x = __builtin_fmaf(g[u].x, wt[u], acc.x); acc.y = __builtin_fmaf(g[u].y, wt[u], acc.y);
-                acc.z = __builtin_fmaf(g[u].z, wt[u], acc.z); acc.w = __builtin_fmaf(g[u].w, wt[u], acc.w);
+                float wu = wt[u];
+                PN2_OPAQUE1(wu);                       // (a plain scalar: hipcc packed these fmas with a HIGH-half select of a (weight, weight) pair -- pn2_common.h)
+                acc.x = __builtin_fmaf(g[u].x, wu, acc.x); acc.y = __builtin_fmaf(g[u].y, wu, acc.y);
+                acc.z = __builtin_fmaf(g[u].z, wu, acc.z); acc.w = __builtin_fmaf(g[u].w, wu, acc.w);
             }
         }
         if (cur >= 0) row_flush(grad_points2 + (b * S + cur) * D, c, D, acc, !(first && head_shared) && cur != tail_next);

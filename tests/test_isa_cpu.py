@@ -19,3 +19,11 @@ def test_hand_counted_waits_and_no_spills():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py"), "grouped", "scratch", "mlp_wide.hip", "grouped.hip"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="no hipcc")
+def test_no_packed_fp32_operation_selects_the_high_half_of_a_vgpr_source():
+    """Round 6: ``v_pk_*_f32 ... op_sel:[0,1]`` on a VGPR src1 is wrong in lanes 48..63 beside bf16 MFMAs on this hardware
+    (csrc/pn2_common.h, PN2_OPAQUE: it cost pn2_fps its index-exactness in the captured step).  The built library must not hold one."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py"), "pkhi"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -5,6 +5,7 @@
     python tools/check_isa.py grouped    # the hand-counted waits of group_conv_fwd_kernel only
     python tools/check_isa.py scratch    # no kernel may spill beyond the allow-list below (private segment size)
     python tools/check_isa.py scratch mlp_wide.hip grouped.hip     # ... of these files only (what the CPU test suite runs)
+    python tools/check_isa.py pkhi       # no packed-fp32 operation reads a VGPR pair through its HIGH half as second source
 
 1. ``group_conv_fwd_kernel`` (csrc/grouped.hip) issues its gather as inline-asm loads and waits with HAND-COUNTED
    ``s_waitcnt vmcnt(kStores + 1)`` / ``vmcnt(kStores)`` (gfx9 retires loads and stores through one in-order counter; hipcc's
@@ -12,6 +13,11 @@
    16 vector-memory loads and kStores = 3 + C_out / 4 stores, in the order  wait A, wait B, loads, stores, and while everything
    requested in the prologue has been waited for before the first trip (the prologue used to rely on dummy
    stores that the compiler removed).  A compiler upgrade that re-schedules the loop fails HERE, not silently on the GPU.
+3. ``pkhi`` (round 6): on the MI355X of this pool ``v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32`` with ``op_sel:[0,1...]`` on a VGPR src1
+   (the low result takes the HIGH dword of the pair) return wrong values in lanes 48..63 while another wave of the SIMD runs bf16
+   MFMAs (csrc/pn2_common.h, PN2_OPAQUE; tools/exp/lds_reader_probe.hip).  hipcc emits the form by itself when it broadcasts the second
+   register of a tuple; the sources avoid it and this check disassembles the BUILT library (every code object of its fat binary) to
+   make sure a compiler change does not bring it back.
 2. Scratch: a spilled register in a hand-scheduled kernel turns a counted wait into vmcnt(0) and costs far more than its
    28 bytes suggest (minor #12).
 """
@@ -154,13 +160,55 @@ def check_scratch(files=None):
     return errs
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def check_pkhi(lib=None):
+    """Every v_pk_{add,mul,fma}_f32 of the built library: src1 must not be a VGPR pair selected through its high half."""
+    lib = lib or os.path.join(ROOT, "pointnet12_amd", "libpn2_hip.so")
+    if not os.path.exists(lib):
+        return ["pkhi: %s is not built" % lib]
+    errs, total = [], 0
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+        data = open(fat, "rb").read()
+        offs = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]       # one bundle per translation unit
+        for i, o in enumerate(offs):
+            part, co = os.path.join(d, "b%d.bin" % i), os.path.join(d, "b%d.co" % i)
+            open(part, "wb").write(data[o:(offs[i + 1] if i + 1 < len(offs) else len(data))])
+            subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, stderr=subprocess.DEVNULL)
+            asm = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", co], capture_output=True, text=True).stdout
+            cur = "?"
+            for ln in asm.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+                if m:
+                    cur = m.group(1)
+                    continue
+                m = re.search(r"\b(v_pk_(?:add|mul|fma)_f32)\s+(.*)", ln.split("//")[0])
+                if not m:
+                    continue
+                total += 1
+                sel = re.search(r"op_sel:\[[01],([01])", m.group(2))
+                src1 = [f.strip() for f in m.group(2).split(",")][2]
+                if sel and sel.group(1) == "1" and src1.startswith("v"):
+                    name = subprocess.run(["c++filt", cur], capture_output=True, text=True).stdout.strip()
+                    errs.append("pkhi: %s: %s %s" % (name[:100], m.group(1), m.group(2).strip()))
+    if total < 1000:
+        errs.append("pkhi: only %d packed fp32 operations found in %s -- the disassembly did not work" % (total, lib))
+    return errs[:20]
+
+
 def main():
-    what = sys.argv[1:] or ["grouped", "scratch"]
+    what = sys.argv[1:] or ["grouped", "scratch", "pkhi"]
     errs = []
     if "grouped" in what:
         errs += check_grouped()
     if "scratch" in what:
         errs += check_scratch([w for w in what if w.endswith(".hip")] or None)
+    if "pkhi" in what:
+        errs += check_pkhi()
     for e in errs:
         print("ISA CHECK FAILED: " + e)
     if not errs:

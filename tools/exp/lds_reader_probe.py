@@ -40,6 +40,16 @@ def main(trials=60):
     def k_none():
         pass
 
+    sink = torch.zeros(256, device=dev)
+    probe.spin.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    spin_names = {"bf16": (0, 3000, "a spinner of v_mfma_f32_32x32x16_bf16"), "f32": (1, 1500, "a spinner of v_mfma_f32_32x32x2_f32"),
+                  "valu": (2, 60000, "a spinner of vector fmas (no MFMA)"), "bf16s": (3, 6000, "a spinner of v_mfma_f32_16x16x32_bf16")}
+
+    def k_spin(kind, iters):
+        def f():
+            assert probe.spin(sink.data_ptr(), kind, 1024, iters, main_s) == 0
+        return f
+
     kinds = {0: "b128, v_pk_add_f32 of the low pair", 1: "b128, two v_add_f32", 2: "b128, v_pk_mul_f32 of the high pair", 3: "b128, v_fma_f64 of the low pair",
              4: "b128, one idle state, v_pk_add_f32", 5: "b64, v_pk_add_f32", 6: "b128, v_mfma_f32_32x32x2_f32", 7: "b128, v_mfma_f32_32x32x16_bf16",
              8: "b128, pk add op_sel/neg (failing form)", 9: "b96, pk add op_sel/neg", 10: "b128, 4 VALU before wait, pk op_sel/neg",
@@ -49,13 +59,34 @@ def main(trials=60):
              19: "b128, 8 VALU, wait, v_add_f32", 20: "b128, 12 VALU, wait, v_add_f32", 21: "b64, 16 VALU, wait, v_add_f32",
              22: "b96, wait, packed + 32-bit mix", 23: "b96, wait, 4 idle, packed + 32-bit mix", 24: "b96, wait, 32-bit only",
              25: "b96, wait, 16 idle, packed + 32-bit mix", 26: "b96 onto its address, wait, mix",
-             27: "32 VALU writes under a b128 read", 28: "32 VALU writes under a b32 read", 29: "32 VALU writes, no LDS read", 30: "b128, wait, 32 VALU writes"}
+             27: "32 VALU writes under a b128 read", 28: "32 VALU writes under a b32 read", 29: "32 VALU writes, no LDS read", 30: "b128, wait, 32 VALU writes",
+             31: "pk + 32-bit writes under a b128 read", 32: "pk + 32-bit writes, no LDS read", 33: "b128, wait, pk + 32-bit writes", 34: "b128, wait, 4 x (pk + 32-bit writes)",
+             35: "TRUTH: b96, wait, idle, check", 36: "TRUTH: b96, wait, pk lo-half + pk hi-half readers", 37: "TRUTH: b96, wait, pk hi-half reader",
+             38: "TRUTH: b96, wait, pk lo-half reader", 39: "TRUTH: b96, wait, both pk readers, check at once",
+             40: "DENSE 16 x (pk HIGH-half read, copy of low reg)", 41: "DENSE 16 x (pk LOW-half read, copy of low reg)", 42: "DENSE HIGH, long after the read",
+             43: "DENSE HIGH, pair written by v_mov (no LDS)", 44: "DENSE HIGH after ds_read_b64",
+             45: "DENSE HIGH, no idles, address in dest, pair read to the end", 46: "DENSE HIGH x5, no idles", 47: "DENSE LOW x5, no idles",
+             48: "RESULT: b96, 16 pk adds through the HIGH half", 49: "RESULT: b96, 16 pk adds through the LOW half", 50: "RESULT: pair by v_mov, HIGH half",
+             51: "RESULT: b96, idle, HIGH half", 52: "RESULT: 2 x b32, HIGH half",
+             53: "RESULT: plain v_pk_add (lo<-lo, hi<-hi)", 54: "RESULT: v_pk_add op_sel:[0,1], no neg", 55: "RESULT: v_pk_mul op_sel:[0,1]",
+             56: "RESULT: v_pk_add, op_sel:[1,0] (src0)", 57: "RESULT: v_pk_add op_sel:[0,1] op_sel_hi:[1,0] (swap)", 58: "RESULT: v_pk_fma op_sel:[0,1,0]",
+             60: "RESULT: v_pk_add, src1 an SGPR pair, op_sel:[0,1]", 61: "RESULT: v_pk_fma op_sel:[0,0,1] (src2)", 62: "RESULT: what the wrong lanes hold"}
+    co = None
+    for a in list(sys.argv):
+        if a.startswith("--co="):
+            co = a[5:]
+            sys.argv.remove(a)
+    alone = "--alone" in sys.argv
+    sys.argv = [a for a in sys.argv if a != "--alone"]
     if len(sys.argv) > 1:
         kinds = {k: v for k, v in kinds.items() if k in [int(a) for a in sys.argv[1:]]}
     side = torch.cuda.Stream(device=dev)
     for kind, label in kinds.items():
-        for name, kern in (("beside the pooled split forward", k_pool),):
-            out = torch.zeros(8 + 4 * 32, dtype=torch.int32, device=dev)
+        runners = (("alone", k_none),) if alone else (("beside the pooled split forward", k_pool),)
+        if co:
+            runners = tuple(("beside " + spin_names[c][2], k_spin(spin_names[c][0], spin_names[c][1])) for c in co.split(","))
+        for name, kern in runners:
+            out = torch.zeros(8 + 8 * 32, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
             for tr in range(trials):
                 side.wait_stream(torch.cuda.current_stream())
@@ -66,6 +97,9 @@ def main(trials=60):
                 torch.cuda.synchronize()
             o = out.cpu().numpy().view(np.uint32)
             lanes = sorted({int(o[9 + 4 * k]) % 64 for k in range(min(32, int(o[2])))})
+            if kind == 62 and o[2]:
+                for k in range(min(4, int(o[2]))):
+                    print("      results (low, high) = (%08x, %08x); wanted y = %08x in both; the pair's LOW dword x = %08x" % (o[136 + 4 * k], o[139 + 4 * k], o[137 + 4 * k], o[138 + 4 * k]))
             print("%-42s %-32s: %d workgroup runs; first reader != late reader %d times in %d threads%s" % (
                 label + ",", name, o[3], o[0], o[2], ("; lanes seen " + str(lanes)) if lanes else ""))
 
