@@ -70,7 +70,9 @@ def main(trials=60):
              51: "RESULT: b96, idle, HIGH half", 52: "RESULT: 2 x b32, HIGH half",
              53: "RESULT: plain v_pk_add (lo<-lo, hi<-hi)", 54: "RESULT: v_pk_add op_sel:[0,1], no neg", 55: "RESULT: v_pk_mul op_sel:[0,1]",
              56: "RESULT: v_pk_add, op_sel:[1,0] (src0)", 57: "RESULT: v_pk_add op_sel:[0,1] op_sel_hi:[1,0] (swap)", 58: "RESULT: v_pk_fma op_sel:[0,1,0]",
-             60: "RESULT: v_pk_add, src1 an SGPR pair, op_sel:[0,1]", 61: "RESULT: v_pk_fma op_sel:[0,0,1] (src2)", 62: "RESULT: what the wrong lanes hold"}
+             60: "RESULT: v_pk_add, src1 an SGPR pair, op_sel:[0,1]", 61: "RESULT: v_pk_fma op_sel:[0,0,1] (src2)", 62: "RESULT: what the wrong lanes hold",
+             63: "RESULT: v_pk_fma op_sel:[1,0,0] (src0 HIGH)", 64: "RESULT: v_pk_fma op_sel_hi:[0,1,1] (src0 LOW bcast)", 65: "RESULT: v_pk_fma op_sel_hi:[1,1,0] (src2 LOW bcast)",
+             66: "RESULT: v_pk_mov_b32 op_sel:[1,0]"}
     co = None
     for a in list(sys.argv):
         if a.startswith("--co="):
