@@ -186,7 +186,9 @@ def make_step(workload, net, pts, labels, bucket, prefetch=True):
     # (round 4 forked behind the loss: 5.84 -> 5.76 ms then.  The bf16-split GEMMs of this round are persistent workgroups that
     # fill a CU's register file -- nothing co-runs with them -- and under the backward chain's small kernels the branch's FPS
     # stretched the chain: rocprofv3 trace, tools/step_timeline.py.)  cfg2 / cfg5: the FPS chain is the step, top.
-    default_fork = {"msg": "top", "ssg": "sa2"}.get(workload, "top") if pts.shape[-1] <= 8192 else "top"
+    # Round 6 (output-free pooled layers, two workgroups per CU): MSG forked behind sa2 4.964 - 5.005 against 5.010 - 5.049 at the top
+    # (five alternating runs each, one box, gpurun_out r6u); SSG top / sa2 / loss equal within the run-to-run spread (2.46 - 2.50).
+    default_fork = {"msg": "sa2", "ssg": "sa2"}.get(workload, "top") if pts.shape[-1] <= 8192 else "top"
     fork_at = os.environ.get("PN2_BENCH_FORK", default_fork)       # top | sa1 | sa2 | loss | sa2_bwd | sa1_bwd
     # (no geometry branch -- eager launches or --no-prefetch -- means nothing to fork: the step is the plain sequence)
     late_fork = prefetch and fork_at != "top" and workload in ("msg", "ssg")

@@ -80,7 +80,7 @@ def test_make_step_flag_matrix_without_a_geometry_branch():
                 assert bench.make_step(workload, net, pts, None, None, prefetch=False).fork_in_step is False
                 assert not hooks
                 with_branch = bench.make_step(workload, net, pts, None, None, prefetch=True).fork_in_step
-                assert with_branch == (workload in ("msg", "ssg") and (fork or {"msg": "top", "ssg": "sa2"}[workload]) != "top")
+                assert with_branch == (workload in ("msg", "ssg") and (fork or {"msg": "sa2", "ssg": "sa2"}[workload]) != "top")
             finally:
                 os.environ.clear()
                 os.environ.update(env)
