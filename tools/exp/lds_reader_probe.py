@@ -43,7 +43,11 @@ def main(trials=60):
     sink = torch.zeros(256, device=dev)
     probe.spin.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     spin_names = {"bf16": (0, 3000, "a spinner of v_mfma_f32_32x32x16_bf16"), "f32": (1, 1500, "a spinner of v_mfma_f32_32x32x2_f32"),
-                  "valu": (2, 60000, "a spinner of vector fmas (no MFMA)"), "bf16s": (3, 6000, "a spinner of v_mfma_f32_16x16x32_bf16")}
+                  "valu": (2, 60000, "a spinner of vector fmas (no MFMA)"), "bf16s": (3, 6000, "a spinner of v_mfma_f32_16x16x32_bf16"),
+                  "bf16x4": (4, 1500, "v_mfma_f32_32x32x16_bf16, 4 independent accumulators"), "f32x4": (5, 750, "v_mfma_f32_32x32x2_f32, 4 independent accumulators"),
+                  "f16x4": (6, 1500, "v_mfma_f32_32x32x16_f16, 4 independent accumulators"),
+                  "f16s": (7, 6000, "a chain of v_mfma_f32_16x16x32_f16"), "f32s": (8, 6000, "a chain of v_mfma_f32_16x16x4_f32"),
+                  "bf16sx4": (9, 3000, "v_mfma_f32_16x16x32_bf16, 4 independent accumulators")}
 
     def k_spin(kind, iters):
         def f():
