@@ -67,7 +67,7 @@ static inline int64_t pn2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
     X(SPLIT_K256, 1) /* ... the pooled data gradients with C_out = 256 (contraction split over wave pairs) */ \
     X(SPLIT_NARROW, 1) /* ... also on the narrow sa1 forward layers the weight-resident kernels served */ \
     X(SPLIT_RES, 1) /* ... and the fused data + weight gradient of the narrow long layers (split_bwd_res_kernel) */ \
-    X(FUSE_FIRST, 0) /* ... with the FIRST layer's dZ^T x formed in the second layer's fused backward (sa1: dZ1 never reaches memory; pn2_conv1x1_bwd_first).  Exact, -0.9 GB of traffic per MSG step (14.8 -> 13.9 GB), and not faster: in the serial step 96 x 64 243 -> 282 us and 64 x 64 113 -> 140 against the 2 x 53 us of weight-gradient launches it shortens (the dX waves' epilogue gains 48 LDS reads + 192 fmas per chunk on the critical path); step 4.96 -> 4.98 ms: off */ \
+    X(FUSE_FIRST, 1) /* ... with the FIRST layer's dZ^T x formed in the second layer's fused backward (sa1: dZ1 never reaches memory; pn2_conv1x1_bwd_first).  Exact, -0.9 GB of traffic per MSG step (14.7 -> 13.9 GB).  Alone the fused kernels are slower than what they replace (serial step: 96 x 64 243 -> 282 us, 64 x 64 113 -> 140 against the 2 x 53 us of weight-gradient launches they shorten), and with the geometry branch forked at the top of the step the step was too (4.96 -> 4.98 ms: off until the end of round 6); with the branch behind sa2 the captured MSG step measures 4.706 - 4.767 against 4.764 - 4.829 ms and 4.739 - 4.772 against 4.775 - 4.945 (eight and six alternating runs on two boxes), cfg5 MSG 40.3 - 40.9 against 40.1 - 40.8, SSG equal: on */ \
     X(SPLIT_WG2, 1) /* ... its four-wave forms (sa1 of MSG) as two workgroups per CU (alone: 96 -> 128 pooled 244 -> 209 us; cfg5 MSG 41.4 -> 41.0 ms) */ \
     X(POOL_CF, 2) /* the pooled last layers of sa1 WITHOUT their pre-BN output: forward stores nothing, backward from the layer's input (split_bwd_cf_kernel); 1: 128 x 96 only, 2: also 128 x 64 */ \
     X(SPLIT_RES_MIN_TILES_128, 1024) /* ... its 128 x 128 pair from this many 64-row tiles on (below: the streamed pair kernel) */ \

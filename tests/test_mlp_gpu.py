@@ -740,7 +740,7 @@ def test_fused_backward_with_the_first_layers_sums_vs_fp64(dev, P, co, ci):
     c0 dZ1^T x0 + q1 (W0 S + (b0 - mean0) s^T) + q0 s^T with S, s the input's moments."""
     lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
     old_opt = _lib.options()["PN2_FUSE_FIRST"]
-    _lib.set_option("PN2_FUSE_FIRST", 1)               # (off by default: measured slower than the two separate launches)
+    _lib.set_option("PN2_FUSE_FIRST", 1)               # (the default since the end of round 6; set here so that the test says what it tests)
     try:
         _bwd_first_case(dev, lib, st, P, co, ci)
     finally:
