@@ -71,6 +71,20 @@ class FpsStartFeed:
         self.turn = (self.turn + 1) % len(self.host)
 
 
+def capture_error_mode():
+    """`global` (torch's default: an unsafe HIP call from ANY thread fails the capture) unless a process group is alive: the RCCL
+    watchdog thread polls its work events with hipEventQuery, and a poll that lands inside a capture window raised
+    hipErrorStreamCaptureUnsupported in that thread and aborted the rank (round 6: 1 of 12 one-rank `bench.py --gpus 1` launches under
+    torchrun; `tests/test_parallel_gpu.py`).  With a process group the capture restricts its own thread only."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return "thread_local"
+    except Exception:                                   # (a torch build without distributed support)
+        pass
+    return "global"
+
+
 class GraphedStep:
     """``step = GraphedStep(fn)``; ``loss = step()`` replays ``fn`` (zero grads + forward + loss + backward).
 
@@ -117,7 +131,7 @@ class GraphedStep:
         U.set_fps_start_feed(self.feed)
         U.set_capture_scope(object())
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode()):
                 self.loss = fn()
         finally:
             U.set_capture_scope(None)
@@ -164,7 +178,7 @@ class GraphedStep:
             U.set_fps_start_feed(feed)
             U.set_capture_scope(object())
             try:
-                with torch.cuda.graph(graph, pool=pool):
+                with torch.cuda.graph(graph, pool=pool, capture_error_mode=capture_error_mode()):
                     main = torch.cuda.current_stream(device)
                     geo_stream.wait_stream(main)
 

@@ -13,6 +13,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import graph as _graph
+
 
 def _skip_collectives(group=None):
     """No process group, or a single rank (unless PN2_FORCE_COLLECTIVES=1: lets a 1-GPU box exercise RCCL)."""
@@ -308,7 +310,7 @@ def verify_in_graph_record(device, replays=3, spin_cycles=40_000_000):
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(work):
-            with torch.cuda.graph(graph, stream=work):
+            with torch.cuda.graph(graph, stream=work, capture_error_mode=_graph.capture_error_mode()):
                 flags.zero_()
                 torch.cuda._sleep(spin_cycles)
                 flags[0:1].fill_(1.0)
