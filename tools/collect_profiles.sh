@@ -58,7 +58,7 @@ stats cfg5_msg $CFG5_MSG --steps 5 --warmup 2
 # 4. A/B lines of the round's switches (same box, back to back, twice)
 : > $O/ab_switches.txt
 for rep in 1 2; do
-  for v in "PN2_SPLIT=1" "PN2_POOL_CF=0" "PN2_POOL_CF=1" "PN2_POOL_CF=2" "PN2_SPLIT_WG2=0" "PN2_SPLIT_WG2=1" "PN2_FPS_PIECE=128" "PN2_FUSE_FIRST=1" "PN2_SPLIT=0" "PN2_SPLIT_RES=0" \
+  for v in "PN2_SPLIT=1" "PN2_POOL_CF=0" "PN2_POOL_CF=1" "PN2_POOL_CF=2" "PN2_SPLIT_WG2=0" "PN2_SPLIT_WG2=1" "PN2_FPS_PIECE=128" "PN2_FUSE_FIRST=0" "PN2_FUSE_FIRST=1" "PN2_SPLIT=0" "PN2_SPLIT_RES=0" \
            "PN2_SPLIT_NARROW=0" "PN2_SPLIT_WGRAD=0" "PN2_SPLIT_K256=0" "PN2_LAZY_BN=0" "PN2_WIDE_POOL=0" "PN2_BWD_PAIR=0"; do
     for w in msg ssg; do
       env $v python3 bench.py --workload $w --no-cpu-baseline --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], d['ms_per_step'])" $v $w >> $O/ab_switches.txt
