@@ -196,3 +196,21 @@ def test_gloo_run_of_the_oracle_network_equals_per_rank_bn_groups(world):
             assert torch.allclose(res[0][1], net.sa1.mlp_bns[0].running_mean, rtol=1e-6, atol=1e-7)   # per-replica BN
     ref /= world
     assert float((res[0][0] - ref).norm()) <= 1e-6 * float(ref.norm())
+
+
+def test_graph_capture_error_mode_follows_the_process_group():
+    """Round 6: the RCCL watchdog thread polls its work events (hipEventQuery); a poll inside a `global`-mode capture window raised
+    hipErrorStreamCaptureUnsupported in that thread and aborted the rank (1 of 12 one-rank torchrun launches of bench.py).  Captures
+    restrict their own thread only while a process group is alive, and keep torch's default otherwise."""
+    from pointnet12_amd import graph
+    assert not dist.is_initialized()
+    assert graph.capture_error_mode() == "global"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        assert graph.capture_error_mode() == "thread_local"
+    finally:
+        dist.destroy_process_group()
+    assert graph.capture_error_mode() == "global"
